@@ -1,0 +1,192 @@
+"""Generate the committed golden vectors under tests/golden/.
+
+TEST INFRASTRUCTURE.  Run ONLY in the build container (needs /root/reference):
+
+    PYTHONDONTWRITEBYTECODE=1 python -m oracle.gen_golden
+
+It imports the reference modules that are importable offline
+(``src.models.discriminator``, ``src.models.losses``, ``src.models.metrics``),
+runs them on seeded inputs and stores inputs' seeds + expected outputs (data only;
+no reference source text) in:
+
+* ``tests/golden/adversarial_ref.npz``  -- produced by the REFERENCE's own classes;
+* ``tests/golden/unet_oracle.npz``      -- produced by ``oracle.unet_ref.UnetRef`` (the
+  encoder-decoder is third-party upstream): a regression anchor for the
+  oracle and a travelling fixture for the GPU tests.  Its structure is pinned
+  separately by ``tests/golden/unet_r50_trace.json``.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+SEED_WEIGHTS = 1234
+
+
+def stats(t):
+    """Order-independent-ish fingerprint of a tensor: sum, abs-sum, and a strided sample."""
+    f = t.detach().double().flatten()
+    n = f.numel()
+    step = max(1, n // 64)
+    return np.array([f.sum().item(), f.abs().sum().item()], dtype=np.float64), \
+        t.detach().flatten()[::step][:64].clone().numpy()
+
+
+def put(out, key, t):
+    s, sample = stats(t)
+    out[key + "/stats"] = s
+    out[key + "/sample"] = sample
+
+
+def gen_adversarial():
+    sys.path.insert(0, REF)
+    from src.models.discriminator import DomainDiscriminator  # reference
+    from src.models.losses import AdversarialLoss             # reference
+    from src.models.metrics import DomainAdaptationMetrics    # reference
+    from oracle.adversarial_ref import synthetic_batch, adversarial_step
+    from oracle.unet_ref import UnetRef
+
+    out = {}
+    torch.set_num_threads(1)  # fixed reduction order for bit-stable fixtures
+
+    # (1) known-answer losses on fixed [4,1] inputs
+    torch.manual_seed(1)
+    p_s = torch.rand(4, 1)
+    p_t = torch.rand(4, 1)
+    L = AdversarialLoss(lambda_adv=0.001)
+    out["ka/p_s"] = p_s.numpy()
+    out["ka/p_t"] = p_t.numpy()
+    out["ka/d_loss"] = np.float32(L.discriminator_loss(p_s, p_t).item())
+    out["ka/g_loss"] = np.float32(L.generator_loss(p_t).item())
+
+    # (2) discriminator forward / loss / grads / BN state, seeded weights
+    torch.manual_seed(SEED_WEIGHTS)
+    D = DomainDiscriminator(input_channels=3)
+    for k, v in D.state_dict().items():
+        if v.dtype.is_floating_point:
+            put(out, "d_init/" + k, v)
+    src, masks, tgt = synthetic_batch(2, 64, 64, seed=0)
+    D.train()
+    ps = D(src)
+    pt = D(tgt)
+    dl = L.discriminator_loss(ps, pt)
+    dl.backward()
+    out["d/p_s"] = ps.detach().numpy()
+    out["d/p_t"] = pt.detach().numpy()
+    out["d/d_loss"] = np.float32(dl.item())
+    for k, p in D.named_parameters():
+        put(out, "d_grad/" + k, p.grad)
+    pt2 = D(tgt)  # third train-mode forward, as adversarial_trainer.py:108
+    out["d/g_loss"] = np.float32(L.generator_loss(pt2).item())
+    for k, v in D.state_dict().items():
+        if "running" in k:
+            out["d_bn3/" + k] = v.numpy().copy()
+        if "num_batches" in k:
+            out["d_bn3/" + k] = np.int64(v.item())
+
+    # (2b) the restatement must equal the reference bit for bit on this machine
+    from oracle.adversarial_ref import DomainDiscriminatorRef, AdversarialLossRef, DomainAdaptationMetricsRef
+    torch.manual_seed(SEED_WEIGHTS)
+    D2 = DomainDiscriminatorRef(input_channels=3)
+    assert list(D2.state_dict().keys()) == list(D.state_dict().keys())
+    L2 = AdversarialLossRef(0.001)
+    D2.train()
+    ps2, pt2b = D2(src), D2(tgt)
+    dl2 = L2.discriminator_loss(ps2, pt2b)
+    dl2.backward()
+    assert torch.equal(ps2, ps) and torch.equal(pt2b, pt) and torch.equal(dl2, dl)
+    for (k, p), (k2, p2) in zip(D.named_parameters(), D2.named_parameters()):
+        assert k == k2 and torch.equal(p.grad, p2.grad), k
+    assert torch.equal(L2.generator_loss(D2(tgt)), L.generator_loss(pt2))
+    for k, v in D.state_dict().items():
+        assert torch.equal(v, D2.state_dict()[k]), k
+    assert torch.equal(L2.discriminator_loss(p_s, p_t), L.discriminator_loss(p_s, p_t))
+    M2 = DomainAdaptationMetricsRef()
+    M2.update(ps.detach(), pt.detach())
+    M2.update(pt.detach(), ps.detach())
+    out["restatement_bit_exact"] = np.bool_(True)
+
+    # (3) metrics strings after two updates
+    M = DomainAdaptationMetrics()
+    M.update(ps.detach(), pt.detach())
+    M.update(pt.detach(), ps.detach())
+    m = M.get_metrics()
+    assert M2.get_metrics() == m
+    out["metrics/keys"] = np.array(sorted(m.keys()))
+    out["metrics/vals"] = np.array([m[k] for k in sorted(m.keys())])
+
+    # (4) one full adversarial iteration, reference D/loss/metrics + restated step order + UnetRef r18
+    torch.manual_seed(SEED_WEIGHTS)
+    model = UnetRef("resnet18", classes=23)
+    D = DomainDiscriminator(input_channels=3)
+    M = DomainAdaptationMetrics()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    dopt = torch.optim.Adam(D.parameters(), lr=opt.param_groups[0]["lr"])
+    model.train()
+    D.train()
+    r = adversarial_step(model, D, L, opt, dopt, src, masks, tgt, metrics=M)
+    for k in ("seg_loss", "d_loss", "adv_loss", "total"):
+        out["advstep/" + k] = np.float32(r[k].item())
+    for k, v in model.state_dict().items():
+        if v.dtype.is_floating_point and (k.endswith("conv1.weight") and k.startswith("encoder.conv1")
+                                          or k.startswith("segmentation_head") or "blocks.4.conv2" in k
+                                          or k.startswith("encoder.bn1")):
+            put(out, "advstep/model/" + k, v)
+    for k, v in D.state_dict().items():
+        if v.dtype.is_floating_point:
+            put(out, "advstep/D/" + k, v)
+    mm = M.get_metrics()
+    out["advstep/metrics"] = np.array([mm[k] for k in sorted(mm.keys())])
+    np.savez_compressed(os.path.join(GOLD, "adversarial_ref.npz"), **out)
+    print("adversarial_ref.npz:", len(out), "arrays")
+
+
+def gen_unet():
+    from oracle.adversarial_ref import synthetic_batch, segmentation_step
+    from oracle.unet_ref import UnetRef
+
+    out = {}
+    torch.set_num_threads(1)
+    for name in ("resnet18", "resnet50"):
+        torch.manual_seed(SEED_WEIGHTS)
+        model = UnetRef(name, classes=23)
+        model.train()
+        x, y, _ = synthetic_batch(2, 64, 64, seed=0)
+        feats = model.encoder(x)
+        for i, f in enumerate(feats[1:]):
+            put(out, f"{name}/feat{i + 1}", f)
+        # fresh model so BN running stats see exactly one forward
+        torch.manual_seed(SEED_WEIGHTS)
+        model = UnetRef(name, classes=23)
+        model.train()
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+        opt.zero_grad()
+        logits = model(x)
+        loss = torch.nn.functional.cross_entropy(logits, y)
+        loss.backward()
+        out[f"{name}/loss"] = np.float32(loss.item())
+        put(out, f"{name}/logits", logits)
+        grads = {k: p.grad.clone() for k, p in model.named_parameters()}
+        for k in ("encoder.conv1.weight", "encoder.bn1.weight", "encoder.bn1.bias", "encoder.layer2.0.conv1.weight",
+                  "encoder.layer2.0.downsample.0.weight", "encoder.layer4.1.bn2.weight",
+                  "decoder.blocks.0.conv1.0.weight", "decoder.blocks.4.conv2.0.weight", "decoder.blocks.4.conv2.1.bias",
+                  "segmentation_head.0.weight", "segmentation_head.0.bias"):
+            put(out, f"{name}/grad/{k}", grads[k])
+        opt.step()
+        sd = model.state_dict()
+        for k in ("encoder.conv1.weight", "encoder.bn1.running_mean", "encoder.bn1.running_var",
+                  "decoder.blocks.4.conv2.1.running_var", "segmentation_head.0.weight", "segmentation_head.0.bias"):
+            put(out, f"{name}/after_adam/{k}", sd[k])
+    np.savez_compressed(os.path.join(GOLD, "unet_oracle.npz"), **out)
+    print("unet_oracle.npz:", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    os.makedirs(GOLD, exist_ok=True)
+    gen_adversarial()
+    gen_unet()
