@@ -1,0 +1,157 @@
+/*
+ * udaseg.h -- C-ABI of libudaseg_hip.so: the MI355X (gfx950) kernels behind the segmentation /
+ * domain-adaptation training hot path of bempt/uda_aerial_semantic_segmentation_research.
+ *
+ * The reference has no FFI layer: its boundary is the torch.nn.Module / callable protocol its trainers
+ * use.  Each entry point below therefore names the reference call it replaces (file:line
+ * under the reference tree); the Python side (uda_aerial_semantic_segmentation_research_amd/) mirrors the
+ * reference's classes on top of these symbols via ctypes.  INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *  - plain pointers + sizes only; every pointer is DEVICE memory owned by the caller (PyTorch);
+ *    the library allocates nothing and never synchronises the host;
+ *  - `stream` is a hipStream_t passed as void* (0 = default stream); all launches are asynchronous;
+ *  - activations are NHWC fp32 with a channel count that is a multiple of 4 (images are padded 3->4,
+ *    logits 23->24 by udaseg_nchw_to_nhwc / the head conv); conv weights are OHWI [co][kh][kw][ci];
+ *  - return 0 on success, a negative UDASEG_E_* otherwise; udaseg_last_error() gives the message
+ *    (thread-local).  No C++ exception crosses the boundary.
+ */
+#ifndef UDASEG_H
+#define UDASEG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UDASEG_OK 0
+#define UDASEG_E_BADARG (-1)
+#define UDASEG_E_UNSUPPORTED (-2)
+#define UDASEG_E_WORKSPACE (-3)
+#define UDASEG_E_HIP (-4)
+
+#define UDASEG_ACT_NONE 0
+#define UDASEG_ACT_LEAKY 1 /* y = x > 0 ? x : slope * x ; slope 0 => ReLU */
+
+int udaseg_version(void);
+const char* udaseg_last_error(void);
+/* number of HIP devices visible to the library (0 on a CPU-only box; never initialises a context) */
+int udaseg_device_count(void);
+
+/* Geometry of one 2-D convolution, NHWC. hi/wi/ci: input; ho/wo/co: output; square stride, symmetric pad.
+ * ci and co are the PHYSICAL channel counts (multiples of 4). */
+typedef struct {
+  int n, hi, wi, ci;
+  int ho, wo, co;
+  int kh, kw, stride, pad;
+} udaseg_conv_desc;
+
+/* ---- convolutions: torch.nn.functional.conv2d reached through smp.Unet.forward (reference
+ *      src/models/train.py:341, src/models/adversarial_trainer.py:104) and DomainDiscriminator.forward
+ *      (src/models/discriminator.py:54).  Implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32). ---- */
+
+/* y[n,ho,wo,co] (+)= conv(x, w) + bias, then optional activation. bias may be NULL. */
+int udaseg_conv2d_fwd(const udaseg_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
+                      int act, float slope, int accumulate, void* stream);
+/* dx[n,hi,wi,ci] (+)= conv_transpose(dy, w).  w_t is the dgrad packing [ci][kh][kw][co] made by
+ * udaseg_pack_dgrad_weights.  Autograd of the convs above: loss.backward() at train.py:343. */
+int udaseg_conv2d_dgrad(const udaseg_conv_desc* d, const float* dy, const float* w_t, float* dx, int accumulate,
+                        void* stream);
+/* dw[co][kh][kw][ci] (+)= sum over pixels of dy (x) x.  If !accumulate dw is overwritten.
+ * Split-K partials are combined with fp32 atomics. */
+int udaseg_conv2d_wgrad(const udaseg_conv_desc* d, const float* x, const float* dy, float* dw, int accumulate,
+                        void* stream);
+/* w[co][kh*kw][ci] -> w_t[ci][kh*kw][co] */
+int udaseg_pack_dgrad_weights(const udaseg_conv_desc* d, const float* w, float* w_t, void* stream);
+/* Conv FLOPs (2*MAC) of one call, for roofline accounting. */
+double udaseg_conv_flops(const udaseg_conv_desc* d);
+
+/* ---- layout: the DataLoader hands NCHW images (train.py:337); kernels want NHWC with C%4==0 ---- */
+/* x[n][c][h][w] -> y[n][h][w][cpad], channels c..cpad-1 zero-filled */
+int udaseg_nchw_to_nhwc(const float* x, float* y, int n, int c, int h, int w, int cpad, void* stream);
+
+/* ---- batch norm (training mode) + activation: torch.nn.BatchNorm2d/ReLU/LeakyReLU inside smp.Unet and
+ *      discriminator.py:21-33.  sums = [2][c] doubles (sum, sum of squares), zeroed by the caller. ---- */
+int udaseg_bn_stats(const float* y, int64_t pixels, int c, double* sums, void* stream);
+/* z = act(gamma*(y-mean)*rstd + beta (+ residual)); writes save_mean/save_rstd [c]; updates running stats
+ * (momentum, unbiased variance) when running_mean != NULL.  residual may be NULL. */
+int udaseg_bn_apply(const float* y, const double* sums, const float* gamma, const float* beta, const float* residual,
+                    float* z, int64_t pixels, int c, float eps, float momentum, float* running_mean,
+                    float* running_var, float* save_mean, float* save_rstd, int act, float slope, void* stream);
+/* eval mode: z = act(gamma*(y-running_mean)/sqrt(running_var+eps) + beta (+ residual)) */
+int udaseg_bn_apply_eval(const float* y, const float* gamma, const float* beta, const float* running_mean,
+                         const float* running_var, const float* residual, float* z, int64_t pixels, int c, float eps,
+                         int act, float slope, void* stream);
+/* backward, pass 1: g = dz * act'(z); bsums[0][c] += sum g, bsums[1][c] += sum g*xhat (doubles, caller-zeroed) */
+int udaseg_bn_bwd_reduce(const float* dz, const float* z, const float* y, const float* save_mean,
+                         const float* save_rstd, int64_t pixels, int c, double* bsums, int act, float slope,
+                         void* stream);
+/* backward, pass 2: dy (+)= gamma*rstd*(g - mean(g) - xhat*mean(g*xhat)); dres (+)= g if dres != NULL;
+ * dgamma/dbeta (+)= from bsums. */
+int udaseg_bn_bwd_apply(const float* dz, const float* z, const float* y, const float* save_mean,
+                        const float* save_rstd, const float* gamma, const double* bsums, float* dy, float* dres,
+                        float* dgamma, float* dbeta, int64_t pixels, int c, int act, float slope, int accumulate_dy,
+                        int accumulate_dres, int accumulate_param, void* stream);
+/* plain activation backward for a conv+bias+act epilogue (discriminator layer 1): dy = dz * act'(z) */
+int udaseg_act_bwd(const float* dz, const float* z, float* dy, int64_t count, int act, float slope, void* stream);
+/* out[c] (+)= sum over pixels of x[p][c]  (bias gradients) */
+int udaseg_channel_sum(const float* x, int64_t pixels, int c, float* out,
+                       int accumulate, void* stream);
+
+/* ---- pooling / resize glue inside smp.Unet ---- */
+/* max_pool2d(3, 2, 1): y[n,ho,wo,c], idx = argmax tap (0..8, first max in scan order) */
+int udaseg_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int n, int h, int w, int c, void* stream);
+int udaseg_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float* dx, int n, int h, int w, int c, int accumulate,
+                            void* stream);
+/* out[n,2h,2w,ca+cb] = cat(nearest_x2(a[n,h,w,ca]), skip[n,2h,2w,cb]); skip may be NULL (cb = 0) */
+int udaseg_upsample2x_concat_fwd(const float* a, const float* skip, float* out, int n, int h, int w, int ca, int cb,
+                                 void* stream);
+/* da (+)= 2x2 sum of dout[..., :ca]; dskip (+)= dout[..., ca:] */
+int udaseg_upsample2x_concat_bwd(const float* dout, float* da, float* dskip, int n, int h, int w, int ca, int cb,
+                                 int accumulate_da, int accumulate_dskip, void* stream);
+
+/* ---- per-pixel cross entropy: nn.CrossEntropyLoss() at train.py:208,342 (mean, no weights/ignore) ----
+ * logits[p][ldc] with `classes` valid channels; target int64[p]; lse[p] saved for backward;
+ * partials: scratch of udaseg_ce_partials() doubles; loss: 1 float. */
+int udaseg_ce_partials(void);
+int udaseg_ce_fwd(const float* logits, const int64_t* target, int64_t pixels, int classes, int ldc, float* lse,
+                  double* partials, float* loss, void* stream);
+/* dlogits[p][ldc] = (softmax - onehot) * (*grad_out) / pixels; pad channels written as 0 */
+int udaseg_ce_bwd(const float* logits, const int64_t* target, const float* lse, const float* grad_out, int64_t pixels,
+                  int classes, int ldc, float* dlogits, void* stream);
+
+/* ---- discriminator tail + adversarial BCE: discriminator.py:37-42, losses.py:18-51 ---- */
+/* pooled[n][c] = mean over hw of z; p[n] = sigmoid(dot(pooled[n], w) + b).  partial: [n][splits][c] floats */
+int udaseg_gap_splits(int hw);
+int udaseg_gap_linear_sigmoid_fwd(const float* z, const float* w, const float* b, float* partial, float* pooled,
+                                  float* p, int n, int hw, int c, void* stream);
+/* given dp[n]: dw (+)=, db (+)=, dz[n][hw][c] = dp*p*(1-p)*w[c]/hw broadcast */
+int udaseg_gap_linear_sigmoid_bwd(const float* dp, const float* p, const float* pooled, const float* w, float* dz,
+                                  float* dw, float* db, int n, int hw, int c, int accumulate_param, void* stream);
+/* loss (+)= weight * mean(softplus(x) - x*label)   (BCEWithLogits on whatever x is: reference feeds probabilities) */
+int udaseg_bce_logits_fwd(const float* x, int n, float label, float weight, float* loss, int accumulate, void* stream);
+/* dx = (*grad_out) * weight * (sigmoid(x) - label) / n */
+int udaseg_bce_logits_bwd(const float* x, int n, float label, float weight, const float* grad_out, float* dx,
+                          int accumulate, void* stream);
+
+/* ---- Adam: torch.optim.Adam(...).step() at train.py:344,461; adversarial_trainer.py:56-59,98,114 ----
+ * flat fp32 arrays; bc1 = 1-beta1^t, bc2 = 1-beta2^t computed by the caller. */
+int udaseg_adam_flat(float* p, const float* g, float* m, float* v, int64_t count, float lr, float beta1, float beta2,
+                     float eps, float bc1, float bc2, void* stream);
+
+/* ---- small utilities ---- */
+int udaseg_fill_f32(float* p, int64_t count, float value, void* stream);
+int udaseg_axpy_f32(float* y, const float* x, int64_t count, float alpha, void* stream); /* y += alpha*x */
+
+/* ---- live kernel timing for bench.py's roofline leg: HIP events bracket every launch of the conv
+ *      kernel families on the launch stream while enabled. ---- */
+int udaseg_prof_enable(int on);
+int udaseg_prof_reset(void);
+/* family: 0 = igemm fwd/dgrad, 1 = wgrad.  Synchronises the recorded events (call outside timed regions). */
+int udaseg_prof_read(int family, double* total_ms, double* total_flops, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UDASEG_H */

@@ -1,0 +1,368 @@
+"""GPU parity, kernel level: every C-ABI entry point against a plain PyTorch fp32 CPU reference of the same op.
+
+Tolerance: north_star's 1e-3 relative (fp32), applied norm-wise per tensor (max |diff| / max |ref|); most ops
+land around 1e-6.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def K():
+    from uda_aerial_semantic_segmentation_research_amd import _lib, kernels
+    _lib.require_gpu()
+    return kernels
+
+
+def dev(t):
+    return t.to("cuda")
+
+
+def nhwc(t):  # NCHW cpu -> NHWC cuda contiguous
+    return t.permute(0, 2, 3, 1).contiguous().to("cuda")
+
+
+def nchw(t):  # NHWC cuda -> NCHW cpu
+    return t.detach().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def relerr(got, ref):
+    got, ref = got.double(), ref.double()
+    return ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+
+
+def assert_close(got, ref, what, rtol=RTOL):
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), f"{what}: non-finite values"
+    e = relerr(got, ref)
+    if e > rtol:
+        d = (got.double() - ref.double()).abs()
+        idx = torch.nonzero(d == d.max())[0].tolist()
+        frac = (d > rtol * ref.abs().max()).double().mean().item()
+        raise AssertionError(f"{what}: rel err {e:.3e} > {rtol:g}; worst at {idx} got {got[tuple(idx)]:.6g} "
+                             f"ref {ref[tuple(idx)]:.6g}; {100 * frac:.2f}% elements off; shape {tuple(ref.shape)}")
+
+
+def w_ohwi(w):  # [co,ci,kh,kw] cpu -> [co,kh,kw,ci] cuda
+    return w.permute(0, 2, 3, 1).contiguous().to("cuda")
+
+
+CONV_CASES = [
+    # n, h, w, ci, co, k, stride, pad                         what it stands for
+    (2, 16, 16, 64, 64, 3, 1, 1),     # layer1 3x3
+    (2, 16, 16, 64, 128, 3, 2, 1),    # layerN.0.conv1 stride 2 (dgrad parity classes 1/2/2/4 taps)
+    (2, 16, 16, 64, 128, 1, 2, 0),    # downsample 1x1/2 (three empty dgrad classes)
+    (1, 8, 8, 256, 256, 3, 1, 1),     # deep layer -> 64x64 tile path
+    (2, 32, 32, 4, 64, 7, 2, 3),      # stem 7x7/2 on the 3->4 padded image (Ci < 32: several taps per K-tile)
+    (2, 32, 32, 4, 64, 4, 2, 1),      # discriminator conv0 4x4/2
+    (1, 16, 16, 64, 128, 4, 2, 1),    # discriminator conv1
+    (1, 24, 24, 32, 16, 3, 1, 1),     # decoder tail Co = 16 (N tile padded to 32)
+    (1, 24, 24, 16, 24, 3, 1, 1),     # head 16 -> 23(+1)
+    (1, 12, 20, 192, 64, 3, 1, 1),    # decoder conv1 after concat, non-square, Ci not a power of two
+    (3, 9, 7, 8, 36, 3, 1, 1),        # ragged everything: M, N, K tails
+    (1, 5, 5, 8, 8, 3, 2, 1),         # odd extent with stride 2
+    (2, 16, 16, 64, 256, 1, 1, 0),    # bottleneck 1x1
+    (1, 64, 64, 64, 64, 3, 1, 1),     # 128x64 tile path? (M = 4096 -> small) keep for coverage
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[("n%d_%dx%d_ci%d_co%d_k%d_s%d_p%d" % c) for c in CONV_CASES])
+def test_conv_fwd_dgrad_wgrad(K, case):
+    n, h, w, ci, co, k, s, p = case
+    g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    x = torch.randn(n, ci, h, w, generator=g)
+    wt = torch.randn(co, ci, k, k, generator=g) / math.sqrt(ci * k * k)
+    bias = torch.randn(co, generator=g)
+    xr = x.clone().requires_grad_(True)
+    wr = wt.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, bias, stride=s, padding=p)
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy)
+
+    d = K.conv_desc(n, h, w, ci, co, k, s, p)
+    xd, wd, bd = nhwc(x), w_ohwi(wt), dev(bias)
+    y = torch.full((n, d.ho, d.wo, co), float("nan"), device="cuda")
+    K.conv2d_fwd(d, xd, wd, bd, y)
+    assert_close(nchw(y), y_ref.detach(), "fwd")
+
+    # fused bias + LeakyReLU epilogue and accumulate
+    y2 = torch.ones((n, d.ho, d.wo, co), device="cuda")
+    K.conv2d_fwd(d, xd, wd, bd, y2, act=1, slope=0.2, accumulate=True)
+    assert_close(nchw(y2), F.leaky_relu(y_ref.detach(), 0.2) + 1.0, "fwd+leaky+acc")
+
+    dyd = nhwc(dy)
+    wtp = torch.empty((ci, k, k, co), device="cuda")
+    K.pack_dgrad_weights(d, wd, wtp)
+    assert torch.equal(wtp.cpu(), wt.permute(1, 2, 3, 0).contiguous()), "pack_dgrad_weights"
+    dx = torch.full((n, h, w, ci), float("nan"), device="cuda")
+    K.conv2d_dgrad(d, dyd, wtp, dx)
+    assert_close(nchw(dx), xr.grad, "dgrad")
+    dx2 = torch.full((n, h, w, ci), 2.0, device="cuda")
+    K.conv2d_dgrad(d, dyd, wtp, dx2, accumulate=True)
+    assert_close(nchw(dx2), xr.grad + 2.0, "dgrad+acc")
+
+    dw = torch.full((co, k, k, ci), float("nan"), device="cuda")
+    K.conv2d_wgrad(d, xd, dyd, dw)
+    assert_close(dw.cpu().permute(0, 3, 1, 2), wr.grad, "wgrad")
+    dw2 = torch.full((co, k, k, ci), 0.5, device="cuda")
+    K.conv2d_wgrad(d, xd, dyd, dw2, accumulate=True)
+    assert_close(dw2.cpu().permute(0, 3, 1, 2), wr.grad + 0.5, "wgrad+acc")
+
+
+def test_conv_identity_weights_asymmetric(K):
+    """A = I check with an asymmetric operand: catches a transposed C-write or a swapped fragment map."""
+    n, h, w, c = 1, 8, 8, 64
+    x = torch.arange(n * h * w * c, dtype=torch.float32).reshape(n, h, w, c) * 1e-3
+    wt = torch.zeros(c, 1, 1, c)
+    for o in range(c):
+        wt[o, 0, 0, (o + 5) % c] = 1.0 + o          # permutation + per-output scale: asymmetric
+    d = K.conv_desc(n, h, w, c, c, 1, 1, 0)
+    y = torch.empty((n, h, w, c), device="cuda")
+    K.conv2d_fwd(d, x.cuda(), wt.cuda(), None, y)
+    ref = torch.stack([x[..., (o + 5) % c] * (1.0 + o) for o in range(c)], dim=-1)
+    assert torch.equal(y.cpu(), ref)
+
+
+def test_conv_large_tiles(K):
+    """Shapes big enough to take the 128x128 / 128x64 tile paths and split-K wgrad; reference = fp64 on CPU subsample."""
+    for (n, h, w, ci, co) in [(8, 96, 96, 64, 64), (8, 80, 80, 64, 128)]:
+        g = torch.Generator().manual_seed(7)
+        x = torch.randn(n, ci, h, w, generator=g)
+        wt = torch.randn(co, ci, 3, 3, generator=g) / math.sqrt(ci * 9)
+        d = K.conv_desc(n, h, w, ci, co, 3, 1, 1)
+        y = torch.empty((n, h, w, co), device="cuda")
+        K.conv2d_fwd(d, nhwc(x), w_ohwi(wt), None, y)
+        y_ref = F.conv2d(x, wt, None, padding=1)
+        assert_close(nchw(y), y_ref, f"fwd big {ci}->{co}")
+        dy = torch.randn(y_ref.shape, generator=g)
+        dw = torch.empty((co, 3, 3, ci), device="cuda")
+        K.conv2d_wgrad(d, nhwc(x), nhwc(dy), dw)
+        dw_ref = torch.nn.grad.conv2d_weight(x, wt.shape, dy, padding=1)
+        assert_close(dw.cpu().permute(0, 3, 1, 2), dw_ref, f"wgrad big {ci}->{co}")
+        wtp = torch.empty((ci, 3, 3, co), device="cuda")
+        K.pack_dgrad_weights(d, w_ohwi(wt), wtp)
+        dx = torch.empty((n, h, w, ci), device="cuda")
+        K.conv2d_dgrad(d, nhwc(dy), wtp, dx)
+        dx_ref = torch.nn.grad.conv2d_input(x.shape, wt, dy, padding=1)
+        assert_close(nchw(dx), dx_ref, f"dgrad big {ci}->{co}")
+
+
+@pytest.mark.parametrize("c", [16, 64, 24, 512, 2048])
+@pytest.mark.parametrize("act,slope,with_res", [(0, 0.0, False), (1, 0.0, True), (1, 0.2, False)])
+def test_bn_train_fwd_bwd(K, c, act, slope, with_res):
+    n, h, w = 2, 6, 10
+    g = torch.Generator().manual_seed(c + act)
+    x = (torch.randn(n, c, h, w, generator=g) * 2 + 0.5).requires_grad_(True)
+    res = torch.randn(n, c, h, w, generator=g).requires_grad_(True) if with_res else None
+    bn = torch.nn.BatchNorm2d(c)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(c, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(c, generator=g))
+        bn.running_mean.copy_(torch.randn(c, generator=g))
+        bn.running_var.copy_(torch.rand(c, generator=g) + 0.5)
+    rm0, rv0 = bn.running_mean.clone(), bn.running_var.clone()
+    bn.train()
+    u = bn(x)
+    if with_res:
+        u = u + res
+    z_ref = F.leaky_relu(u, slope) if act else u
+    dz = torch.randn(z_ref.shape, generator=g)
+    z_ref.backward(dz)
+
+    yd = nhwc(x.detach())
+    sums = torch.zeros(2 * c, dtype=torch.float64, device="cuda")
+    K.bn_stats(yd, sums)
+    z = torch.empty_like(yd)
+    rm, rv = dev(rm0), dev(rv0)
+    sm, sr = torch.empty(c, device="cuda"), torch.empty(c, device="cuda")
+    gam, bet = dev(bn.weight.detach()), dev(bn.bias.detach())
+    resd = nhwc(res.detach()) if with_res else None
+    K.bn_apply(yd, sums, gam, bet, resd, z, bn.eps, bn.momentum, rm, rv, sm, sr, act, slope)
+    assert_close(nchw(z), z_ref.detach(), "bn fwd")
+    assert_close(rm.cpu(), bn.running_mean, "running_mean", 1e-5)
+    assert_close(rv.cpu(), bn.running_var, "running_var", 1e-5)
+
+    bs = torch.zeros(2 * c, dtype=torch.float64, device="cuda")
+    dzd = nhwc(dz)
+    K.bn_bwd_reduce(dzd, z, yd, sm, sr, bs, act, slope)
+    dy = torch.empty_like(yd)
+    dres = torch.empty_like(yd) if with_res else None
+    dg, db = torch.empty(c, device="cuda"), torch.empty(c, device="cuda")
+    K.bn_bwd_apply(dzd, z, yd, sm, sr, gam, bs, dy, dres, dg, db, act, slope)
+    assert_close(nchw(dy), x.grad, "bn dx")
+    assert_close(dg.cpu(), bn.weight.grad, "bn dgamma")
+    assert_close(db.cpu(), bn.bias.grad, "bn dbeta")
+    if with_res:
+        assert_close(nchw(dres), res.grad, "bn dres")
+    # eval mode
+    bn.eval()
+    with torch.no_grad():
+        ze_ref = bn(x.detach())
+        if with_res:
+            ze_ref = ze_ref + res.detach()
+        ze_ref = F.leaky_relu(ze_ref, slope) if act else ze_ref
+    ze = torch.empty_like(yd)
+    K.bn_apply_eval(yd, gam, bet, rm, rv, resd, ze, bn.eps, act, slope)
+    assert_close(nchw(ze), ze_ref, "bn eval")
+
+
+def test_act_bwd_and_channel_sum(K):
+    g = torch.Generator().manual_seed(3)
+    z = torch.randn(2, 5, 7, 24, generator=g)
+    dz = torch.randn(2, 5, 7, 24, generator=g)
+    dy = torch.empty(2, 5, 7, 24, device="cuda")
+    K.act_bwd(dz.cuda(), z.cuda(), dy, 1, 0.2)
+    assert_close(dy.cpu(), dz * torch.where(z > 0, 1.0, 0.2), "act_bwd")
+    out = torch.full((24,), 3.0, device="cuda")
+    K.channel_sum(dz.cuda(), out, accumulate=False)
+    assert_close(out.cpu(), dz.sum(dim=(0, 1, 2)), "channel_sum", 1e-5)
+    K.channel_sum(dz.cuda(), out, accumulate=True)
+    assert_close(out.cpu(), 2 * dz.sum(dim=(0, 1, 2)), "channel_sum acc", 1e-5)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 16, 16), (1, 8, 7, 9), (2, 16, 2, 2)])
+def test_maxpool(K, shape):
+    g = torch.Generator().manual_seed(1)
+    x = torch.relu(torch.randn(*shape, generator=g)).requires_grad_(True)   # many exact ties at 0, like post-ReLU
+    y_ref = F.max_pool2d(x, 3, 2, 1)
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy)
+    y, idx = K.maxpool_fwd(nhwc(x.detach()))
+    assert torch.equal(nchw(y), y_ref.detach())
+    dx = torch.full((shape[0], shape[2], shape[3], shape[1]), float("nan"), device="cuda")
+    K.maxpool_bwd(nhwc(dy), idx, dx)
+    assert_close(nchw(dx), x.grad, "maxpool bwd (tie rule)", 1e-6)
+
+
+@pytest.mark.parametrize("ca,cb", [(32, 0), (64, 64), (512, 256)])
+def test_upsample_concat(K, ca, cb):
+    g = torch.Generator().manual_seed(2)
+    a = torch.randn(2, ca, 5, 6, generator=g).requires_grad_(True)
+    s = torch.randn(2, cb, 10, 12, generator=g).requires_grad_(True) if cb else None
+    up = F.interpolate(a, scale_factor=2.0, mode="nearest")
+    ref = torch.cat([up, s], dim=1) if cb else up
+    dout = torch.randn(ref.shape, generator=g)
+    ref.backward(dout)
+    out = K.upsample2x_concat_fwd(nhwc(a.detach()), nhwc(s.detach()) if cb else None)
+    assert torch.equal(nchw(out), ref.detach())
+    da = torch.empty((2, 5, 6, ca), device="cuda")
+    ds = torch.empty((2, 10, 12, cb), device="cuda") if cb else None
+    K.upsample2x_concat_bwd(nhwc(dout), da, ds, ca, cb)
+    assert_close(nchw(da), a.grad, "upcat da", 1e-6)
+    if cb:
+        assert torch.equal(nchw(ds), s.grad)
+
+
+def test_nchw_to_nhwc(K):
+    x = torch.randn(3, 3, 10, 14)
+    y = K.nchw_to_nhwc(x.cuda(), 4)
+    assert y.shape == (3, 10, 14, 4)
+    assert torch.equal(y[..., :3].cpu(), x.permute(0, 2, 3, 1))
+    assert float(y[..., 3].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("classes,ldc", [(23, 24), (4, 4), (17, 20)])
+def test_cross_entropy(K, classes, ldc):
+    from uda_aerial_semantic_segmentation_research_amd import _lib
+    g = torch.Generator().manual_seed(5)
+    n, h, w = 2, 9, 11
+    logits = (torch.randn(n, classes, h, w, generator=g) * 3).requires_grad_(True)
+    tgt = torch.randint(0, classes, (n, h, w), generator=g)
+    loss_ref = F.cross_entropy(logits, tgt)
+    (loss_ref * 0.7).backward()
+    buf = torch.full((n, h, w, ldc), 7.0, device="cuda")       # pad channels hold junk on purpose
+    buf[..., :classes] = logits.detach().permute(0, 2, 3, 1).cuda()
+    pixels = n * h * w
+    lse = torch.empty(pixels, device="cuda")
+    partials = torch.empty(_lib.load().udaseg_ce_partials(), dtype=torch.float64, device="cuda")
+    loss = torch.empty((), device="cuda")
+    K.ce_fwd(buf, tgt.cuda(), pixels, classes, ldc, lse, partials, loss)
+    assert abs(loss.item() - loss_ref.item()) <= 1e-5 * abs(loss_ref.item())
+    gout = torch.tensor(0.7, device="cuda")
+    dl = torch.full((n, h, w, ldc), float("nan"), device="cuda")
+    K.ce_bwd(buf, tgt.cuda(), lse, gout, pixels, classes, ldc, dl)
+    assert_close(dl[..., :classes].cpu().permute(0, 3, 1, 2), logits.grad, "ce bwd", 1e-5)
+    if ldc > classes:
+        assert float(dl[..., classes:].abs().max()) == 0.0
+
+
+def test_cross_entropy_extreme_logits(K):
+    """Large-magnitude logits: the max-shifted log-sum-exp must not overflow (torch's own behaviour)."""
+    from uda_aerial_semantic_segmentation_research_amd import _lib
+    logits = torch.tensor([[[[80.0]], [[-90.0]], [[0.0]], [[79.0]]]])      # [1,4,1,1]
+    tgt = torch.tensor([[[1]]])
+    ref = F.cross_entropy(logits, tgt)
+    buf = logits.permute(0, 2, 3, 1).contiguous().cuda()
+    lse = torch.empty(1, device="cuda")
+    partials = torch.empty(_lib.load().udaseg_ce_partials(), dtype=torch.float64, device="cuda")
+    loss = torch.empty((), device="cuda")
+    K.ce_fwd(buf, tgt.cuda(), 1, 4, 4, lse, partials, loss)
+    assert math.isfinite(loss.item()) and abs(loss.item() - ref.item()) < 1e-4 * ref.item()
+
+
+def test_gap_linear_sigmoid(K):
+    g = torch.Generator().manual_seed(9)
+    n, c, h, w = 3, 512, 4, 6
+    z = torch.randn(n, c, h, w, generator=g).requires_grad_(True)
+    lin = torch.nn.Linear(c, 1)
+    p_ref = torch.sigmoid(lin(F.adaptive_avg_pool2d(z, 1).flatten(1)))
+    dp = torch.randn(n, 1, generator=g)
+    p_ref.backward(dp)
+    wd, bd = lin.weight.detach().reshape(-1).cuda(), lin.bias.detach().cuda()
+    p, pooled = K.gap_linear_sigmoid_fwd(nhwc(z.detach()), wd, bd)
+    assert_close(p.cpu(), p_ref.detach(), "gap/linear/sigmoid fwd", 1e-5)
+    dz = torch.empty((n, h, w, c), device="cuda")
+    dw, db = torch.empty(c, device="cuda"), torch.empty(1, device="cuda")
+    K.gap_linear_sigmoid_bwd(dp.cuda(), p, pooled, wd, dz, dw, db)
+    assert_close(nchw(dz), z.grad, "gap bwd dz", 1e-5)
+    assert_close(dw.cpu(), lin.weight.grad.reshape(-1), "gap bwd dw", 1e-5)
+    assert_close(db.cpu(), lin.bias.grad, "gap bwd db", 1e-5)
+
+
+def test_bce_with_logits_known_answers(K, golden_dir):
+    """The reference's AdversarialLoss on its fixed [4,1] inputs (vectors made by importing src.models.losses)."""
+    import os
+    import numpy as np
+    gold = np.load(os.path.join(golden_dir, "adversarial_ref.npz"))
+    p_s, p_t = torch.from_numpy(gold["ka/p_s"]).cuda(), torch.from_numpy(gold["ka/p_t"]).cuda()
+    loss = torch.empty((), device="cuda")
+    K.bce_logits_fwd(p_s, 1.0, 0.5, loss, accumulate=False)
+    K.bce_logits_fwd(p_t, 0.0, 0.5, loss, accumulate=True)
+    assert abs(loss.item() - float(gold["ka/d_loss"])) < 1e-6
+    K.bce_logits_fwd(p_t, 1.0, 0.001, loss, accumulate=False)
+    assert abs(loss.item() - float(gold["ka/g_loss"])) < 1e-9
+    x = p_t.cpu().clone().requires_grad_(True)
+    (0.001 * F.binary_cross_entropy_with_logits(x, torch.ones_like(x)) * 2.0).backward()
+    dx = torch.empty(4, 1, device="cuda")
+    K.bce_logits_bwd(p_t, 1.0, 0.001, torch.tensor(2.0, device="cuda"), dx)
+    assert_close(dx.cpu(), x.grad, "bce bwd", 1e-5)
+
+
+@pytest.mark.parametrize("count", [4096, 1027])
+def test_adam_matches_torch(K, count):
+    g = torch.Generator().manual_seed(11)
+    p0 = torch.randn(count, generator=g)
+    p_ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([p_ref], lr=1e-3)
+    pd = p0.clone().cuda()
+    m, v = torch.zeros(count, device="cuda"), torch.zeros(count, device="cuda")
+    for t in range(1, 4):
+        grad = torch.randn(count, generator=g) * (10.0 ** (t - 2))
+        p_ref.grad = grad.clone()
+        opt.step()
+        K.adam_flat(pd, grad.cuda(), m, v, count, 1e-3, 0.9, 0.999, 1e-8, 1 - 0.9 ** t, 1 - 0.999 ** t)
+    assert_close(pd.cpu(), p_ref.detach(), "adam params", 1e-6)
+
+
+def test_bad_arguments_raise(K):
+    d = K.conv_desc(1, 8, 8, 6, 8, 3, 1, 1)    # ci not a multiple of 4
+    t = torch.empty(1024, device="cuda")
+    with pytest.raises(RuntimeError, match="multiples of 4"):
+        K.conv2d_fwd(d, t, t, None, t)

@@ -1,0 +1,96 @@
+"""ctypes binding of libudaseg_hip.so (the C-ABI declared in include/udaseg.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails, a RuntimeError is raised.
+Build it with ``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C <pkg>/csrc``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libudaseg_hip.so")
+
+ACT_NONE = 0
+ACT_LEAKY = 1  # slope 0 => ReLU
+
+
+class ConvDesc(C.Structure):
+    """udaseg_conv_desc"""
+    _fields_ = [(k, C.c_int) for k in ("n", "hi", "wi", "ci", "ho", "wo", "co", "kh", "kw", "stride", "pad")]
+
+
+_P = C.c_void_p
+_I = C.c_int
+_L = C.c_int64
+_F = C.c_float
+_D = C.POINTER(ConvDesc)
+
+# name -> (restype, argtypes); every symbol include/udaseg.h declares
+SIGNATURES = {
+    "udaseg_version": (_I, []),
+    "udaseg_last_error": (C.c_char_p, []),
+    "udaseg_device_count": (_I, []),
+    "udaseg_conv2d_fwd": (_I, [_D, _P, _P, _P, _P, _I, _F, _I, _P]),
+    "udaseg_conv2d_dgrad": (_I, [_D, _P, _P, _P, _I, _P]),
+    "udaseg_conv2d_wgrad": (_I, [_D, _P, _P, _P, _I, _P]),
+    "udaseg_pack_dgrad_weights": (_I, [_D, _P, _P, _P]),
+    "udaseg_conv_flops": (C.c_double, [_D]),
+    "udaseg_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "udaseg_bn_stats": (_I, [_P, _L, _I, _P, _P]),
+    "udaseg_bn_apply": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _F, _F, _P, _P, _P, _P, _I, _F, _P]),
+    "udaseg_bn_apply_eval": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _F, _P]),
+    "udaseg_bn_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _L, _I, _P, _I, _F, _P]),
+    "udaseg_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _I, _I, _I, _P]),
+    "udaseg_act_bwd": (_I, [_P, _P, _P, _L, _I, _F, _P]),
+    "udaseg_channel_sum": (_I, [_P, _L, _I, _P, _I, _P]),
+    "udaseg_maxpool3x3s2_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "udaseg_maxpool3x3s2_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "udaseg_upsample2x_concat_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "udaseg_upsample2x_concat_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "udaseg_ce_partials": (_I, []),
+    "udaseg_ce_fwd": (_I, [_P, _P, _L, _I, _I, _P, _P, _P, _P]),
+    "udaseg_ce_bwd": (_I, [_P, _P, _P, _P, _L, _I, _I, _P, _P]),
+    "udaseg_gap_splits": (_I, [_I]),
+    "udaseg_gap_linear_sigmoid_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "udaseg_gap_linear_sigmoid_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "udaseg_bce_logits_fwd": (_I, [_P, _I, _F, _F, _P, _I, _P]),
+    "udaseg_bce_logits_bwd": (_I, [_P, _I, _F, _F, _P, _P, _I, _P]),
+    "udaseg_adam_flat": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _P]),
+    "udaseg_fill_f32": (_I, [_P, _L, _F, _P]),
+    "udaseg_axpy_f32": (_I, [_P, _P, _L, _F, _P]),
+    "udaseg_prof_enable": (_I, [_I]),
+    "udaseg_prof_reset": (_I, []),
+    "udaseg_prof_read": (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library once; raise loudly when it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c \"import __graft_entry__ as g; "
+            f"g.build()\"` (or `make -C {os.path.join(_HERE, 'csrc')}`). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().udaseg_last_error().decode(errors="replace")
+        raise RuntimeError(f"libudaseg_hip {what} failed (rc={rc}): {msg}")
+
+
+def require_gpu():
+    lib = load()
+    if lib.udaseg_device_count() < 1:
+        raise RuntimeError("libudaseg_hip: no HIP device visible; this path has no CPU fallback")
+    return lib

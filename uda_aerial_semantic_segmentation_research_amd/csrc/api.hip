@@ -1,0 +1,104 @@
+// Library-level entry points: version, thread-local error text, device probe, live launch timing.
+#include <string.h>
+#include <vector>
+
+#include "common.h"
+
+namespace udaseg {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char* what) {
+  set_error("%s: %s", what, hipGetErrorString(e));
+  return UDASEG_E_HIP;
+}
+
+// ---- live timing of the conv kernel families (bench.py roofline leg) ------------------------------------------
+struct ProfRec {
+  hipEvent_t a, b;
+  double flops;
+};
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_recs[2];
+static std::vector<hipEvent_t> g_pool;
+static hipEvent_t g_open[2];
+
+static hipEvent_t get_event() {
+  if (!g_pool.empty()) {
+    hipEvent_t e = g_pool.back();
+    g_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+
+void prof_begin(int family, hipStream_t s) {
+  if (!g_prof_on) return;
+  g_open[family] = get_event();
+  if (g_open[family]) hipEventRecord(g_open[family], s);
+}
+
+void prof_end(int family, hipStream_t s, double flops) {
+  if (!g_prof_on || !g_open[family]) return;
+  hipEvent_t b = get_event();
+  if (!b) return;
+  hipEventRecord(b, s);
+  g_recs[family].push_back({g_open[family], b, flops});
+  g_open[family] = nullptr;
+}
+
+}  // namespace udaseg
+
+using namespace udaseg;
+
+extern "C" int udaseg_version(void) { return 100; }
+extern "C" const char* udaseg_last_error(void) { return g_err; }
+
+extern "C" int udaseg_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+extern "C" int udaseg_prof_enable(int on) {
+  g_prof_on = on != 0;
+  return UDASEG_OK;
+}
+
+extern "C" int udaseg_prof_reset(void) {
+  for (int f = 0; f < 2; ++f) {
+    for (auto& r : g_recs[f]) {
+      g_pool.push_back(r.a);
+      g_pool.push_back(r.b);
+    }
+    g_recs[f].clear();
+  }
+  return UDASEG_OK;
+}
+
+extern "C" int udaseg_prof_read(int family, double* total_ms, double* total_flops, int64_t* launches) {
+  UDASEG_CHECK_ARG(family >= 0 && family < 2 && total_ms && total_flops && launches, "prof_read: bad arguments");
+  double ms = 0.0, fl = 0.0;
+  for (auto& r : g_recs[family]) {
+    hipError_t e = hipEventSynchronize(r.b);
+    if (e != hipSuccess) return hip_fail(e, "hipEventSynchronize(prof)");
+    float t = 0.f;
+    e = hipEventElapsedTime(&t, r.a, r.b);
+    if (e != hipSuccess) return hip_fail(e, "hipEventElapsedTime(prof)");
+    ms += t;
+    fl += r.flops;
+  }
+  *total_ms = ms;
+  *total_flops = fl;
+  *launches = (int64_t)g_recs[family].size();
+  return UDASEG_OK;
+}

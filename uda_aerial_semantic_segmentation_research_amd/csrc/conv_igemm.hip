@@ -1,0 +1,361 @@
+// Implicit-GEMM 2-D convolution, forward and data-gradient, NHWC fp32 on v_mfma_f32_32x32x2_f32 (gfx950).
+//
+// Replaces torch.nn.functional.conv2d / its autograd dgrad as reached from smp.Unet.forward and
+// DomainDiscriminator.forward (reference src/models/train.py:341,343; src/models/discriminator.py:54).
+//
+// GEMM view:  C[M x N] = A[M x K] * B[K x N]
+//   M = output pixels of one launch (a sub-lattice of the output tensor, see below)
+//   N = output channels, K = taps * gathered channels
+//   A is gathered on the fly from the NHWC operand (im2col never materialised), B is the OHWI weight.
+// One kernel serves forward and dgrad: a launch is described by an output sub-lattice
+//   out(y, x) = (cy + sy_o*jy, cx + sx_o*jx)      jy < JY, jx < JX
+// and a tap table   in(y, x) = (sy_i*jy + dy[t], sx_i*jx + dx[t]),  weight tap wt[t].
+//   forward, stride s, pad p :  lattice = whole output, sy_i = s, dy[t] = r - p
+//   dgrad of a stride-s conv :  one launch per output parity class (ph, pw) in [0,s)^2 with the taps
+//                               r = (ph+p) mod s, ...;  dy[t] = (ph + p - r)/s, sy_i = 1  -> dense work, no atomics.
+//
+// Tiling (256 threads = 4 waves): block tile BM x BN x 32, double-buffered LDS, A and B staged through
+// registers (global_load_dwordx4 issued before the MFMA phase of the current tile, ds_write_b128 after it),
+// one barrier per K-tile.  LDS rows are K-contiguous with a 4-float pad: ds_read_b128 conflict-free.
+// Each lane's 16-byte LDS read feeds 4 consecutive MFMAs (the K order inside a tile is permuted identically
+// for A and B, which a GEMM does not care about).
+#include "common.h"
+
+namespace udaseg {
+
+struct IgemmArgs {
+  const float* x;
+  const float* w;
+  const float* bias;
+  float* y;
+  int hi, wi, ci;
+  int ho, wo, co;
+  int JY, JX, M;
+  int cy, cx, sy_o, sx_o, sy_i, sx_i;
+  int ntaps, tfull, K;
+  float inv_ci, inv_jx, inv_jy;
+  int accumulate, act;
+  float slope;
+  int dense_out;
+  signed char dy[64];
+  signed char dx[64];
+  unsigned char wt[64];
+};
+
+constexpr int BK = 32;
+constexpr int LDS_LD = BK + 4;
+
+template <int BM, int BN>
+constexpr int igemm_lds_bytes() { return 2 * (BM + BN) * LDS_LD * 4 + 3 * 64 * 4; }
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int A_PASS = BM / 32;
+  constexpr int B_PASS = (BN + 31) / 32;
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+  static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile must be a multiple of 32x32");
+
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* As = reinterpret_cast<float*>(smem_raw);          // [2][BM][LDS_LD]
+  float* Bs = As + 2 * BM * LDS_LD;                         // [2][BN][LDS_LD]
+  int* taps = reinterpret_cast<int*>(Bs + 2 * BN * LDS_LD);  // [3][64]: dy, dx, wt
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int wm = (wave / WAVES_N) * WM, wn = (wave % WAVES_N) * WN;
+
+  // ---- block -> tile, XCD-aware: blocks that share blockIdx%8 (one XCD's L2) take a contiguous run of
+  // tiles, N-tiles innermost, so an XCD re-reads its own A rows / halos from its own L2.
+  const int ntn = (a.co + BN - 1) / BN;
+  const int nblk = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int m0 = (bid / ntn) * BM;
+  const int n0 = (bid % ntn) * BN;
+
+  if (tid < 64) {
+    taps[tid] = a.dy[tid];
+    taps[64 + tid] = a.dx[tid];
+    taps[128 + tid] = a.wt[tid];
+  }
+
+  // ---- per-thread load slots: float4 column kq of rows lrow + 32*p
+  const int kq = tid & 7, lrow = tid >> 3;
+  int a_base[A_PASS], a_iy[A_PASS], a_ix[A_PASS];
+#pragma unroll
+  for (int p = 0; p < A_PASS; ++p) {
+    const int m = m0 + lrow + 32 * p;
+    if (m < a.M) {
+      const int t1 = fast_div(m, a.JX, a.inv_jx);
+      const int jx = m - t1 * a.JX;
+      const int ni = fast_div(t1, a.JY, a.inv_jy);
+      const int jy = t1 - ni * a.JY;
+      a_base[p] = ni * a.hi * a.wi;
+      a_iy[p] = jy * a.sy_i;
+      a_ix[p] = jx * a.sx_i;
+    } else {
+      a_base[p] = 0;
+      a_iy[p] = -(1 << 20);
+      a_ix[p] = 0;
+    }
+  }
+  int b_off[B_PASS];
+#pragma unroll
+  for (int p = 0; p < B_PASS; ++p) {
+    const int n = n0 + lrow + 32 * p;
+    b_off[p] = (n < a.co && (lrow + 32 * p) < BN) ? n * a.tfull * a.ci : -1;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+  f32x4 ra[A_PASS], rb[B_PASS];
+  const int nkt = (a.K + BK - 1) / BK;
+
+  __syncthreads();  // tap table visible
+
+  auto load_tile = [&](int kt) {
+    const int kk = kt * BK + kq * 4;
+    const bool kvalid = kk < a.K;
+    int t = (int)(((float)kk + 0.5f) * a.inv_ci);
+    const int c = kk - t * a.ci;
+    t = t < a.ntaps ? t : a.ntaps - 1;
+    t = t < 0 ? 0 : t;
+    const int dyt = taps[t], dxt = taps[64 + t], wtt = taps[128 + t];
+#pragma unroll
+    for (int p = 0; p < A_PASS; ++p) {
+      const int iy = a_iy[p] + dyt, ix = a_ix[p] + dxt;
+      const bool ok = kvalid && (unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) {
+        const size_t off = (size_t)(a_base[p] + iy * a.wi + ix) * (size_t)a.ci + (size_t)c;
+        v = *reinterpret_cast<const f32x4*>(a.x + off);
+      }
+      ra[p] = v;
+    }
+#pragma unroll
+    for (int p = 0; p < B_PASS; ++p) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (kvalid && b_off[p] >= 0) {
+        const size_t off = (size_t)b_off[p] + (size_t)(wtt * a.ci + c);
+        v = *reinterpret_cast<const f32x4*>(a.w + off);
+      }
+      rb[p] = v;
+    }
+  };
+  auto store_tile = [&](int buf) {
+    float* Ad = As + buf * BM * LDS_LD;
+    float* Bd = Bs + buf * BN * LDS_LD;
+#pragma unroll
+    for (int p = 0; p < A_PASS; ++p)
+      *reinterpret_cast<f32x4*>(Ad + (lrow + 32 * p) * LDS_LD + kq * 4) = ra[p];
+#pragma unroll
+    for (int p = 0; p < B_PASS; ++p)
+      if (lrow + 32 * p < BN) *reinterpret_cast<f32x4*>(Bd + (lrow + 32 * p) * LDS_LD + kq * 4) = rb[p];
+  };
+
+  if (nkt > 0) {
+    load_tile(0);
+    store_tile(0);
+  }
+  __syncthreads();
+
+  int cur = 0;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const bool more = (kt + 1) < nkt;
+    if (more) load_tile(kt + 1);
+    const float* Ac = As + cur * BM * LDS_LD + (wm + lr) * LDS_LD + lh * 4;
+    const float* Bc = Bs + cur * BN * LDS_LD + (wn + lr) * LDS_LD + lh * 4;
+#pragma unroll
+    for (int s = 0; s < BK / 8; ++s) {
+      f32x4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ac + i * 32 * LDS_LD + s * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bc + j * 32 * LDS_LD + s * 8);
+#pragma unroll
+      for (int k2 = 0; k2 < 4; ++k2)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][k2], bf[j][k2], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_tile(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue: D[i][j] reg v of lane (lr, lh) = C[row = (v&3) + 8*(v>>2) + 4*lh][col = lr]
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int m = m0 + wm + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
+      if (m >= a.M) continue;
+      size_t pix;
+      if (a.dense_out) {
+        pix = (size_t)m;
+      } else {
+        const int t1 = fast_div(m, a.JX, a.inv_jx);
+        const int jx = m - t1 * a.JX;
+        const int ni = fast_div(t1, a.JY, a.inv_jy);
+        const int jy = t1 - ni * a.JY;
+        pix = ((size_t)ni * a.ho + (size_t)(a.cy + a.sy_o * jy)) * a.wo + (size_t)(a.cx + a.sx_o * jx);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn + j * 32 + lr;
+        if (n < a.co) {
+          float val = acc[i][j][v];
+          if (a.bias) val += a.bias[n];
+          val = act_apply(val, a.act, a.slope);
+          float* dst = a.y + pix * (size_t)a.co + n;
+          if (a.accumulate) val += *dst;
+          *dst = val;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- host side
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+static int launch_cfg(const IgemmArgs& a, hipStream_t s) {
+  static bool attr_done = false;
+  constexpr int lds = igemm_lds_bytes<BM, BN>();
+  auto kern = conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N>;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv_igemm)");
+    attr_done = true;
+  }
+  const int mt = cdiv(a.M, BM), nt = cdiv(a.co, BN);
+  dim3 grid((unsigned)(mt * nt)), block(256);
+  hipLaunchKernelGGL(kern, grid, block, lds, s, a);
+  UDASEG_LAUNCH_CHECK("conv_igemm launch");
+  return UDASEG_OK;
+}
+
+static int launch_igemm(const IgemmArgs& a, hipStream_t s) {
+  if (a.M <= 0) return UDASEG_OK;
+  const long long tiles128 = (long long)cdiv(a.M, 128);
+  // tile choice: widest N tile the channel count fills; fall back to 64x64 when a 128-row tiling would
+  // leave most of the 256 CUs idle (deep, low-resolution layers).
+  if (a.co > 64) {
+    if (tiles128 * cdiv(a.co, 128) >= 384) return launch_cfg<128, 128, 2, 2>(a, s);
+    return launch_cfg<64, 64, 2, 2>(a, s);
+  }
+  if (a.co > 32) {
+    if (tiles128 >= 384) return launch_cfg<128, 64, 2, 2>(a, s);
+    return launch_cfg<64, 64, 2, 2>(a, s);
+  }
+  return launch_cfg<128, 32, 4, 1>(a, s);
+}
+
+static int check_desc(const udaseg_conv_desc* d) {
+  UDASEG_CHECK_ARG(d != nullptr, "conv desc is NULL");
+  UDASEG_CHECK_ARG(d->n > 0 && d->hi > 0 && d->wi > 0 && d->ho > 0 && d->wo > 0, "conv desc: non-positive extent");
+  UDASEG_CHECK_ARG(d->ci > 0 && d->co > 0 && d->ci % 4 == 0 && d->co % 4 == 0,
+                   "conv desc: channel counts must be positive multiples of 4 (ci=%d co=%d)", d->ci, d->co);
+  UDASEG_CHECK_ARG(d->kh > 0 && d->kw > 0 && d->kh * d->kw <= 64, "conv desc: kernel %dx%d unsupported", d->kh, d->kw);
+  UDASEG_CHECK_ARG(d->stride >= 1 && d->stride <= 4 && d->pad >= 0 && d->pad < 64, "conv desc: stride/pad unsupported");
+  UDASEG_CHECK_ARG(d->ho == (d->hi + 2 * d->pad - d->kh) / d->stride + 1 && d->wo == (d->wi + 2 * d->pad - d->kw) / d->stride + 1,
+                   "conv desc: output extent %dx%d inconsistent with input %dx%d k%d s%d p%d", d->ho, d->wo, d->hi, d->wi,
+                   d->kh, d->stride, d->pad);
+  UDASEG_CHECK_ARG((long long)d->n * d->hi * d->wi * d->ci < (1LL << 31) && (long long)d->n * d->ho * d->wo * d->co < (1LL << 31),
+                   "conv desc: tensor exceeds 2^31 elements");
+  return UDASEG_OK;
+}
+
+}  // namespace udaseg
+
+using namespace udaseg;
+
+extern "C" double udaseg_conv_flops(const udaseg_conv_desc* d) {
+  if (!d) return 0.0;
+  return 2.0 * (double)d->n * d->ho * d->wo * (double)d->co * (double)d->ci * d->kh * d->kw;
+}
+
+extern "C" int udaseg_conv2d_fwd(const udaseg_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
+                                 int act, float slope, int accumulate, void* stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  UDASEG_CHECK_ARG(x && w && y, "conv2d_fwd: NULL pointer");
+  IgemmArgs a = {};
+  a.x = x; a.w = w; a.bias = bias; a.y = y;
+  a.hi = d->hi; a.wi = d->wi; a.ci = d->ci;
+  a.ho = d->ho; a.wo = d->wo; a.co = d->co;
+  a.JY = d->ho; a.JX = d->wo; a.M = d->n * d->ho * d->wo;
+  a.cy = 0; a.cx = 0; a.sy_o = 1; a.sx_o = 1; a.sy_i = d->stride; a.sx_i = d->stride;
+  a.ntaps = d->kh * d->kw; a.tfull = a.ntaps; a.K = a.ntaps * d->ci;
+  a.inv_ci = 1.0f / d->ci; a.inv_jx = 1.0f / a.JX; a.inv_jy = 1.0f / a.JY;
+  a.accumulate = accumulate; a.act = act; a.slope = slope; a.dense_out = 1;
+  for (int r = 0; r < d->kh; ++r)
+    for (int s = 0; s < d->kw; ++s) {
+      const int t = r * d->kw + s;
+      a.dy[t] = (signed char)(r - d->pad);
+      a.dx[t] = (signed char)(s - d->pad);
+      a.wt[t] = (unsigned char)t;
+    }
+  hipStream_t st = as_stream(stream);
+  prof_begin(0, st);
+  rc = launch_igemm(a, st);
+  prof_end(0, st, udaseg_conv_flops(d));
+  return rc;
+}
+
+extern "C" int udaseg_conv2d_dgrad(const udaseg_conv_desc* d, const float* dy, const float* w_t, float* dx,
+                                   int accumulate, void* stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  UDASEG_CHECK_ARG(dy && w_t && dx, "conv2d_dgrad: NULL pointer");
+  hipStream_t st = as_stream(stream);
+  const int s = d->stride;
+  prof_begin(0, st);
+  for (int ph = 0; ph < s; ++ph)
+    for (int pw = 0; pw < s; ++pw) {
+      IgemmArgs a = {};
+      a.x = dy; a.w = w_t; a.bias = nullptr; a.y = dx;
+      a.hi = d->ho; a.wi = d->wo; a.ci = d->co;   // gathered operand: dy
+      a.ho = d->hi; a.wo = d->wi; a.co = d->ci;   // output: dx
+      a.JY = (d->hi - ph + s - 1) / s;
+      a.JX = (d->wi - pw + s - 1) / s;
+      if (a.JY <= 0 || a.JX <= 0) continue;
+      a.M = d->n * a.JY * a.JX;
+      a.cy = ph; a.cx = pw; a.sy_o = s; a.sx_o = s; a.sy_i = 1; a.sx_i = 1;
+      int nt = 0;
+      for (int r = 0; r < d->kh; ++r) {
+        if ((ph + d->pad - r) % s != 0) continue;
+        for (int q = 0; q < d->kw; ++q) {
+          if ((pw + d->pad - q) % s != 0) continue;
+          a.dy[nt] = (signed char)((ph + d->pad - r) / s);
+          a.dx[nt] = (signed char)((pw + d->pad - q) / s);
+          a.wt[nt] = (unsigned char)(r * d->kw + q);
+          ++nt;
+        }
+      }
+      if (nt == 0 && accumulate) continue;  // nothing to add for this parity class
+      a.ntaps = nt; a.tfull = d->kh * d->kw; a.K = nt * d->co;
+      a.inv_ci = 1.0f / d->co; a.inv_jx = 1.0f / a.JX; a.inv_jy = 1.0f / a.JY;
+      a.accumulate = accumulate; a.act = UDASEG_ACT_NONE; a.slope = 0.f;
+      a.dense_out = (s == 1) ? 1 : 0;
+      rc = launch_igemm(a, st);
+      if (rc) return rc;
+    }
+  // dgrad FLOPs equal the forward's (every (pixel, tap, ci, co) product appears once)
+  prof_end(0, st, udaseg_conv_flops(d));
+  return UDASEG_OK;
+}

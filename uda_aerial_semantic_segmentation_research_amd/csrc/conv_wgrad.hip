@@ -1,0 +1,231 @@
+// Convolution weight gradient, NHWC fp32, split-K implicit GEMM on v_mfma_f32_32x32x2_f32 (gfx950).
+//
+// Replaces autograd's conv weight-gradient reached by loss.backward() (reference src/models/train.py:343,
+// src/models/adversarial_trainer.py:97,113).
+//
+// GEMM view:  dW[co][j] = sum_m dy[m][co] * X[m][j],   j = tap*ci + c  (the OHWI weight row, J = taps*ci),
+//             m over the N*Ho*Wo output pixels, X[m][j] = x[n, oy*s - p + r, ox*s - p + q, c] (0 outside).
+//   GEMM-M = co, GEMM-N = j, GEMM-K = pixels.  Both operands are pixel-major in memory, so a K-tile of 32
+//   pixels is staged as LDS rows [pixel][channel] and MFMA operands are read with ds_read_b32 (lane = channel).
+// grid.x = (co tiles) * (j tiles), grid.y = K splits; each block reduces its pixel range in registers and
+// adds its tile to dW with global_atomic_add_f32 (one 128-B row segment per half-wave = full atomic rate),
+// or stores directly when there is a single split.
+#include "common.h"
+
+namespace udaseg {
+
+struct WgradArgs {
+  const float* x;
+  const float* dy;
+  float* dw;
+  int hi, wi, ci, ho, wo, co;
+  int kw, stride, pad;
+  int M, J;          // pixels, taps*ci
+  int kchunk;        // pixels per split (multiple of 32)
+  int use_atomic;
+  float inv_ci, inv_kw, inv_wo, inv_ho;
+};
+
+constexpr int WBK = 32;  // pixels per K-tile
+
+template <int BMW, int BNW, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
+  constexpr int WM = BMW / WAVES_M, WN = BNW / WAVES_N;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int AQ = BMW / 4, BQ = BNW / 4;           // float4 columns per row
+  constexpr int A_ROWS = 256 / AQ, B_ROWS = 256 / BQ;  // rows covered per pass
+  constexpr int A_PASS = WBK / A_ROWS, B_PASS = WBK / B_ROWS;
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+  static_assert(A_PASS >= 1 && B_PASS >= 1, "tile too wide");
+
+  __shared__ __attribute__((aligned(16))) float As[2][WBK][BMW];
+  __shared__ __attribute__((aligned(16))) float Bs[2][WBK][BNW];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int wm = (wave / WAVES_N) * WM, wn = (wave % WAVES_N) * WN;
+
+  const int ntj = (a.J + BNW - 1) / BNW;
+  const int co0 = (blockIdx.x / ntj) * BMW;
+  const int j0 = (blockIdx.x % ntj) * BNW;
+  const int kbeg = blockIdx.y * a.kchunk;
+  const int kend = min(a.M, kbeg + a.kchunk);
+
+  // A (dy) slot: column aq (4 channels), rows arow + A_ROWS*p
+  const int aq = tid % AQ, arow = tid / AQ;
+  const int a_co = co0 + aq * 4;
+  const bool a_ok = a_co < a.co;
+  // B (x gather) slot: column bq -> fixed (tap, c)
+  const int bq = tid % BQ, brow = tid / BQ;
+  const int j = j0 + bq * 4;
+  const bool b_ok = j < a.J;
+  int b_dy = 0, b_dx = 0, b_c = 0;
+  if (b_ok) {
+    const int tap = fast_div(j, a.ci, a.inv_ci);
+    b_c = j - tap * a.ci;
+    const int r = fast_div(tap, a.kw, a.inv_kw);
+    b_dy = r - a.pad;
+    b_dx = (tap - r * a.kw) - a.pad;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[i][jn][v] = 0.f;
+
+  f32x4 ra[A_PASS], rb[B_PASS];
+  const int nkt = (kend - kbeg + WBK - 1) / WBK;
+
+  auto load_tile = [&](int kt) {
+    const int mb = kbeg + kt * WBK;
+#pragma unroll
+    for (int p = 0; p < A_PASS; ++p) {
+      const int m = mb + arow + A_ROWS * p;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (a_ok && m < kend) v = *reinterpret_cast<const f32x4*>(a.dy + (size_t)m * a.co + a_co);
+      ra[p] = v;
+    }
+#pragma unroll
+    for (int p = 0; p < B_PASS; ++p) {
+      const int m = mb + brow + B_ROWS * p;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (b_ok && m < kend) {
+        const int t1 = fast_div(m, a.wo, a.inv_wo);
+        const int ox = m - t1 * a.wo;
+        const int ni = fast_div(t1, a.ho, a.inv_ho);
+        const int oy = t1 - ni * a.ho;
+        const int iy = oy * a.stride + b_dy, ix = ox * a.stride + b_dx;
+        if ((unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi)
+          v = *reinterpret_cast<const f32x4*>(a.x + ((size_t)(ni * a.hi + iy) * a.wi + ix) * (size_t)a.ci + b_c);
+      }
+      rb[p] = v;
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < A_PASS; ++p) *reinterpret_cast<f32x4*>(&As[buf][arow + A_ROWS * p][aq * 4]) = ra[p];
+#pragma unroll
+    for (int p = 0; p < B_PASS; ++p) *reinterpret_cast<f32x4*>(&Bs[buf][brow + B_ROWS * p][bq * 4]) = rb[p];
+  };
+
+  if (nkt > 0) {
+    load_tile(0);
+    store_tile(0);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const bool more = (kt + 1) < nkt;
+    if (more) load_tile(kt + 1);
+#pragma unroll
+    for (int k2 = 0; k2 < WBK / 2; ++k2) {
+      float af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = As[cur][2 * k2 + lh][wm + i * 32 + lr];
+#pragma unroll
+      for (int jn = 0; jn < TN; ++jn) bf[jn] = Bs[cur][2 * k2 + lh][wn + jn * 32 + lr];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn)
+          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[jn], acc[i][jn], 0, 0, 0);
+    }
+    if (more) store_tile(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // D reg v of lane (lr, lh): row co = (v&3) + 8*(v>>2) + 4*lh, col j = lr
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int co = co0 + wm + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
+      if (co >= a.co) continue;
+#pragma unroll
+      for (int jn = 0; jn < TN; ++jn) {
+        const int jj = j0 + wn + jn * 32 + lr;
+        if (jj < a.J) {
+          float* dst = a.dw + (size_t)co * a.J + jj;
+          if (a.use_atomic) atomicAdd(dst, acc[i][jn][v]);
+          else *dst = acc[i][jn][v];
+        }
+      }
+    }
+}
+
+template <int BMW, int BNW, int WAVES_M, int WAVES_N>
+static int launch_wgrad(WgradArgs a, int accumulate, hipStream_t s) {
+  const int tiles = cdiv(a.co, BMW) * cdiv(a.J, BNW);
+  // enough blocks for ~4 per CU, at least 256 pixels per split
+  int splits = cdiv(1024, tiles);
+  const int max_splits = cdiv(a.M, 256);
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  int kchunk = cdiv(cdiv(a.M, splits), WBK) * WBK;
+  splits = cdiv(a.M, kchunk);
+  a.kchunk = kchunk;
+  a.use_atomic = (splits > 1 || accumulate) ? 1 : 0;
+  if (a.use_atomic && !accumulate) {
+    hipError_t e = hipMemsetAsync(a.dw, 0, (size_t)a.co * a.J * sizeof(float), s);
+    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(dw)");
+  }
+  dim3 grid((unsigned)tiles, (unsigned)splits), block(256);
+  hipLaunchKernelGGL((conv_wgrad_kernel<BMW, BNW, WAVES_M, WAVES_N>), grid, block, 0, s, a);
+  UDASEG_LAUNCH_CHECK("conv_wgrad launch");
+  return UDASEG_OK;
+}
+
+}  // namespace udaseg
+
+using namespace udaseg;
+
+extern "C" int udaseg_conv2d_wgrad(const udaseg_conv_desc* d, const float* x, const float* dy, float* dw,
+                                   int accumulate, void* stream) {
+  UDASEG_CHECK_ARG(d && x && dy && dw, "conv2d_wgrad: NULL pointer");
+  UDASEG_CHECK_ARG(d->ci % 4 == 0 && d->co % 4 == 0 && d->ci > 0 && d->co > 0, "conv2d_wgrad: channels must be multiples of 4");
+  UDASEG_CHECK_ARG(d->kh > 0 && d->kw > 0 && d->stride >= 1, "conv2d_wgrad: bad kernel/stride");
+  UDASEG_CHECK_ARG((long long)d->n * d->hi * d->wi * d->ci < (1LL << 31) && (long long)d->n * d->ho * d->wo * d->co < (1LL << 31),
+                   "conv2d_wgrad: tensor exceeds 2^31 elements");
+  WgradArgs a = {};
+  a.x = x; a.dy = dy; a.dw = dw;
+  a.hi = d->hi; a.wi = d->wi; a.ci = d->ci; a.ho = d->ho; a.wo = d->wo; a.co = d->co;
+  a.kw = d->kw; a.stride = d->stride; a.pad = d->pad;
+  a.M = d->n * d->ho * d->wo;
+  a.J = d->kh * d->kw * d->ci;
+  a.inv_ci = 1.0f / d->ci; a.inv_kw = 1.0f / d->kw; a.inv_wo = 1.0f / d->wo; a.inv_ho = 1.0f / d->ho;
+  hipStream_t st = as_stream(stream);
+  prof_begin(1, st);
+  int rc;
+  if (d->co > 32) rc = launch_wgrad<64, 64, 2, 2>(a, accumulate, st);
+  else rc = launch_wgrad<32, 128, 1, 4>(a, accumulate, st);
+  prof_end(1, st, udaseg_conv_flops(d));
+  return rc;
+}
+
+// ---- weight repack for dgrad: w[co][t][ci] -> w_t[ci][t][co] ------------------------------------------------
+namespace udaseg {
+__global__ void pack_dgrad_kernel(const float* __restrict__ w, float* __restrict__ wt, int co, int T, int ci) {
+  const long long total = (long long)co * T * ci;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    // i indexes the destination [ci][T][co]
+    const int o = (int)(i % co);
+    const long long r = i / co;
+    const int t = (int)(r % T);
+    const int c = (int)(r / T);
+    wt[i] = w[((long long)o * T + t) * ci + c];
+  }
+}
+}  // namespace udaseg
+
+extern "C" int udaseg_pack_dgrad_weights(const udaseg_conv_desc* d, const float* w, float* w_t, void* stream) {
+  UDASEG_CHECK_ARG(d && w && w_t, "pack_dgrad_weights: NULL pointer");
+  const long long total = (long long)d->co * d->kh * d->kw * d->ci;
+  const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+  hipLaunchKernelGGL(pack_dgrad_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, w_t, d->co, d->kh * d->kw, d->ci);
+  UDASEG_LAUNCH_CHECK("pack_dgrad launch");
+  return UDASEG_OK;
+}

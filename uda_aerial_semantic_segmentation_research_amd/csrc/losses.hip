@@ -1,0 +1,295 @@
+// Loss kernels (no MFMA; wavefront reductions), fp32 (gfx950).
+//
+//  * per-pixel cross entropy, mean reduction, no class weights / ignore_index:
+//      nn.CrossEntropyLoss() constructed at reference src/models/train.py:208, applied at :342,:403 and at
+//      src/models/adversarial_trainer.py:105,155.
+//  * discriminator tail  AdaptiveAvgPool2d(1) -> Flatten -> Linear(512,1) -> Sigmoid
+//      (src/models/discriminator.py:37-42) and its autograd.
+//  * AdversarialLoss' nn.BCEWithLogitsLoss terms (src/models/losses.py:16,33-36,51).  The reference feeds the
+//      discriminator's *probabilities* into the with-logits loss; these kernels are agnostic: they compute
+//      mean(softplus(x) - x*label) of whatever x is.
+#include "common.h"
+
+namespace udaseg {
+
+constexpr int CE_BLOCKS = 1024;
+constexpr int CE_MAXC = 64;
+
+// One thread per pixel, logits row in registers (classes <= 64, ldc % 4 == 0).  HBM-bound: 4*ldc B/pixel read.
+template <int LDC4>
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const f32x4* __restrict__ logits, const int64_t* __restrict__ target,
+                                                     int64_t pixels, int classes, float* __restrict__ lse,
+                                                     double* __restrict__ partials) {
+  __shared__ double red[4];
+  const int64_t T = (int64_t)gridDim.x * blockDim.x;
+  double local = 0.0;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < pixels; p += T) {
+    f32x4 v[LDC4];
+#pragma unroll
+    for (int k = 0; k < LDC4; ++k) v[k] = logits[p * LDC4 + k];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < LDC4; ++k)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (k * 4 + e < classes) mx = fmaxf(mx, v[k][e]);
+    float sum = 0.f;
+    const int t = (int)target[p];
+    float xt = 0.f;
+#pragma unroll
+    for (int k = 0; k < LDC4; ++k)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (k * 4 + e < classes) {
+          sum += expf(v[k][e] - mx);
+          if (k * 4 + e == t) xt = v[k][e];
+        }
+    const float l = mx + logf(sum);
+    lse[p] = l;
+    local += (double)(l - xt);
+  }
+  local = wave_sum_d(local);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ void ce_finish_kernel(const double* __restrict__ partials, int n, int64_t pixels, float* __restrict__ loss) {
+  // single wave: deterministic final sum
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 64) s += partials[i];
+  s = wave_sum_d(s);
+  if (threadIdx.x == 0) *loss = (float)(s / (double)pixels);
+}
+
+template <int LDC4>
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const f32x4* __restrict__ logits, const int64_t* __restrict__ target,
+                                                     const float* __restrict__ lse, const float* __restrict__ grad_out,
+                                                     int64_t pixels, int classes, f32x4* __restrict__ dlogits) {
+  const float scale = (grad_out ? *grad_out : 1.f) / (float)pixels;
+  const int64_t T = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < pixels; p += T) {
+    const float l = lse[p];
+    const int t = (int)target[p];
+#pragma unroll
+    for (int k = 0; k < LDC4; ++k) {
+      const f32x4 v = logits[p * LDC4 + k];
+      f32x4 g;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = k * 4 + e;
+        float d = 0.f;
+        if (c < classes) d = (expf(v[e] - l) - (c == t ? 1.f : 0.f)) * scale;
+        g[e] = d;
+      }
+      dlogits[p * LDC4 + k] = g;
+    }
+  }
+}
+
+// ---- discriminator tail ---------------------------------------------------------------------------------------
+constexpr int GAP_SPLITS = 32;
+
+// partial[n][s][c] = sum over the s-th slice of the hw pixels of z[n][p][c]
+__global__ void gap_partial_kernel(const f32x4* __restrict__ z, f32x4* __restrict__ partial, int hw, int c4, int splits) {
+  const int ni = blockIdx.y, s = blockIdx.x;
+  const int per = (hw + splits - 1) / splits;
+  const int p0 = s * per, p1 = min(hw, p0 + per);
+  for (int q = threadIdx.x; q < c4; q += blockDim.x) {
+    f32x4 acc = {0, 0, 0, 0};
+    for (int p = p0; p < p1; ++p) acc += z[((int64_t)ni * hw + p) * c4 + q];
+    partial[((int64_t)ni * splits + s) * c4 + q] = acc;
+  }
+}
+
+// one block per image: pooled = sum_s partial / hw ; p = sigmoid(dot(pooled, w) + b)
+__global__ __launch_bounds__(256) void gap_linear_sigmoid_kernel(const float* __restrict__ partial, const float* __restrict__ w,
+                                                                 const float* __restrict__ b, float* __restrict__ pooled,
+                                                                 float* __restrict__ p, int hw, int c, int splits) {
+  __shared__ float red[4];
+  const int ni = blockIdx.x;
+  float dot = 0.f;
+  const float inv = 1.f / (float)hw;
+  for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += partial[((int64_t)ni * splits + k) * c + ch];
+    s *= inv;
+    pooled[(int64_t)ni * c + ch] = s;
+    dot += s * w[ch];
+  }
+  dot = wave_sum(dot);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float t = red[0] + red[1] + red[2] + red[3] + b[0];
+    p[ni] = 1.f / (1.f + expf(-t));
+  }
+}
+
+// dz[n][p][c] = dlogit[n] * w[c] / hw, broadcast over the hw pixels
+__global__ void gap_bwd_broadcast_kernel(const float* __restrict__ dp, const float* __restrict__ p, const f32x4* __restrict__ w,
+                                         f32x4* __restrict__ dz, int n, int hw, int c4) {
+  const int64_t total = (int64_t)n * hw * c4;
+  const int64_t T = (int64_t)gridDim.x * blockDim.x;
+  const float inv = 1.f / (float)hw;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += T) {
+    const int q = (int)(i % c4);
+    const int ni = (int)(i / ((int64_t)hw * c4));
+    const float pv = p[ni];
+    const float dl = dp[ni] * pv * (1.f - pv) * inv;
+    dz[i] = w[q] * dl;
+  }
+}
+
+// dw[c] (+)= sum_n dlogit[n]*pooled[n][c] ; db (+)= sum_n dlogit[n]
+__global__ void gap_bwd_param_kernel(const float* __restrict__ dp, const float* __restrict__ p, const float* __restrict__ pooled,
+                                     float* __restrict__ dw, float* __restrict__ db, int n, int c, int accumulate) {
+  for (int ch = blockIdx.x * blockDim.x + threadIdx.x; ch < c; ch += gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int ni = 0; ni < n; ++ni) s += dp[ni] * p[ni] * (1.f - p[ni]) * pooled[(int64_t)ni * c + ch];
+    dw[ch] = accumulate ? dw[ch] + s : s;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    float s = 0.f;
+    for (int ni = 0; ni < n; ++ni) s += dp[ni] * p[ni] * (1.f - p[ni]);
+    db[0] = accumulate ? db[0] + s : s;
+  }
+}
+
+// ---- BCE with logits on a short vector: single wave -------------------------------------------------------------
+__device__ __forceinline__ float softplus_f(float x) {
+  // log(1 + exp(x)) = max(x,0) + log1p(exp(-|x|))
+  return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x)));
+}
+
+__global__ void bce_fwd_kernel(const float* __restrict__ x, int n, float label, float weight, float* __restrict__ loss,
+                               int accumulate) {
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 64) {
+    const float v = x[i];
+    // torch: (1 - y) * x + softplus(-x)   [= max(-x,0) + log1p(exp(-|x|)) form]
+    s += (1.f - label) * v + softplus_f(-v);
+  }
+  s = wave_sum(s);
+  if (threadIdx.x == 0) {
+    const float l = weight * (s / (float)n);
+    *loss = accumulate ? *loss + l : l;
+  }
+}
+
+__global__ void bce_bwd_kernel(const float* __restrict__ x, int n, float label, float weight, const float* __restrict__ grad_out,
+                               float* __restrict__ dx, int accumulate) {
+  const float g = (grad_out ? *grad_out : 1.f) * weight / (float)n;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float v = x[i];
+    const float sg = 1.f / (1.f + expf(-v));
+    const float d = (sg - label) * g;
+    dx[i] = accumulate ? dx[i] + d : d;
+  }
+}
+
+}  // namespace udaseg
+
+using namespace udaseg;
+
+extern "C" int udaseg_ce_partials(void) { return CE_BLOCKS; }
+
+extern "C" int udaseg_ce_fwd(const float* logits, const int64_t* target, int64_t pixels, int classes, int ldc, float* lse,
+                             double* partials, float* loss, void* stream) {
+  UDASEG_CHECK_ARG(logits && target && lse && partials && loss, "ce_fwd: NULL pointer");
+  UDASEG_CHECK_ARG(pixels > 0 && classes > 0 && classes <= ldc && ldc % 4 == 0 && ldc <= CE_MAXC,
+                   "ce_fwd: need 0 < classes <= ldc <= %d, ldc %% 4 == 0 (classes=%d ldc=%d)", CE_MAXC, classes, ldc);
+  hipStream_t st = as_stream(stream);
+  int grid = (int)((pixels + 255) / 256 > CE_BLOCKS ? CE_BLOCKS : (pixels + 255) / 256);
+#define CE_FWD_CASE(L)                                                                                                 \
+  case L:                                                                                                              \
+    hipLaunchKernelGGL(ce_fwd_kernel<L>, dim3(grid), dim3(256), 0, st, (const f32x4*)logits, target, pixels, classes, lse, \
+                       partials);                                                                                      \
+    break;
+  switch (ldc / 4) {
+    CE_FWD_CASE(1) CE_FWD_CASE(2) CE_FWD_CASE(3) CE_FWD_CASE(4) CE_FWD_CASE(5) CE_FWD_CASE(6) CE_FWD_CASE(7) CE_FWD_CASE(8)
+    CE_FWD_CASE(9) CE_FWD_CASE(10) CE_FWD_CASE(11) CE_FWD_CASE(12) CE_FWD_CASE(13) CE_FWD_CASE(14) CE_FWD_CASE(15) CE_FWD_CASE(16)
+    default:
+      set_error("ce_fwd: unsupported ldc %d", ldc);
+      return UDASEG_E_UNSUPPORTED;
+  }
+#undef CE_FWD_CASE
+  UDASEG_LAUNCH_CHECK("ce_fwd launch");
+  hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(64), 0, st, partials, grid, pixels, loss);
+  UDASEG_LAUNCH_CHECK("ce_finish launch");
+  return UDASEG_OK;
+}
+
+extern "C" int udaseg_ce_bwd(const float* logits, const int64_t* target, const float* lse, const float* grad_out,
+                             int64_t pixels, int classes, int ldc, float* dlogits, void* stream) {
+  UDASEG_CHECK_ARG(logits && target && lse && dlogits, "ce_bwd: NULL pointer");
+  UDASEG_CHECK_ARG(pixels > 0 && classes > 0 && classes <= ldc && ldc % 4 == 0 && ldc <= CE_MAXC, "ce_bwd: bad shape");
+  hipStream_t st = as_stream(stream);
+  int grid = (int)((pixels + 255) / 256 > 4096 ? 4096 : (pixels + 255) / 256);
+#define CE_BWD_CASE(L)                                                                                                  \
+  case L:                                                                                                               \
+    hipLaunchKernelGGL(ce_bwd_kernel<L>, dim3(grid), dim3(256), 0, st, (const f32x4*)logits, target, lse, grad_out, pixels, \
+                       classes, (f32x4*)dlogits);                                                                       \
+    break;
+  switch (ldc / 4) {
+    CE_BWD_CASE(1) CE_BWD_CASE(2) CE_BWD_CASE(3) CE_BWD_CASE(4) CE_BWD_CASE(5) CE_BWD_CASE(6) CE_BWD_CASE(7) CE_BWD_CASE(8)
+    CE_BWD_CASE(9) CE_BWD_CASE(10) CE_BWD_CASE(11) CE_BWD_CASE(12) CE_BWD_CASE(13) CE_BWD_CASE(14) CE_BWD_CASE(15) CE_BWD_CASE(16)
+    default:
+      set_error("ce_bwd: unsupported ldc %d", ldc);
+      return UDASEG_E_UNSUPPORTED;
+  }
+#undef CE_BWD_CASE
+  UDASEG_LAUNCH_CHECK("ce_bwd launch");
+  return UDASEG_OK;
+}
+
+extern "C" int udaseg_gap_splits(int hw) {
+  int s = GAP_SPLITS;
+  if (s > hw) s = hw;
+  return s < 1 ? 1 : s;
+}
+
+extern "C" int udaseg_gap_linear_sigmoid_fwd(const float* z, const float* w, const float* b, float* partial, float* pooled,
+                                             float* p, int n, int hw, int c, void* stream) {
+  UDASEG_CHECK_ARG(z && w && b && partial && pooled && p, "gap_linear_sigmoid_fwd: NULL pointer");
+  UDASEG_CHECK_ARG(n > 0 && hw > 0 && c > 0 && c % 4 == 0, "gap_linear_sigmoid_fwd: bad shape");
+  hipStream_t st = as_stream(stream);
+  const int splits = udaseg_gap_splits(hw);
+  const int bs = (c / 4) < 256 ? (((c / 4) + 63) / 64) * 64 : 256;
+  hipLaunchKernelGGL(gap_partial_kernel, dim3(splits, n), dim3(bs), 0, st, (const f32x4*)z, (f32x4*)partial, hw, c / 4, splits);
+  UDASEG_LAUNCH_CHECK("gap_partial launch");
+  hipLaunchKernelGGL(gap_linear_sigmoid_kernel, dim3(n), dim3(256), 0, st, partial, w, b, pooled, p, hw, c, splits);
+  UDASEG_LAUNCH_CHECK("gap_linear_sigmoid launch");
+  return UDASEG_OK;
+}
+
+extern "C" int udaseg_gap_linear_sigmoid_bwd(const float* dp, const float* p, const float* pooled, const float* w, float* dz,
+                                             float* dw, float* db, int n, int hw, int c, int accumulate_param, void* stream) {
+  UDASEG_CHECK_ARG(dp && p && pooled && w && dz && dw && db, "gap_linear_sigmoid_bwd: NULL pointer");
+  UDASEG_CHECK_ARG(n > 0 && hw > 0 && c > 0 && c % 4 == 0, "gap_linear_sigmoid_bwd: bad shape");
+  hipStream_t st = as_stream(stream);
+  const int64_t total = (int64_t)n * hw * (c / 4);
+  int grid = (int)((total + 511) / 512 > 2048 ? 2048 : (total + 511) / 512);
+  hipLaunchKernelGGL(gap_bwd_broadcast_kernel, dim3(grid), dim3(256), 0, st, dp, p, (const f32x4*)w, (f32x4*)dz, n, hw, c / 4);
+  UDASEG_LAUNCH_CHECK("gap_bwd_broadcast launch");
+  hipLaunchKernelGGL(gap_bwd_param_kernel, dim3((c + 255) / 256), dim3(256), 0, st, dp, p, pooled, dw, db, n, c, accumulate_param);
+  UDASEG_LAUNCH_CHECK("gap_bwd_param launch");
+  return UDASEG_OK;
+}
+
+extern "C" int udaseg_bce_logits_fwd(const float* x, int n, float label, float weight, float* loss, int accumulate,
+                                     void* stream) {
+  UDASEG_CHECK_ARG(x && loss && n > 0, "bce_logits_fwd: bad arguments");
+  hipLaunchKernelGGL(bce_fwd_kernel, dim3(1), dim3(64), 0, as_stream(stream), x, n, label, weight, loss, accumulate);
+  UDASEG_LAUNCH_CHECK("bce_fwd launch");
+  return UDASEG_OK;
+}
+
+extern "C" int udaseg_bce_logits_bwd(const float* x, int n, float label, float weight, const float* grad_out, float* dx,
+                                     int accumulate, void* stream) {
+  UDASEG_CHECK_ARG(x && dx && n > 0, "bce_logits_bwd: bad arguments");
+  hipLaunchKernelGGL(bce_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), x, n, label, weight, grad_out, dx,
+                     accumulate);
+  UDASEG_LAUNCH_CHECK("bce_bwd launch");
+  return UDASEG_OK;
+}

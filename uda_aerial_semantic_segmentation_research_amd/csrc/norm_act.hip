@@ -1,0 +1,389 @@
+// Training-mode batch norm (+ReLU / LeakyReLU / residual add) forward and backward, NHWC fp32 (gfx950).
+//
+// Replaces torch.nn.BatchNorm2d / ReLU / LeakyReLU / `out += identity` and their autograd inside smp.Unet
+// (reference src/models/train.py:341,343) and DomainDiscriminator (src/models/discriminator.py:21-33).
+//
+// All kernels here are HBM-bound streams over a [pixels][C] tensor read as float4: the launch is shaped so
+// that (total threads) % (C/4) == 0, hence every thread meets the same 4 channels on every grid-stride step
+// and keeps its per-channel partials in registers; one LDS pass folds the rows of a block, one f64 atomic
+// per channel per block folds the blocks (f64: the cross-block order no longer shows after rounding to f32).
+#include "common.h"
+
+namespace udaseg {
+
+struct StreamShape {
+  int bs;      // threads per block (multiple of 64... or of C4 when C4 is not a power of two)
+  int grid;
+  int c4;
+};
+
+// Choose block/grid so grid*bs is a multiple of c4 (see header comment).
+static StreamShape stream_shape(int64_t n4, int c4) {
+  StreamShape s;
+  s.c4 = c4;
+  int unit;  // grid must be a multiple of `unit`
+  if (c4 <= 256) {
+    s.bs = (256 / c4) * c4;
+    unit = 1;
+  } else {
+    s.bs = 256;
+    unit = (c4 + 255) / 256;
+    while ((unit * 256) % c4 != 0) ++unit;  // c4 = 512 -> 2
+  }
+  int64_t want = (n4 + (int64_t)s.bs * 4 - 1) / ((int64_t)s.bs * 4);  // ~4 float4 per thread
+  if (want > 2048) want = 2048;
+  if (want < 1) want = 1;
+  s.grid = (int)(((want + unit - 1) / unit) * unit);
+  // every channel quad needs an owning thread among the first c4 global threads
+  while ((int64_t)s.grid * s.bs < c4) s.grid += unit;
+  return s;
+}
+
+// Fold a per-thread float4 partial over the rows of the block and add it to dst[q*4 .. q*4+3] (f64 atomics).
+// Threads with equal (tid % c4) own the same channels when bs % c4 == 0; otherwise (c4 > bs) each is unique.
+__device__ __forceinline__ void block_fold_add(f32x4 v, double* dst, int c4, int q, float4* red) {
+  const int tid = threadIdx.x, bs = blockDim.x;
+  if (c4 >= bs) {
+    atomicAdd(dst + q * 4 + 0, (double)v[0]);
+    atomicAdd(dst + q * 4 + 1, (double)v[1]);
+    atomicAdd(dst + q * 4 + 2, (double)v[2]);
+    atomicAdd(dst + q * 4 + 3, (double)v[3]);
+    return;
+  }
+  red[tid] = make_float4(v[0], v[1], v[2], v[3]);
+  __syncthreads();
+  if (tid < c4) {
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    for (int r = tid; r < bs; r += c4) {
+      const float4 t = red[r];
+      s0 += t.x; s1 += t.y; s2 += t.z; s3 += t.w;
+    }
+    atomicAdd(dst + q * 4 + 0, s0);
+    atomicAdd(dst + q * 4 + 1, s1);
+    atomicAdd(dst + q * 4 + 2, s2);
+    atomicAdd(dst + q * 4 + 3, s3);
+  }
+  __syncthreads();
+}
+
+__global__ void bn_stats_kernel(const f32x4* __restrict__ y, int64_t n4, int c4, double* __restrict__ sums) {
+  __shared__ float4 red[256];
+  const int64_t T = (int64_t)gridDim.x * blockDim.x;
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int q = (int)(g % c4);
+  f32x4 s = {0, 0, 0, 0}, ss = {0, 0, 0, 0};
+  for (int64_t i = g; i < n4; i += T) {
+    const f32x4 v = y[i];
+    s += v;
+    ss += v * v;
+  }
+  block_fold_add(s, sums, c4, q, red);
+  block_fold_add(ss, sums + (size_t)c4 * 4, c4, q, red);
+}
+
+struct BnCoef {
+  f32x4 scale, shift, mean, rstd;
+};
+
+__device__ __forceinline__ BnCoef bn_coef_from_sums(const double* sums, const float* gamma, const float* beta, int c4,
+                                                    int q, int64_t pixels, float eps, f32x4* var_out) {
+  BnCoef k;
+  const double inv = 1.0 / (double)pixels;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int c = q * 4 + e;
+    const double m = sums[c] * inv;
+    double var = sums[(size_t)c4 * 4 + c] * inv - m * m;
+    var = var > 0.0 ? var : 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    k.mean[e] = (float)m;
+    k.rstd[e] = rstd;
+    k.scale[e] = gamma[c] * rstd;
+    k.shift[e] = beta[c] - (float)m * k.scale[e];
+    (*var_out)[e] = (float)var;
+  }
+  return k;
+}
+
+__global__ void bn_apply_kernel(const f32x4* __restrict__ y, const double* __restrict__ sums,
+                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                const f32x4* __restrict__ residual, f32x4* __restrict__ z, int64_t n4, int c4,
+                                int64_t pixels, float eps, float momentum, float* running_mean, float* running_var,
+                                float* save_mean, float* save_rstd, int act, float slope) {
+  const int64_t T = (int64_t)gridDim.x * blockDim.x;
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int q = (int)(g % c4);
+  f32x4 var;
+  const BnCoef k = bn_coef_from_sums(sums, gamma, beta, c4, q, pixels, eps, &var);
+  if (g < c4) {  // exactly one owner per channel quad
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = q * 4 + e;
+      if (save_mean) save_mean[c] = k.mean[e];
+      if (save_rstd) save_rstd[c] = k.rstd[e];
+      if (running_mean) {
+        const float unb = pixels > 1 ? var[e] * ((float)pixels / (float)(pixels - 1)) : var[e];
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * k.mean[e];
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+      }
+    }
+  }
+  for (int64_t i = g; i < n4; i += T) {
+    f32x4 v = y[i] * k.scale + k.shift;
+    if (residual) v += residual[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], act, slope);
+    z[i] = v;
+  }
+}
+
+__global__ void bn_apply_eval_kernel(const f32x4* __restrict__ y, const float* __restrict__ gamma,
+                                     const float* __restrict__ beta, const float* __restrict__ rm,
+                                     const float* __restrict__ rv, const f32x4* __restrict__ residual,
+                                     f32x4* __restrict__ z, int64_t n4, int c4, float eps, int act, float slope) {
+  const int64_t T = (int64_t)gridDim.x * blockDim.x;
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int q = (int)(g % c4);
+  f32x4 scale, shift;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int c = q * 4 + e;
+    const float rstd = 1.0f / sqrtf(rv[c] + eps);
+    scale[e] = gamma[c] * rstd;
+    shift[e] = beta[c] - rm[c] * scale[e];
+  }
+  for (int64_t i = g; i < n4; i += T) {
+    f32x4 v = y[i] * scale + shift;
+    if (residual) v += residual[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], act, slope);
+    z[i] = v;
+  }
+}
+
+__global__ void bn_bwd_reduce_kernel(const f32x4* __restrict__ dz, const f32x4* __restrict__ z,
+                                     const f32x4* __restrict__ y, const float* __restrict__ save_mean,
+                                     const float* __restrict__ save_rstd, int64_t n4, int c4,
+                                     double* __restrict__ bsums, int act, float slope) {
+  __shared__ float4 red[256];
+  const int64_t T = (int64_t)gridDim.x * blockDim.x;
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int q = (int)(g % c4);
+  f32x4 mean, rstd;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    mean[e] = save_mean[q * 4 + e];
+    rstd[e] = save_rstd[q * 4 + e];
+  }
+  f32x4 sg = {0, 0, 0, 0}, sgx = {0, 0, 0, 0};
+  for (int64_t i = g; i < n4; i += T) {
+    f32x4 gz = dz[i];
+    if (act != UDASEG_ACT_NONE) {
+      const f32x4 zz = z[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) gz[e] *= act_grad(zz[e], act, slope);
+    }
+    const f32x4 xh = (y[i] - mean) * rstd;
+    sg += gz;
+    sgx += gz * xh;
+  }
+  block_fold_add(sg, bsums, c4, q, red);
+  block_fold_add(sgx, bsums + (size_t)c4 * 4, c4, q, red);
+}
+
+__global__ void bn_bwd_apply_kernel(const f32x4* __restrict__ dz, const f32x4* __restrict__ z,
+                                    const f32x4* __restrict__ y, const float* __restrict__ save_mean,
+                                    const float* __restrict__ save_rstd, const float* __restrict__ gamma,
+                                    const double* __restrict__ bsums, f32x4* __restrict__ dy, f32x4* __restrict__ dres,
+                                    float* dgamma, float* dbeta, int64_t n4, int c4, int64_t pixels, int act,
+                                    float slope, int acc_dy, int acc_dres, int acc_param) {
+  const int64_t T = (int64_t)gridDim.x * blockDim.x;
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int q = (int)(g % c4);
+  f32x4 mean, rstd, scale, mg, mgx;
+  const double inv = 1.0 / (double)pixels;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int c = q * 4 + e;
+    mean[e] = save_mean[c];
+    rstd[e] = save_rstd[c];
+    scale[e] = gamma[c] * rstd[e];
+    mg[e] = (float)(bsums[c] * inv);
+    mgx[e] = (float)(bsums[(size_t)c4 * 4 + c] * inv);
+    if (g < c4) {
+      const float db = (float)bsums[c], dg = (float)bsums[(size_t)c4 * 4 + c];
+      if (dbeta) dbeta[c] = acc_param ? dbeta[c] + db : db;
+      if (dgamma) dgamma[c] = acc_param ? dgamma[c] + dg : dg;
+    }
+  }
+  for (int64_t i = g; i < n4; i += T) {
+    f32x4 gz = dz[i];
+    if (act != UDASEG_ACT_NONE) {
+      const f32x4 zz = z[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) gz[e] *= act_grad(zz[e], act, slope);
+    }
+    const f32x4 xh = (y[i] - mean) * rstd;
+    f32x4 out = scale * (gz - mg - xh * mgx);
+    if (acc_dy) out += dy[i];
+    dy[i] = out;
+    if (dres) {
+      f32x4 r = gz;
+      if (acc_dres) r += dres[i];
+      dres[i] = r;
+    }
+  }
+}
+
+__global__ void act_bwd_kernel(const f32x4* __restrict__ dz, const f32x4* __restrict__ z, f32x4* __restrict__ dy,
+                               int64_t n4, int act, float slope) {
+  const int64_t T = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += T) {
+    f32x4 gz = dz[i];
+    const f32x4 zz = z[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) gz[e] *= act_grad(zz[e], act, slope);
+    dy[i] = gz;
+  }
+}
+
+__global__ void channel_sum_kernel(const f32x4* __restrict__ x, int64_t n4, int c4, float* __restrict__ out) {
+  __shared__ float4 red[256];
+  const int64_t T = (int64_t)gridDim.x * blockDim.x;
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int q = (int)(g % c4);
+  f32x4 s = {0, 0, 0, 0};
+  for (int64_t i = g; i < n4; i += T) s += x[i];
+  const int tid = threadIdx.x, bs = blockDim.x;
+  if (c4 >= bs) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) atomicAdd(out + q * 4 + e, s[e]);
+    return;
+  }
+  red[tid] = make_float4(s[0], s[1], s[2], s[3]);
+  __syncthreads();
+  if (tid < c4) {
+    float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    for (int r = tid; r < bs; r += c4) {
+      const float4 t = red[r];
+      a0 += t.x; a1 += t.y; a2 += t.z; a3 += t.w;
+    }
+    atomicAdd(out + q * 4 + 0, a0);
+    atomicAdd(out + q * 4 + 1, a1);
+    atomicAdd(out + q * 4 + 2, a2);
+    atomicAdd(out + q * 4 + 3, a3);
+  }
+}
+
+static int check_pc(int64_t pixels, int c, const char* who) {
+  UDASEG_CHECK_ARG(pixels > 0 && c > 0 && c % 4 == 0, "%s: need pixels > 0 and channels a positive multiple of 4 (got %lld, %d)",
+                   who, (long long)pixels, c);
+  UDASEG_CHECK_ARG(c <= 4096, "%s: channels > 4096 unsupported", who);
+  return UDASEG_OK;
+}
+
+}  // namespace udaseg
+
+using namespace udaseg;
+
+extern "C" int udaseg_bn_stats(const float* y, int64_t pixels, int c, double* sums, void* stream) {
+  int rc = check_pc(pixels, c, "bn_stats");
+  if (rc) return rc;
+  UDASEG_CHECK_ARG(y && sums, "bn_stats: NULL pointer");
+  const int64_t n4 = pixels * (c / 4);
+  const StreamShape s = stream_shape(n4, c / 4);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(s.grid), dim3(s.bs), 0, as_stream(stream), (const f32x4*)y, n4, s.c4, sums);
+  UDASEG_LAUNCH_CHECK("bn_stats launch");
+  return UDASEG_OK;
+}
+
+extern "C" int udaseg_bn_apply(const float* y, const double* sums, const float* gamma, const float* beta,
+                               const float* residual, float* z, int64_t pixels, int c, float eps, float momentum,
+                               float* running_mean, float* running_var, float* save_mean, float* save_rstd, int act,
+                               float slope, void* stream) {
+  int rc = check_pc(pixels, c, "bn_apply");
+  if (rc) return rc;
+  UDASEG_CHECK_ARG(y && sums && gamma && beta && z, "bn_apply: NULL pointer");
+  UDASEG_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "bn_apply: running_mean/var must come together");
+  const int64_t n4 = pixels * (c / 4);
+  const StreamShape s = stream_shape(n4, c / 4);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(s.grid), dim3(s.bs), 0, as_stream(stream), (const f32x4*)y, sums, gamma, beta,
+                     (const f32x4*)residual, (f32x4*)z, n4, s.c4, pixels, eps, momentum, running_mean, running_var,
+                     save_mean, save_rstd, act, slope);
+  UDASEG_LAUNCH_CHECK("bn_apply launch");
+  return UDASEG_OK;
+}
+
+extern "C" int udaseg_bn_apply_eval(const float* y, const float* gamma, const float* beta, const float* running_mean,
+                                    const float* running_var, const float* residual, float* z, int64_t pixels, int c,
+                                    float eps, int act, float slope, void* stream) {
+  int rc = check_pc(pixels, c, "bn_apply_eval");
+  if (rc) return rc;
+  UDASEG_CHECK_ARG(y && gamma && beta && running_mean && running_var && z, "bn_apply_eval: NULL pointer");
+  const int64_t n4 = pixels * (c / 4);
+  const StreamShape s = stream_shape(n4, c / 4);
+  hipLaunchKernelGGL(bn_apply_eval_kernel, dim3(s.grid), dim3(s.bs), 0, as_stream(stream), (const f32x4*)y, gamma, beta,
+                     running_mean, running_var, (const f32x4*)residual, (f32x4*)z, n4, s.c4, eps, act, slope);
+  UDASEG_LAUNCH_CHECK("bn_apply_eval launch");
+  return UDASEG_OK;
+}
+
+extern "C" int udaseg_bn_bwd_reduce(const float* dz, const float* z, const float* y, const float* save_mean,
+                                    const float* save_rstd, int64_t pixels, int c, double* bsums, int act, float slope,
+                                    void* stream) {
+  int rc = check_pc(pixels, c, "bn_bwd_reduce");
+  if (rc) return rc;
+  UDASEG_CHECK_ARG(dz && y && save_mean && save_rstd && bsums, "bn_bwd_reduce: NULL pointer");
+  UDASEG_CHECK_ARG(act == UDASEG_ACT_NONE || z, "bn_bwd_reduce: z required when an activation follows the norm");
+  const int64_t n4 = pixels * (c / 4);
+  const StreamShape s = stream_shape(n4, c / 4);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(s.grid), dim3(s.bs), 0, as_stream(stream), (const f32x4*)dz, (const f32x4*)z,
+                     (const f32x4*)y, save_mean, save_rstd, n4, s.c4, bsums, act, slope);
+  UDASEG_LAUNCH_CHECK("bn_bwd_reduce launch");
+  return UDASEG_OK;
+}
+
+extern "C" int udaseg_bn_bwd_apply(const float* dz, const float* z, const float* y, const float* save_mean,
+                                   const float* save_rstd, const float* gamma, const double* bsums, float* dy,
+                                   float* dres, float* dgamma, float* dbeta, int64_t pixels, int c, int act,
+                                   float slope, int accumulate_dy, int accumulate_dres, int accumulate_param,
+                                   void* stream) {
+  int rc = check_pc(pixels, c, "bn_bwd_apply");
+  if (rc) return rc;
+  UDASEG_CHECK_ARG(dz && y && save_mean && save_rstd && gamma && bsums && dy, "bn_bwd_apply: NULL pointer");
+  UDASEG_CHECK_ARG(act == UDASEG_ACT_NONE || z, "bn_bwd_apply: z required when an activation follows the norm");
+  const int64_t n4 = pixels * (c / 4);
+  const StreamShape s = stream_shape(n4, c / 4);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(s.grid), dim3(s.bs), 0, as_stream(stream), (const f32x4*)dz, (const f32x4*)z,
+                     (const f32x4*)y, save_mean, save_rstd, gamma, bsums, (f32x4*)dy, (f32x4*)dres, dgamma, dbeta, n4, s.c4,
+                     pixels, act, slope, accumulate_dy, accumulate_dres, accumulate_param);
+  UDASEG_LAUNCH_CHECK("bn_bwd_apply launch");
+  return UDASEG_OK;
+}
+
+extern "C" int udaseg_act_bwd(const float* dz, const float* z, float* dy, int64_t count, int act, float slope,
+                              void* stream) {
+  UDASEG_CHECK_ARG(dz && z && dy && count > 0 && count % 4 == 0, "act_bwd: bad arguments");
+  const int64_t n4 = count / 4;
+  int grid = (int)((n4 + 1023) / 1024 > 2048 ? 2048 : (n4 + 1023) / 1024);
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(grid), dim3(256), 0, as_stream(stream), (const f32x4*)dz, (const f32x4*)z,
+                     (f32x4*)dy, n4, act, slope);
+  UDASEG_LAUNCH_CHECK("act_bwd launch");
+  return UDASEG_OK;
+}
+
+extern "C" int udaseg_channel_sum(const float* x, int64_t pixels, int c, float* out, int accumulate, void* stream) {
+  int rc = check_pc(pixels, c, "channel_sum");
+  if (rc) return rc;
+  UDASEG_CHECK_ARG(x && out, "channel_sum: NULL pointer");
+  hipStream_t st = as_stream(stream);
+  if (!accumulate) {
+    hipError_t e = hipMemsetAsync(out, 0, (size_t)c * sizeof(float), st);
+    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(channel_sum)");
+  }
+  const int64_t n4 = pixels * (c / 4);
+  const StreamShape s = stream_shape(n4, c / 4);
+  hipLaunchKernelGGL(channel_sum_kernel, dim3(s.grid), dim3(s.bs), 0, st, (const f32x4*)x, n4, s.c4, out);
+  UDASEG_LAUNCH_CHECK("channel_sum launch");
+  return UDASEG_OK;
+}

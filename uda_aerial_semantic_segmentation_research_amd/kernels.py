@@ -1,0 +1,212 @@
+"""Thin tensor-level wrappers over the C-ABI (one Python function per entry point of include/udaseg.h).
+
+No autograd here and no arithmetic: these marshal ``torch.Tensor`` storage pointers, sizes and the current HIP
+stream into libudaseg_hip.so.  All activations are NHWC fp32 contiguous tensors ``[N, H, W, C]`` with C % 4 == 0.
+"""
+import torch
+
+from . import _lib
+from ._lib import ACT_LEAKY, ACT_NONE, ConvDesc, check
+
+_byref = _lib.C.byref
+
+
+def stream():
+    """hipStream_t of torch's current stream (kernels are enqueued there, asynchronously)."""
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def conv_desc(n, hi, wi, ci, co, k, stride, pad):
+    ho = (hi + 2 * pad - k) // stride + 1
+    wo = (wi + 2 * pad - k) // stride + 1
+    return ConvDesc(n, hi, wi, ci, ho, wo, co, k, k, stride, pad)
+
+
+def conv2d_fwd(d, x, w, bias, y, act=ACT_NONE, slope=0.0, accumulate=False, st=None):
+    check(_lib.load().udaseg_conv2d_fwd(_byref(d), x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), act, slope,
+                                         int(accumulate), st if st is not None else stream()), "conv2d_fwd")
+
+
+def conv2d_dgrad(d, dy, w_t, dx, accumulate=False, st=None):
+    check(_lib.load().udaseg_conv2d_dgrad(_byref(d), dy.data_ptr(), w_t.data_ptr(), dx.data_ptr(), int(accumulate),
+                                           st if st is not None else stream()), "conv2d_dgrad")
+
+
+def conv2d_wgrad(d, x, dy, dw, accumulate=False, st=None):
+    check(_lib.load().udaseg_conv2d_wgrad(_byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), int(accumulate),
+                                           st if st is not None else stream()), "conv2d_wgrad")
+
+
+def pack_dgrad_weights(d, w, w_t, st=None):
+    check(_lib.load().udaseg_pack_dgrad_weights(_byref(d), w.data_ptr(), w_t.data_ptr(),
+                                                 st if st is not None else stream()), "pack_dgrad_weights")
+
+
+def conv_flops(d):
+    return _lib.load().udaseg_conv_flops(_byref(d))
+
+
+def nchw_to_nhwc(x, cpad=None, st=None):
+    """[N,C,H,W] contiguous -> [N,H,W,cpad] (zero-padded channels)."""
+    n, c, h, w = x.shape
+    cpad = cpad or ((c + 3) // 4) * 4
+    if not x.is_contiguous():
+        x = x.contiguous()
+    y = torch.empty((n, h, w, cpad), device=x.device, dtype=torch.float32)
+    check(_lib.load().udaseg_nchw_to_nhwc(x.data_ptr(), y.data_ptr(), n, c, h, w, cpad,
+                                           st if st is not None else stream()), "nchw_to_nhwc")
+    return y
+
+
+def bn_stats(y, sums, st=None):
+    c = y.shape[-1]
+    check(_lib.load().udaseg_bn_stats(y.data_ptr(), y.numel() // c, c, sums.data_ptr(),
+                                       st if st is not None else stream()), "bn_stats")
+
+
+def bn_apply(y, sums, gamma, beta, residual, z, eps, momentum, running_mean, running_var, save_mean, save_rstd, act, slope,
+             st=None):
+    c = y.shape[-1]
+    check(_lib.load().udaseg_bn_apply(y.data_ptr(), sums.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(residual),
+                                       z.data_ptr(), y.numel() // c, c, eps, momentum, _ptr(running_mean), _ptr(running_var),
+                                       _ptr(save_mean), _ptr(save_rstd), act, slope,
+                                       st if st is not None else stream()), "bn_apply")
+
+
+def bn_apply_eval(y, gamma, beta, running_mean, running_var, residual, z, eps, act, slope, st=None):
+    c = y.shape[-1]
+    check(_lib.load().udaseg_bn_apply_eval(y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), running_mean.data_ptr(),
+                                            running_var.data_ptr(), _ptr(residual), z.data_ptr(), y.numel() // c, c, eps, act,
+                                            slope, st if st is not None else stream()), "bn_apply_eval")
+
+
+def bn_bwd_reduce(dz, z, y, save_mean, save_rstd, bsums, act, slope, st=None):
+    c = y.shape[-1]
+    check(_lib.load().udaseg_bn_bwd_reduce(dz.data_ptr(), _ptr(z), y.data_ptr(), save_mean.data_ptr(), save_rstd.data_ptr(),
+                                            y.numel() // c, c, bsums.data_ptr(), act, slope,
+                                            st if st is not None else stream()), "bn_bwd_reduce")
+
+
+def bn_bwd_apply(dz, z, y, save_mean, save_rstd, gamma, bsums, dy, dres, dgamma, dbeta, act, slope, accumulate_dy=False,
+                 accumulate_dres=False, accumulate_param=False, st=None):
+    c = y.shape[-1]
+    check(_lib.load().udaseg_bn_bwd_apply(dz.data_ptr(), _ptr(z), y.data_ptr(), save_mean.data_ptr(), save_rstd.data_ptr(),
+                                           gamma.data_ptr(), bsums.data_ptr(), dy.data_ptr(), _ptr(dres), _ptr(dgamma),
+                                           _ptr(dbeta), y.numel() // c, c, act, slope, int(accumulate_dy),
+                                           int(accumulate_dres), int(accumulate_param),
+                                           st if st is not None else stream()), "bn_bwd_apply")
+
+
+def act_bwd(dz, z, dy, act, slope, st=None):
+    check(_lib.load().udaseg_act_bwd(dz.data_ptr(), z.data_ptr(), dy.data_ptr(), dz.numel(), act, slope,
+                                      st if st is not None else stream()), "act_bwd")
+
+
+def channel_sum(x, out, accumulate=False, st=None):
+    c = x.shape[-1]
+    check(_lib.load().udaseg_channel_sum(x.data_ptr(), x.numel() // c, c, out.data_ptr(), int(accumulate),
+                                          st if st is not None else stream()), "channel_sum")
+
+
+def maxpool_fwd(x, st=None):
+    n, h, w, c = x.shape
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    y = torch.empty((n, ho, wo, c), device=x.device, dtype=torch.float32)
+    idx = torch.empty((n, ho, wo, c), device=x.device, dtype=torch.uint8)
+    check(_lib.load().udaseg_maxpool3x3s2_fwd(x.data_ptr(), y.data_ptr(), idx.data_ptr(), n, h, w, c,
+                                               st if st is not None else stream()), "maxpool_fwd")
+    return y, idx
+
+
+def maxpool_bwd(dy, idx, dx, accumulate=False, st=None):
+    n, h, w, c = dx.shape
+    check(_lib.load().udaseg_maxpool3x3s2_bwd(dy.data_ptr(), idx.data_ptr(), dx.data_ptr(), n, h, w, c, int(accumulate),
+                                               st if st is not None else stream()), "maxpool_bwd")
+
+
+def upsample2x_concat_fwd(a, skip, st=None):
+    n, h, w, ca = a.shape
+    cb = 0 if skip is None else skip.shape[-1]
+    out = torch.empty((n, 2 * h, 2 * w, ca + cb), device=a.device, dtype=torch.float32)
+    check(_lib.load().udaseg_upsample2x_concat_fwd(a.data_ptr(), _ptr(skip), out.data_ptr(), n, h, w, ca, cb,
+                                                    st if st is not None else stream()), "upsample2x_concat_fwd")
+    return out
+
+
+def upsample2x_concat_bwd(dout, da, dskip, ca, cb, accumulate_da=False, accumulate_dskip=False, st=None):
+    n, h2, w2, _ = dout.shape
+    check(_lib.load().udaseg_upsample2x_concat_bwd(dout.data_ptr(), _ptr(da), _ptr(dskip), n, h2 // 2, w2 // 2, ca, cb,
+                                                    int(accumulate_da), int(accumulate_dskip),
+                                                    st if st is not None else stream()), "upsample2x_concat_bwd")
+
+
+def ce_fwd(logits_base, target, pixels, classes, ldc, lse, partials, loss, st=None):
+    check(_lib.load().udaseg_ce_fwd(logits_base.data_ptr(), target.data_ptr(), pixels, classes, ldc, lse.data_ptr(),
+                                     partials.data_ptr(), loss.data_ptr(), st if st is not None else stream()), "ce_fwd")
+
+
+def ce_bwd(logits_base, target, lse, grad_out, pixels, classes, ldc, dlogits, st=None):
+    check(_lib.load().udaseg_ce_bwd(logits_base.data_ptr(), target.data_ptr(), lse.data_ptr(), _ptr(grad_out), pixels, classes,
+                                     ldc, dlogits.data_ptr(), st if st is not None else stream()), "ce_bwd")
+
+
+def gap_linear_sigmoid_fwd(z, w, b, st=None):
+    n, h, wd, c = z.shape
+    hw = h * wd
+    splits = _lib.load().udaseg_gap_splits(hw)
+    partial = torch.empty((n, splits, c), device=z.device, dtype=torch.float32)
+    pooled = torch.empty((n, c), device=z.device, dtype=torch.float32)
+    p = torch.empty((n, 1), device=z.device, dtype=torch.float32)
+    check(_lib.load().udaseg_gap_linear_sigmoid_fwd(z.data_ptr(), w.data_ptr(), b.data_ptr(), partial.data_ptr(),
+                                                     pooled.data_ptr(), p.data_ptr(), n, hw, c,
+                                                     st if st is not None else stream()), "gap_linear_sigmoid_fwd")
+    return p, pooled
+
+
+def gap_linear_sigmoid_bwd(dp, p, pooled, w, dz, dw, db, accumulate_param=False, st=None):
+    n, h, wd, c = dz.shape
+    check(_lib.load().udaseg_gap_linear_sigmoid_bwd(dp.data_ptr(), p.data_ptr(), pooled.data_ptr(), w.data_ptr(), dz.data_ptr(),
+                                                     dw.data_ptr(), db.data_ptr(), n, h * wd, c, int(accumulate_param),
+                                                     st if st is not None else stream()), "gap_linear_sigmoid_bwd")
+
+
+def bce_logits_fwd(x, label, weight, loss, accumulate=False, st=None):
+    check(_lib.load().udaseg_bce_logits_fwd(x.data_ptr(), x.numel(), label, weight, loss.data_ptr(), int(accumulate),
+                                             st if st is not None else stream()), "bce_logits_fwd")
+
+
+def bce_logits_bwd(x, label, weight, grad_out, dx, accumulate=False, st=None):
+    check(_lib.load().udaseg_bce_logits_bwd(x.data_ptr(), x.numel(), label, weight, _ptr(grad_out), dx.data_ptr(),
+                                             int(accumulate), st if st is not None else stream()), "bce_logits_bwd")
+
+
+def adam_flat(p, g, m, v, count, lr, beta1, beta2, eps, bc1, bc2, st=None):
+    check(_lib.load().udaseg_adam_flat(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), count, lr, beta1, beta2, eps,
+                                        bc1, bc2, st if st is not None else stream()), "adam_flat")
+
+
+def fill(t, value, st=None):
+    check(_lib.load().udaseg_fill_f32(t.data_ptr(), t.numel(), value, st if st is not None else stream()), "fill_f32")
+
+
+def axpy(y, x, alpha=1.0, st=None):
+    check(_lib.load().udaseg_axpy_f32(y.data_ptr(), x.data_ptr(), y.numel(), alpha, st if st is not None else stream()),
+          "axpy_f32")
+
+
+def prof_enable(on):
+    check(_lib.load().udaseg_prof_enable(int(on)))
+
+
+def prof_reset():
+    check(_lib.load().udaseg_prof_reset())
+
+
+def prof_read(family):
+    ms, fl, n = _lib.C.c_double(), _lib.C.c_double(), _lib.C.c_int64()
+    check(_lib.load().udaseg_prof_read(family, _byref(ms), _byref(fl), _byref(n)), "prof_read")
+    return ms.value, fl.value, n.value
