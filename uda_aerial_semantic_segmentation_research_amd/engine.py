@@ -1,0 +1,341 @@
+"""Shared machinery of the HIP-backed networks: parameter arenas, layer holders, conv+BN+activation plans.
+
+Design (MI355X-first):
+* every parameter of a network lives in ONE flat fp32 arena in HBM (conv weights physically OHWI, channel counts
+  padded to multiples of 4); the ``nn.Parameter`` objects the reference's code sees (OIHW shapes, smp / reference
+  ``state_dict`` keys) are strided views into it.  Gradients are produced into a mirror arena, so the optimizer is one
+  fused pass and the data-parallel all-reduce works on large contiguous buckets;
+* a network's forward/backward is an explicit plan of C-ABI kernel launches behind a single ``autograd.Function``
+  (no per-op autograd graph, no per-op allocator traffic beyond activations).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import kernels as K
+from ._lib import ACT_LEAKY, ACT_NONE
+
+ALIGN = 64  # floats; every arena entry starts on a 256-byte boundary
+
+
+def ceil4(c):
+    return (c + 3) // 4 * 4
+
+
+class ConvP(nn.Module):
+    """Parameter holder for one convolution (logical OIHW ``weight``, optional ``bias``); no forward of its own."""
+
+    def __init__(self, cin, cout, k, stride=1, pad=0, bias=False):
+        super().__init__()
+        self.cin, self.cout, self.k, self.stride, self.pad = cin, cout, k, stride, pad
+        self.weight = nn.Parameter(torch.empty(cout, cin, k, k))
+        self.bias = nn.Parameter(torch.empty(cout)) if bias else None
+        self.needs_dgrad = True
+
+    @property
+    def cin_p(self):
+        return ceil4(self.cin)
+
+    @property
+    def cout_p(self):
+        return ceil4(self.cout)
+
+    def extra_repr(self):
+        return f"{self.cin}, {self.cout}, kernel_size={self.k}, stride={self.stride}, padding={self.pad}, bias={self.bias is not None}"
+
+
+class BNP(nn.Module):
+    """Parameter/buffer holder for one BatchNorm2d (eps 1e-5, momentum 0.1: the traced reference values)."""
+
+    def __init__(self, c, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.c, self.eps, self.momentum = c, eps, momentum
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+    def extra_repr(self):
+        return f"{self.c}, eps={self.eps}, momentum={self.momentum}"
+
+
+class ArenaModule(nn.Module):
+    """Base of the HIP-backed networks: owns the flat parameter / buffer arenas."""
+
+    def __init__(self):
+        super().__init__()
+        self._arena = None          # flat fp32 parameters
+        self._buf_arena = None      # flat fp32 BN running stats
+        self._entries = []          # (param, offset, numel_physical, physical_shape, logical_view_fn)
+        self._param_list = []
+        self._wt_arena = None       # dgrad-packed weights (scratch, refreshed every backward)
+        self._wt_off = {}
+        self._nbt = None            # int64 arena of the BN num_batches_tracked counters
+        self._idx = {}
+        self._nbn = 0
+
+    # ---- arena construction ------------------------------------------------------------------------------------
+    def _phys_shape(self, owner, name, p):
+        if isinstance(owner, ConvP) and name == "weight":
+            return (owner.cout_p, owner.k, owner.k, owner.cin_p)
+        return (ceil4(p.numel()),)
+
+    @staticmethod
+    def _logical_view(flat, owner, name, p_shape):
+        if isinstance(owner, ConvP) and name == "weight":
+            co, ci, k, _ = p_shape
+            return flat.view(owner.cout_p, k, k, owner.cin_p)[:co, :, :, :ci].permute(0, 3, 1, 2)
+        return flat[: p_shape[0]] if len(p_shape) == 1 else flat.view(p_shape)
+
+    def _owners(self):
+        for mod in self.modules():
+            for name, p in mod._parameters.items():
+                if p is not None:
+                    yield mod, name, p
+
+    def build_arena(self, device=None):
+        """(Re)build the flat arenas from the parameters' current values and re-point ``.data`` into them."""
+        owners = list(self._owners())
+        device = device or owners[0][2].device
+        layout, off = [], 0
+        for mod, name, p in owners:
+            shp = self._phys_shape(mod, name, p)
+            n = math.prod(shp)
+            layout.append((mod, name, p, off, n, shp))
+            off += (n + ALIGN - 1) // ALIGN * ALIGN
+        arena = torch.zeros(off, device=device, dtype=torch.float32)
+        self._entries, self._param_list = [], []
+        with torch.no_grad():
+            for mod, name, p, o, n, shp in layout:
+                view = self._logical_view(arena[o:o + n], mod, name, tuple(p.shape))
+                view.copy_(p.data.to(device=device, dtype=torch.float32))
+                p.data = view
+                self._entries.append((p, o, n, shp, mod, name))
+                self._param_list.append(p)
+        self._arena = arena
+        # BN running statistics
+        bns = [m for m in self.modules() if isinstance(m, BNP)]
+        boff, blay = 0, []
+        for m in bns:
+            blay.append((m, boff))
+            boff += 2 * ((m.c + ALIGN - 1) // ALIGN * ALIGN)
+        bufs = torch.zeros(max(boff, 1), device=device, dtype=torch.float32)
+        with torch.no_grad():
+            for m, o in blay:
+                half = (m.c + ALIGN - 1) // ALIGN * ALIGN
+                rm, rv = bufs[o:o + m.c], bufs[o + half:o + half + m.c]
+                rm.copy_(m.running_mean.to(device))
+                rv.copy_(m.running_var.to(device))
+                m._buffers["running_mean"], m._buffers["running_var"] = rm, rv
+        self._buf_arena = bufs
+        nbt = torch.zeros(max(len(bns), 1), device=device, dtype=torch.long)
+        with torch.no_grad():
+            for i, m in enumerate(bns):
+                nbt[i] = m.num_batches_tracked.to(device)
+                m._buffers["num_batches_tracked"] = nbt[i]
+        self._nbt = nbt
+        self._nbn = sum(2 * ceil4(m.c) for m in bns)
+        self._idx = {(id(e[4]), e[5]): (e[1], e[2], e[3]) for e in self._entries}
+        # scratch for dgrad-packed weights
+        self._wt_off, woff = {}, 0
+        for m in self.modules():
+            if isinstance(m, ConvP) and m.needs_dgrad:
+                self._wt_off[id(m)] = woff
+                woff += m.cout_p * m.k * m.k * m.cin_p
+        self._wt_arena = torch.empty(max(woff, 4), device=device, dtype=torch.float32)
+        return self
+
+    def _arena_ok(self, full=True):
+        if self._arena is None:
+            return False
+        base = self._arena.data_ptr()
+        ents = self._entries if full else (self._entries[0], self._entries[-1])
+        for p, o, n, shp, mod, name in ents:
+            if p.data_ptr() != base + 4 * o or p.device != self._arena.device:
+                return False
+        return True
+
+    def ensure_arena(self):
+        """Cheap per-forward check (first/last entry); anything that re-homes parameters goes through _apply."""
+        if not self._arena_ok(full=False):
+            self.build_arena()
+
+    def tick_batchnorm_counters(self):
+        self._nbt.add_(1)
+
+    def _apply(self, fn, *a, **kw):
+        out = super()._apply(fn, *a, **kw)
+        self._arena = None  # .to()/.cuda() replaced the parameter storages: rebuild lazily
+        return out
+
+    # ---- helpers used by the plans -------------------------------------------------------------------------------
+    def phys_weight(self, conv):
+        """The conv's weight as its physical OHWI tensor [co_p, k, k, ci_p] (a view of the arena)."""
+        for p, o, n, shp, mod, name in self._entries_of(conv):
+            if name == "weight":
+                return self._arena[o:o + n].view(shp)
+        raise KeyError("conv not in arena")
+
+    def _entries_of(self, mod):
+        return [e for e in self._entries if e[4] is mod]
+
+    def entry_index(self):
+        """{(id(module), name): (offset, numel, phys_shape)}"""
+        return self._idx
+
+    def grad_views(self, garena):
+        """Logical-shape gradient views (one per parameter, in ``self._param_list`` order) over a grad arena."""
+        outs = []
+        for p, o, n, shp, mod, name in self._entries:
+            outs.append(self._logical_view(garena[o:o + n], mod, name, tuple(p.shape)))
+        return outs
+
+
+class Plan:
+    """One forward (and later backward) pass over an ArenaModule: scratch arenas + the launch helpers."""
+
+    def __init__(self, net, training, save):
+        self.net = net
+        self.training = training
+        self.save = save
+        self.st = K.stream()
+        self.idx = net.entry_index()
+        dev = net._arena.device
+        nbn = net._nbn
+        self.dev = dev
+        if training:
+            self.stats = torch.zeros(max(nbn, 2), dtype=torch.float64, device=dev)      # [sum | sumsq] per BN
+            self.saved_stats = torch.empty(max(nbn, 2), dtype=torch.float32, device=dev)  # [mean | rstd] per BN
+        self._stat_off = 0
+        self.garena = None
+        self.bstats = None
+        self._bstat_off = 0
+        self.conv_flops = 0.0
+
+    # -- parameter access
+    def w(self, conv):
+        o, n, shp = self.idx[(id(conv), "weight")]
+        return self.net._arena[o:o + n].view(shp)
+
+    def b(self, conv):
+        o, n, shp = self.idx[(id(conv), "bias")]
+        return self.net._arena[o:o + n]
+
+    def pvec(self, mod, name):
+        o, n, shp = self.idx[(id(mod), name)]
+        return self.net._arena[o:o + n]
+
+    def gvec(self, mod, name):
+        o, n, shp = self.idx[(id(mod), name)]
+        return self.garena[o:o + n]
+
+    def gw(self, conv):
+        o, n, shp = self.idx[(id(conv), "weight")]
+        return self.garena[o:o + n].view(shp)
+
+    def offset_of(self, mod, name="weight"):
+        return self.idx[(id(mod), name)][0]
+
+    # -- forward pieces
+    def conv(self, conv, x, act=ACT_NONE, slope=0.0):
+        n, h, w, ci = x.shape
+        assert ci == conv.cin_p, (ci, conv.cin_p)
+        d = K.conv_desc(n, h, w, ci, conv.cout_p, conv.k, conv.stride, conv.pad)
+        y = torch.empty((n, d.ho, d.wo, conv.cout_p), device=x.device, dtype=torch.float32)
+        K.conv2d_fwd(d, x, self.w(conv), self.b(conv) if conv.bias is not None else None, y, act, slope, False, self.st)
+        return y, d
+
+    def bn(self, bn, y, act, slope, residual=None):
+        c = ceil4(bn.c)
+        z = torch.empty_like(y)
+        gamma, beta = self.pvec(bn, "weight"), self.pvec(bn, "bias")
+        if self.training:
+            o = self._stat_off
+            self._stat_off += 2 * c
+            sums = self.stats[o:o + 2 * c]
+            mean, rstd = self.saved_stats[o:o + c], self.saved_stats[o + c:o + 2 * c]
+            K.bn_stats(y, sums, self.st)
+            K.bn_apply(y, sums, gamma, beta, residual, z, bn.eps, bn.momentum, bn.running_mean, bn.running_var, mean, rstd,
+                       act, slope, self.st)
+            return z, (mean, rstd)
+        K.bn_apply_eval(y, gamma, beta, bn.running_mean, bn.running_var, residual, z, bn.eps, act, slope, self.st)
+        return z, None
+
+    def conv_bn_act(self, conv, bn, x, act=ACT_LEAKY, slope=0.0, residual=None):
+        """z = act(bn(conv(x)) (+ residual)); returns (z, record for backward)."""
+        y, d = self.conv(conv, x)
+        z, ms = self.bn(bn, y, act, slope, residual)
+        rec = (conv, bn, d, x, y, z, ms, act, slope) if self.save else None
+        return z, rec
+
+    # -- backward pieces
+    def begin_backward(self):
+        net = self.net
+        self.st = K.stream()
+        self.garena = torch.zeros_like(net._arena)
+        nbn = net._nbn
+        self.bstats = torch.zeros(max(nbn, 2), dtype=torch.float64, device=self.dev)
+        self._bstat_off = 0
+
+    def packed_wt(self, conv):
+        o = self.net._wt_off[id(conv)]
+        n = conv.cout_p * conv.k * conv.k * conv.cin_p
+        return self.net._wt_arena[o:o + n]
+
+    def conv_bwd(self, conv, d, x, dy, dx=None, dx_acc=False):
+        """dW (+ dbias) into the grad arena; dx (+)= dgrad when dx is given."""
+        K.conv2d_wgrad(d, x, dy, self.gw(conv), True, self.st)
+        if conv.bias is not None:
+            K.channel_sum(dy, self.gvec(conv, "bias"), True, self.st)
+        if dx is not None:
+            wt = self.packed_wt(conv)
+            K.pack_dgrad_weights(d, self.w(conv), wt, self.st)
+            K.conv2d_dgrad(d, dy, wt, dx, dx_acc, self.st)
+
+    def bn_bwd(self, bn, y, z, ms, dz, act, slope, dres=None, dres_acc=False):
+        """In place: dz becomes dy (grad w.r.t. the conv output).  dres (+)= masked grad for the residual branch."""
+        c = ceil4(bn.c)
+        o = self._bstat_off
+        self._bstat_off += 2 * c
+        bs = self.bstats[o:o + 2 * c]
+        mean, rstd = ms
+        gamma = self.pvec(bn, "weight")
+        K.bn_bwd_reduce(dz, z, y, mean, rstd, bs, act, slope, self.st)
+        K.bn_bwd_apply(dz, z, y, mean, rstd, gamma, bs, dz, dres, self.gvec(bn, "weight"), self.gvec(bn, "bias"), act, slope,
+                       False, dres_acc, False, self.st)
+        return dz
+
+    def conv_bn_act_bwd(self, rec, dz, dx=None, dx_acc=False, dres=None, dres_acc=False):
+        conv, bn, d, x, y, z, ms, act, slope = rec
+        dy = self.bn_bwd(bn, y, z, ms, dz, act, slope, dres, dres_acc)
+        self.conv_bwd(conv, d, x, dy, dx, dx_acc)
+
+
+class GradSlots:
+    """Gradient buffers of activations during one backward: first writer overwrites, later writers accumulate."""
+
+    def __init__(self):
+        self._g = {}
+
+    def slot(self, t):
+        """-> (buffer, accumulate?)"""
+        k = id(t)
+        if k in self._g:
+            return self._g[k], True
+        b = torch.empty_like(t)
+        self._g[k] = b
+        return b, False
+
+    def get(self, t):
+        return self._g[id(t)]
+
+    def has(self, t):
+        return id(t) in self._g
+
+    def put(self, t, g):
+        self._g[id(t)] = g
+
+    def pop(self, t):
+        return self._g.pop(id(t))

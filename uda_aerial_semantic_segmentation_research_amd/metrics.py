@@ -1,0 +1,83 @@
+"""``DomainAdaptationMetrics`` -- mirror of reference ``src/models/metrics.py:5-73`` (running domain accuracy and the
+entropy of ``sigmoid(pred)``; the reference re-applies the sigmoid to probabilities), plus the per-batch
+segmentation metrics of ``SegmentationTrainer.calculate_metrics`` (reference ``src/models/train.py:225-243``).
+
+These are logging side-cars, not the hot path: plain torch ops with ONE device->host transfer per call (the reference
+issues >= 25 ``.item()`` syncs per step).
+"""
+import torch
+import torch.nn.functional as F
+
+
+class DomainAdaptationMetrics:
+    """Track metrics for domain adaptation training."""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.source_correct = 0
+        self.source_total = 0
+        self.target_correct = 0
+        self.target_total = 0
+        self.domain_entropy_sum = 0.0
+        self.feature_alignment_sum = 0.0
+        self.n_batches = 0
+
+    def update(self, source_pred, target_pred, source_features=None, target_features=None):
+        source_pred, target_pred = source_pred.detach(), target_pred.detach()
+        p = torch.sigmoid(torch.cat([source_pred, target_pred], dim=0))
+        ent = (-p * torch.log(p + 1e-10) - (1 - p) * torch.log(1 - p + 1e-10)).mean()
+        packed = torch.stack([(source_pred >= 0.5).sum().float(), (target_pred < 0.5).sum().float(), ent]).cpu()
+        self.source_correct += int(packed[0])
+        self.source_total += source_pred.size(0)
+        self.target_correct += int(packed[1])
+        self.target_total += target_pred.size(0)
+        self.domain_entropy_sum += float(packed[2])
+        if source_features is not None and target_features is not None:
+            a = F.normalize(source_features.mean(0), dim=0)
+            b = F.normalize(target_features.mean(0), dim=0)
+            self.feature_alignment_sum += F.cosine_similarity(a, b, dim=0).item()
+        self.n_batches += 1
+
+    def update_domain_accuracy(self, source_pred, target_pred):
+        self.source_correct += int((source_pred >= 0.5).sum().item())
+        self.source_total += source_pred.size(0)
+        self.target_correct += int((target_pred < 0.5).sum().item())
+        self.target_total += target_pred.size(0)
+
+    def get_metrics(self):
+        return {
+            "source_domain_acc": f"{self.source_correct / max(self.source_total, 1):.4f}",
+            "target_domain_acc": f"{self.target_correct / max(self.target_total, 1):.4f}",
+            "domain_confusion": f"{self.domain_entropy_sum / max(self.n_batches, 1):.4f}",
+        }
+
+    def get_confusion_metrics(self):
+        return {
+            "domain_entropy": self.domain_entropy_sum / max(self.n_batches, 1),
+            "feature_alignment": self.feature_alignment_sum / max(self.n_batches, 1),
+        }
+
+
+def segmentation_metrics(outputs, masks, num_classes):
+    """{'iou': macro Jaccard over the classes present, 'accuracy', 'iou_class_k': binary Jaccard of class k}.
+
+    Definitions follow torchmetrics' JaccardIndex (multiclass macro: classes absent from both prediction and target
+    carry no weight; binary: tp / (tp + fp + fn), 0 when empty), which the reference instantiates at
+    ``src/models/train.py:209-222``.  One bincount confusion matrix on the device, one transfer.
+    """
+    pred = outputs.argmax(dim=1)
+    k = num_classes
+    cm = torch.bincount((masks.reshape(-1) * k + pred.reshape(-1)), minlength=k * k).reshape(k, k).double()
+    tp = cm.diag()
+    denom = cm.sum(0) + cm.sum(1) - tp
+    iou_c = torch.where(denom > 0, tp / denom.clamp_min(1), torch.zeros_like(tp))
+    present = (cm.sum(0) + cm.sum(1)) > 0
+    macro = (iou_c * present).sum() / present.sum().clamp_min(1)
+    acc = tp.sum() / cm.sum().clamp_min(1)
+    host = torch.cat([macro.reshape(1), acc.reshape(1), iou_c]).cpu().tolist()
+    out = {"iou": host[0], "accuracy": host[1]}
+    for c in range(k):
+        out[f"iou_class_{c}"] = host[2 + c]
+    return out

@@ -1,0 +1,304 @@
+"""``Unet`` -- the encoder-decoder the reference creates with ``smp.Unet(encoder_name=..., encoder_weights=...,
+in_channels=..., classes=...)`` (reference ``src/test_system.py:90-95``, ``src/models/train.py:572-577``), as a
+drop-in ``nn.Module`` whose arithmetic runs in libudaseg_hip.so.
+
+Architecture (pinned by the reference's traced-graph fixture): torchvision-ResNet encoder
+(resnet18/34: BasicBlock, resnet50: Bottleneck with the stride on the 3x3), smp ``UnetDecoder`` with channels
+(256,128,64,32,16) -- nearest x2 upsample, ``cat([up, skip], 1)``, two conv3x3+BN+ReLU per block -- and a
+``Conv2d(16, classes, 3, padding=1)`` head.  ``state_dict`` keys follow smp (``encoder.layer1.0.conv1.weight``,
+``decoder.blocks.0.conv1.0.weight``, ``segmentation_head.0.bias`` ...), so reference checkpoints
+(``src/models/train.py:491-500``) load unchanged.
+
+``forward`` returns logits shaped ``[N, classes, H, W]`` like the reference; physically they are NHWC with the class
+dimension padded to a multiple of 4 (a strided view), which ``losses.CrossEntropyLoss`` consumes without a copy.
+"""
+import warnings
+
+import torch
+import torch.nn as nn
+
+from . import kernels as K
+from ._lib import ACT_LEAKY, ACT_NONE, require_gpu
+from .engine import ArenaModule, BNP, ConvP, GradSlots, Plan, ceil4
+
+ENCODERS = {
+    "resnet18": ("basic", (2, 2, 2, 2), (64, 64, 128, 256, 512)),
+    "resnet34": ("basic", (3, 4, 6, 3), (64, 64, 128, 256, 512)),
+    "resnet50": ("bottleneck", (3, 4, 6, 3), (64, 256, 512, 1024, 2048)),
+}
+DECODER_CHANNELS = (256, 128, 64, 32, 16)
+RELU = (ACT_LEAKY, 0.0)
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=False):
+        super().__init__()
+        self.conv1 = ConvP(inplanes, planes, 3, stride, 1)
+        self.bn1 = BNP(planes)
+        self.conv2 = ConvP(planes, planes, 3, 1, 1)
+        self.bn2 = BNP(planes)
+        self.downsample = nn.Sequential(ConvP(inplanes, planes, 1, stride, 0), BNP(planes)) if downsample else None
+
+    def fwd(self, P, x):
+        a1, r1 = P.conv_bn_act(self.conv1, self.bn1, x, *RELU)
+        if self.downsample is not None:
+            idt, rd = P.conv_bn_act(self.downsample[0], self.downsample[1], x, ACT_NONE, 0.0)
+        else:
+            idt, rd = x, None
+        out, r2 = P.conv_bn_act(self.conv2, self.bn2, a1, *RELU, residual=idt)
+        return out, (x, a1, idt, r1, r2, rd)
+
+    def bwd(self, P, G, rec, out):
+        x, a1, idt, r1, r2, rd = rec
+        d_out = G.pop(out)
+        dx, dx_acc = G.slot(x)
+        if rd is None:
+            # identity branch: the masked gradient goes straight into dx; conv1's dgrad accumulates on top
+            d_a1 = torch.empty_like(a1)
+            P.conv_bn_act_bwd(r2, d_out, dx=d_a1, dres=dx, dres_acc=dx_acc)
+            P.conv_bn_act_bwd(r1, d_a1, dx=dx, dx_acc=True)
+        else:
+            d_idt = torch.empty_like(idt)
+            d_a1 = torch.empty_like(a1)
+            P.conv_bn_act_bwd(r2, d_out, dx=d_a1, dres=d_idt)
+            P.conv_bn_act_bwd(rd, d_idt, dx=dx, dx_acc=dx_acc)
+            P.conv_bn_act_bwd(r1, d_a1, dx=dx, dx_acc=True)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=False):
+        super().__init__()
+        self.conv1 = ConvP(inplanes, planes, 1, 1, 0)
+        self.bn1 = BNP(planes)
+        self.conv2 = ConvP(planes, planes, 3, stride, 1)
+        self.bn2 = BNP(planes)
+        self.conv3 = ConvP(planes, planes * 4, 1, 1, 0)
+        self.bn3 = BNP(planes * 4)
+        self.downsample = nn.Sequential(ConvP(inplanes, planes * 4, 1, stride, 0), BNP(planes * 4)) if downsample else None
+
+    def fwd(self, P, x):
+        a1, r1 = P.conv_bn_act(self.conv1, self.bn1, x, *RELU)
+        a2, r2 = P.conv_bn_act(self.conv2, self.bn2, a1, *RELU)
+        if self.downsample is not None:
+            idt, rd = P.conv_bn_act(self.downsample[0], self.downsample[1], x, ACT_NONE, 0.0)
+        else:
+            idt, rd = x, None
+        out, r3 = P.conv_bn_act(self.conv3, self.bn3, a2, *RELU, residual=idt)
+        return out, (x, a1, a2, idt, r1, r2, r3, rd)
+
+    def bwd(self, P, G, rec, out):
+        x, a1, a2, idt, r1, r2, r3, rd = rec
+        d_out = G.pop(out)
+        dx, dx_acc = G.slot(x)
+        d_a2 = torch.empty_like(a2)
+        d_a1 = torch.empty_like(a1)
+        if rd is None:
+            P.conv_bn_act_bwd(r3, d_out, dx=d_a2, dres=dx, dres_acc=dx_acc)
+        else:
+            d_idt = torch.empty_like(idt)
+            P.conv_bn_act_bwd(r3, d_out, dx=d_a2, dres=d_idt)
+            P.conv_bn_act_bwd(rd, d_idt, dx=dx, dx_acc=dx_acc)
+        P.conv_bn_act_bwd(r2, d_a2, dx=d_a1)
+        P.conv_bn_act_bwd(r1, d_a1, dx=dx, dx_acc=True)
+
+
+class ResNetEncoder(nn.Module):
+    def __init__(self, name, in_channels=3):
+        super().__init__()
+        kind, layers, chans = ENCODERS[name]
+        block = BasicBlock if kind == "basic" else Bottleneck
+        self.out_channels = (in_channels,) + chans
+        self.conv1 = ConvP(in_channels, 64, 7, 2, 3)
+        self.conv1.needs_dgrad = False            # the image needs no gradient
+        self.bn1 = BNP(64)
+        inpl = 64
+        for li, (planes, nblk, stride) in enumerate(zip((64, 128, 256, 512), layers, (1, 2, 2, 2)), start=1):
+            blocks = []
+            for b in range(nblk):
+                s = stride if b == 0 else 1
+                ds = b == 0 and (s != 1 or inpl != planes * block.expansion)
+                blocks.append(block(inpl, planes, s, ds))
+                inpl = planes * block.expansion
+            setattr(self, f"layer{li}", nn.Sequential(*blocks))
+        for m in self.modules():                  # torchvision ResNet initialisation
+            if isinstance(m, ConvP):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+    def stages(self):
+        return (self.layer1, self.layer2, self.layer3, self.layer4)
+
+
+class DecoderBlock(nn.Module):
+    def __init__(self, in_ch, skip_ch, out_ch):
+        super().__init__()
+        self.in_ch, self.skip_ch, self.out_ch = in_ch, skip_ch, out_ch
+        self.conv1 = nn.Sequential(ConvP(in_ch + skip_ch, out_ch, 3, 1, 1), BNP(out_ch))
+        self.conv2 = nn.Sequential(ConvP(out_ch, out_ch, 3, 1, 1), BNP(out_ch))
+
+    def fwd(self, P, x, skip):
+        cat = K.upsample2x_concat_fwd(x, skip, P.st)
+        a1, r1 = P.conv_bn_act(self.conv1[0], self.conv1[1], cat, *RELU)
+        out, r2 = P.conv_bn_act(self.conv2[0], self.conv2[1], a1, *RELU)
+        return out, (x, skip, cat, a1, r1, r2)
+
+    def bwd(self, P, G, rec, out):
+        x, skip, cat, a1, r1, r2 = rec
+        d_out = G.pop(out)
+        d_a1 = torch.empty_like(a1)
+        P.conv_bn_act_bwd(r2, d_out, dx=d_a1)
+        d_cat = torch.empty_like(cat)
+        P.conv_bn_act_bwd(r1, d_a1, dx=d_cat)
+        dx, dx_acc = G.slot(x)
+        if skip is not None:
+            ds, ds_acc = G.slot(skip)
+        else:
+            ds, ds_acc = None, False
+        K.upsample2x_concat_bwd(d_cat, dx, ds, x.shape[-1], 0 if skip is None else skip.shape[-1], dx_acc, ds_acc, P.st)
+
+
+class UnetDecoder(nn.Module):
+    def __init__(self, encoder_channels, decoder_channels=DECODER_CHANNELS):
+        super().__init__()
+        enc = list(encoder_channels[1:])[::-1]
+        in_ch = [enc[0]] + list(decoder_channels[:-1])
+        skip_ch = enc[1:] + [0]
+        self.blocks = nn.ModuleList(DecoderBlock(i, s, o) for i, s, o in zip(in_ch, skip_ch, decoder_channels))
+        for m in self.modules():                  # smp initialize_decoder
+            if isinstance(m, ConvP):
+                nn.init.kaiming_uniform_(m.weight, mode="fan_in", nonlinearity="relu")
+
+
+class _UnetFunction(torch.autograd.Function):
+    """One autograd node for the whole network: forward = kernel plan, backward = the reverse plan."""
+
+    @staticmethod
+    def forward(ctx, net, x, *params):
+        logits_buf, tape = net._forward_plan(x, True)
+        ctx.net, ctx.tape = net, tape
+        return logits_buf.permute(0, 3, 1, 2)[:, : net.classes]
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        net, tape = ctx.net, ctx.tape
+        if tape is None:
+            raise RuntimeError("Unet: backward needs a training-mode forward with grad enabled")
+        ctx.tape = None
+        grads = net._backward_plan(tape, dlogits)
+        return (None, None) + tuple(grads)
+
+
+class Unet(ArenaModule):
+    """smp.Unet-shaped factory (same keyword arguments as the reference's call sites)."""
+
+    def __init__(self, encoder_name="resnet34", encoder_depth=5, encoder_weights=None, decoder_use_batchnorm=True,
+                 decoder_channels=DECODER_CHANNELS, in_channels=3, classes=1, activation=None, **unused):
+        super().__init__()
+        if encoder_name not in ENCODERS:
+            raise ValueError(f"unsupported encoder {encoder_name!r}; available: {sorted(ENCODERS)}")
+        if encoder_depth != 5 or tuple(decoder_channels) != DECODER_CHANNELS or not decoder_use_batchnorm or activation:
+            raise ValueError("only the reference's configuration is built: depth 5, decoder (256,128,64,32,16), batchnorm, "
+                             "no head activation")
+        self.name = f"u-{encoder_name}"
+        self.classes = classes
+        self.in_channels = in_channels
+        self.encoder = ResNetEncoder(encoder_name, in_channels)
+        self.decoder = UnetDecoder(self.encoder.out_channels, DECODER_CHANNELS)
+        head = ConvP(DECODER_CHANNELS[-1], classes, 3, 1, 1, bias=True)
+        nn.init.xavier_uniform_(head.weight)      # smp initialize_head
+        nn.init.constant_(head.bias, 0)
+        self.segmentation_head = nn.Sequential(head)
+        self.grad_ready_hook = None               # set by ddp.GradAllReducer: called with the lowest finished offset
+        if isinstance(encoder_weights, str) and encoder_weights not in ("imagenet",):
+            self.load_state_dict(torch.load(encoder_weights, map_location="cpu"), strict=False)
+        elif encoder_weights == "imagenet":
+            warnings.warn("encoder_weights='imagenet' needs a download; offline build keeps the seeded random init "
+                          "(pass a state_dict path to load pretrained weights)")
+        self.build_arena()
+
+    # ------------------------------------------------------------------------------------------------ forward
+    def forward(self, x):
+        require_gpu()
+        if x.device.type != "cuda":
+            raise RuntimeError("Unet.forward: input must live on the GPU (no CPU path in this build)")
+        self.ensure_arena()
+        if x.dim() != 4 or x.shape[1] != self.in_channels:
+            raise ValueError(f"expected [N,{self.in_channels},H,W], got {tuple(x.shape)}")
+        if x.shape[2] % 32 or x.shape[3] % 32:
+            raise RuntimeError(f"Wrong input shape height={x.shape[2]}, width={x.shape[3]}. Expected image height and width "
+                               f"divisible by 32.")  # smp's check_input_shape
+        x = x.float()
+        if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self._param_list):
+            return _UnetFunction.apply(self, x, *self._param_list)
+        with torch.no_grad():                     # inference / validation: no tape, no autograd node
+            logits_buf, _ = self._forward_plan(x, False)
+        return logits_buf.permute(0, 3, 1, 2)[:, : self.classes]
+
+    def _forward_plan(self, x, save):
+        P = Plan(self, self.training, save)
+        enc = self.encoder
+        tape = []
+        x4 = K.nchw_to_nhwc(x, ceil4(self.in_channels), P.st)
+        f1, r_stem = P.conv_bn_act(enc.conv1, enc.bn1, x4, *RELU)
+        pooled, pidx = K.maxpool_fwd(f1, P.st)
+        feats = [f1]
+        h = pooled
+        for stage in enc.stages():
+            for blk in stage:
+                h, rec = blk.fwd(P, h)
+                tape.append((blk, rec, h))
+            feats.append(h)
+        skips = feats[:-1][::-1]                  # f4, f3, f2, f1
+        for i, blk in enumerate(self.decoder.blocks):
+            skip = skips[i] if i < len(skips) else None
+            h, rec = blk.fwd(P, h, skip)
+            tape.append((blk, rec, h))
+        head = self.segmentation_head[0]
+        logits, d_head = P.conv(head, h)
+        if self.training:
+            self.tick_batchnorm_counters()
+        if not save:
+            return logits, None
+        return logits, (P, tape, (r_stem, f1, pooled, pidx), (head, d_head, h))
+
+    # ----------------------------------------------------------------------------------------------- backward
+    def _backward_plan(self, tape_all, dlogits):
+        P, tape, (r_stem, f1, pooled, pidx), (head, d_head, h_last) = tape_all
+        P.begin_backward()
+        G = GradSlots()
+        n, _, hh, ww = dlogits.shape
+        cp = head.cout_p
+        # dlogits arrives NCHW-shaped; the CE kernel hands over the padded NHWC buffer as a strided view -- use it as is
+        if (dlogits.dtype == torch.float32 and dlogits.stride(1) == 1 and dlogits.stride(3) == cp
+                and dlogits.stride(2) == cp * ww and dlogits.stride(0) == cp * ww * hh and dlogits.storage_offset() == 0
+                and dlogits.untyped_storage().nbytes() >= 4 * n * hh * ww * cp):
+            dl = dlogits.as_strided((n, hh, ww, cp), (hh * ww * cp, ww * cp, cp, 1), 0)
+        else:
+            dl = torch.zeros((n, hh, ww, cp), device=dlogits.device, dtype=torch.float32)
+            dl.permute(0, 3, 1, 2)[:, : self.classes].copy_(dlogits)
+        dh, _ = G.slot(h_last)
+        P.conv_bwd(head, d_head, h_last, dl, dx=dh, dx_acc=False)
+        hook = self.grad_ready_hook
+        if hook is not None:
+            hook(P, P.offset_of(head))
+        for blk, rec, out in reversed(tape):
+            blk.bwd(P, G, rec, out)
+            if hook is not None:
+                first = next(m for m in blk.modules() if isinstance(m, ConvP))
+                hook(P, P.offset_of(first))
+        # stem: maxpool backward accumulates onto the skip gradient of f1, then BN+ReLU and the 7x7 wgrad
+        d_pooled = G.pop(pooled)
+        d_f1, acc = G.slot(f1)
+        K.maxpool_bwd(d_pooled, pidx, d_f1, acc, P.st)
+        P.conv_bn_act_bwd(r_stem, d_f1, dx=None)
+        if hook is not None:
+            hook(P, 0)
+        return self.grad_views(P.garena)
+
+
+def create_model(encoder_name="resnet50", encoder_weights=None, in_channels=3, classes=23):
+    """The build's model-creation entry point (mirrors reference ``model_creation_suite``, src/test_system.py:87-101)."""
+    return Unet(encoder_name=encoder_name, encoder_weights=encoder_weights, in_channels=in_channels, classes=classes)
