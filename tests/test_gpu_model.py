@@ -46,6 +46,93 @@ def _pair(name, classes=23):
     return ref, net.to("cuda").train()
 
 
+def _f64_twin(ref):
+    import copy
+    r64 = copy.deepcopy(ref).double()
+    return r64
+
+
+def cos(a, b):
+    a, b = a.detach().double().cpu().flatten(), b.detach().double().cpu().flatten()
+    return (a @ b / (a.norm() * b.norm()).clamp_min(1e-300)).item()
+
+
+def _unit_of(name):
+    """Execution-order index of the block a parameter belongs to: stem, encoder blocks, decoder blocks, head."""
+    parts = name.split(".")
+    if parts[0] == "encoder":
+        if parts[1].startswith("layer"):
+            return (1, int(parts[1][5:]), int(parts[2]))
+        return (0, 0, 0)
+    if parts[0] == "decoder":
+        return (2, int(parts[2]), 0)
+    return (3, 0, 0)
+
+
+def _gpu_relu_outputs(net):
+    """(unit, NCHW cpu tensor) of every ReLU output of the last training forward, in execution order."""
+    from uda_aerial_semantic_segmentation_research_amd import unet as U
+    P, tape, (r_stem, f1, pooled, pidx), _ = net._last_tape
+    names = {id(m): n for n, m in net.named_modules()}
+    outs = [((0, 0, 0), f1)]
+    for blk, rec, out in tape:
+        unit = _unit_of(names[id(blk)] + ".x")
+        if isinstance(blk, U.BasicBlock):
+            zs = [rec[1], out]
+        elif isinstance(blk, U.Bottleneck):
+            zs = [rec[1], rec[2], out]
+        else:
+            zs = [rec[3], out]
+        outs += [(unit, z) for z in zs]
+    return [(u, z.detach().cpu().permute(0, 3, 1, 2)) for u, z in outs]
+
+
+def grads_vs_oracle(net, ref32, x, loss_fn, label):
+    """Gradient parity at north_star's 1e-3 (norm-wise per tensor) on EVERY parameter tensor.
+
+    The loss is piecewise smooth: each ReLU mask bit is a kink, and two correct fp32 evaluations that disagree on a
+    single bit in block u differ by 1e-2..1e-1 on every gradient of the blocks <= u (fp32 vs fp64 CPU oracle: 2 of
+    913k bits differ for r18 at 2x64x64 and deep gradients move by up to 0.12; in fp64 alone a 1e-7 input
+    perturbation moves them by 6e-3 -- tools/diag_parity.py).  A bit can only disagree where the
+    pre-activation is ~1e-6 from zero, so the oracle is re-run with every ReLU's mask taken from the HIP path's
+    activations (y = t * mask): its forward is unchanged to rounding, and both paths now differentiate the same linear
+    piece.  Returns the number of bits that disagreed."""
+    import oracle.unet_ref as R
+    gpu = _gpu_relu_outputs(net)
+    masks = [(z > 0).to(torch.float32) for _, z in gpu]
+    natural, forced_in = [], []
+    orig = R._relu
+    state = {k: v.clone() for k, v in ref32.state_dict().items()}
+    it = iter(masks)
+
+    def forced(t):
+        m = next(it)
+        natural.append((t.detach() > 0).to(torch.float32))
+        return t * m
+    R._relu = forced
+    try:
+        ref32.zero_grad()
+        out = ref32(x)
+        loss_fn(out).backward()
+    finally:
+        R._relu = orig
+        ref32.load_state_dict(state)
+    assert len(natural) == len(masks)
+    nflip = int(sum((a != b).sum() for a, b in zip(natural, masks)))
+    for (unit, zg), a in zip(gpu, natural):
+        assert zg.shape == a.shape
+    g32 = dict(ref32.named_parameters())
+    worst = ("", 0.0)
+    for k, p in net.named_parameters():
+        assert p.grad is not None, k
+        e = check(p.grad, g32[k].grad, f"{label} grad {k}")
+        if e > worst[1]:
+            worst = (k, e)
+    print(f"{label}: {nflip} of {sum(m.numel() for m in masks)} ReLU mask bits disagreed; worst gradient rel err "
+          f"{worst[1]:.2e} at {worst[0]}")
+    return nflip
+
+
 @pytest.mark.parametrize("name", ["resnet18", "resnet34", "resnet50"])
 def test_unet_forward_backward_adam_vs_oracle(pkg, name, golden_dir):
     from oracle.adversarial_ref import synthetic_batch
@@ -62,6 +149,7 @@ def test_unet_forward_backward_adam_vs_oracle(pkg, name, golden_dir):
 
     opt = FusedAdam(net.parameters(), lr=1e-4)
     opt.zero_grad()
+    net.debug_keep_tape = True
     logits = net(x.cuda())
     assert logits.shape == (2, 23, 64, 64)
     loss = CrossEntropyLoss()(logits, y.cuda())
@@ -69,15 +157,10 @@ def test_unet_forward_backward_adam_vs_oracle(pkg, name, golden_dir):
     loss.backward()
 
     check(logits, logits_ref, "logits")
-    assert abs(loss.item() - loss_ref.item()) <= RTOL * abs(loss_ref.item())
-    worst = ("", 0.0)
+    assert abs(loss.item() - loss_ref.item()) <= 1e-5 * abs(loss_ref.item())
+    gpu_logits_err = check(logits, logits_ref, "logits")
+    grads_vs_oracle(net, ref, x, lambda o: torch.nn.functional.cross_entropy(o, y), name)
     gref = dict(ref.named_parameters())
-    for k, p in net.named_parameters():
-        assert p.grad is not None, k
-        e = check(p.grad, gref[k].grad, f"grad {k}")
-        if e > worst[1]:
-            worst = (k, e)
-    print(f"{name}: worst grad rel err {worst[1]:.2e} at {worst[0]}")
     # BN running statistics after one training forward
     sd, sdr = net.state_dict(), ref.state_dict()
     for k in sdr:
@@ -93,18 +176,121 @@ def test_unet_forward_backward_adam_vs_oracle(pkg, name, golden_dir):
         got = logits.detach().cpu().contiguous().flatten()[::step][:64].numpy()
         want = g[f"{name}/logits/sample"]
         assert np.abs(got - want).max() <= RTOL * np.abs(logits_ref.detach().numpy()).max()
-    # one optimizer step: fused flat Adam vs torch.optim.Adam.  A weight moves by ~lr whatever its gradient, so
-    # compare the UPDATE, restricted to entries whose gradient is far above rounding noise.
+    # one optimizer step: fused flat Adam vs torch.optim.Adam.  Adam moves every weight by ~lr whatever the size of
+    # its gradient, so compare the UPDATE on entries whose gradient agrees in sign and is far above the noise.
     before = {k: v.detach().clone() for k, v in ref.named_parameters()}
+    gpu_grads = {k: p.grad.detach().cpu().clone() for k, p in net.named_parameters()}
     opt_ref.step()
     opt.step()
     for k, p in net.named_parameters():
-        gr = gref[k].grad
-        big = gr.abs() > 1e-3 * gr.abs().max()
-        upd = (p.detach().cpu() - before[k])[big]
-        upd_ref = (gref[k].detach() - before[k])[big]
-        assert (upd - upd_ref).abs().max() <= 0.02 * 1e-4 + 1e-9, k
+        gr, gg = gref[k].grad, gpu_grads[k]
+        sel = (gr.abs() > 0.05 * gr.abs().max()) & ((gr - gg).abs() <= 1e-3 * gr.abs())
+        if not sel.any():
+            continue
+        upd = (p.detach().cpu() - before[k])[sel]
+        upd_ref = (gref[k].detach() - before[k])[sel]
+        assert (upd - upd_ref).abs().max() <= 0.01 * 1e-4, k
     assert ("flat", 0) in opt.state, "FusedAdam did not take the flat-arena path"
+
+
+def _harness(block):
+    from uda_aerial_semantic_segmentation_research_amd.engine import ArenaModule
+
+    class H(ArenaModule):
+        def __init__(self):
+            super().__init__()
+            self.block = block
+            self.build_arena()
+    return H()
+
+
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def _nchw(t):
+    return t.detach().cpu().permute(0, 3, 1, 2)
+
+
+@pytest.mark.parametrize("kind,cin,planes,stride", [("basic", 64, 64, 1), ("basic", 64, 128, 2), ("bottleneck", 64, 64, 1),
+                                                     ("bottleneck", 256, 128, 2), ("bottleneck", 256, 64, 1)])
+def test_residual_block_plan(pkg, kind, cin, planes, stride):
+    """One residual block, forward + backward plan (identity / downsample wiring, gradient accumulation into an
+    already-populated slot) against torch autograd on the oracle's block with the same weights: 2-3 layers deep, so the
+    plain 1e-3 bar applies with a wide margin."""
+    from oracle import unet_ref as R
+    from uda_aerial_semantic_segmentation_research_amd import unet as U
+    from uda_aerial_semantic_segmentation_research_amd.engine import GradSlots, Plan
+    torch.manual_seed(7)
+    exp = 1 if kind == "basic" else 4
+    need_ds = stride != 1 or cin != planes * exp
+    if kind == "basic":
+        rb = R.BasicBlock(cin, planes, stride, torch.nn.Sequential(torch.nn.Conv2d(cin, planes, 1, stride, bias=False),
+                                                                   torch.nn.BatchNorm2d(planes)) if need_ds else None)
+        mb = U.BasicBlock(cin, planes, stride, need_ds)
+    else:
+        rb = R.Bottleneck(cin, planes, stride, torch.nn.Sequential(torch.nn.Conv2d(cin, planes * 4, 1, stride, bias=False),
+                                                                   torch.nn.BatchNorm2d(planes * 4)) if need_ds else None)
+        mb = U.Bottleneck(cin, planes, stride, need_ds)
+    for m in rb.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            torch.nn.init.uniform_(m.weight, 0.5, 1.5)
+            torch.nn.init.normal_(m.bias, 0, 0.3)
+    rb.train()
+    mb.load_state_dict(rb.state_dict())
+    h = _harness(mb).cuda().train()
+    h.ensure_arena()
+    x = torch.relu(torch.randn(2, cin, 12, 12)).requires_grad_(True)
+    out_ref = rb(x)
+    d_out = torch.randn(out_ref.shape)
+    out_ref.backward(d_out)
+
+    P = Plan(h, True, True)
+    xd = _nhwc(x.detach())
+    out, rec = mb.fwd(P, xd)
+    check(_nchw(out), out_ref, "block out", 1e-4)
+    P.begin_backward()
+    G = GradSlots()
+    G.put(out, _nhwc(d_out))
+    prior = torch.randn(xd.shape, device="cuda")          # an earlier consumer already wrote into dx
+    G.put(xd, prior.clone())
+    mb.bwd(P, G, rec, out)
+    check(_nchw(G.get(xd) - prior), x.grad, "block dx", 1e-3)
+    gr = dict(rb.named_parameters())
+    for (k, p), g in zip(h.named_parameters(), h.grad_views(P.garena)):
+        check(g, gr[k[len("block."):]].grad, f"block grad {k}", 1e-3)
+
+
+@pytest.mark.parametrize("cin,cskip,cout", [(512, 256, 256), (64, 64, 32), (32, 0, 16)])
+def test_decoder_block_plan(pkg, cin, cskip, cout):
+    from oracle import unet_ref as R
+    from uda_aerial_semantic_segmentation_research_amd import unet as U
+    from uda_aerial_semantic_segmentation_research_amd.engine import GradSlots, Plan
+    torch.manual_seed(9)
+    rb = R.DecoderBlockRef(cin, cskip, cout).train()
+    mb = U.DecoderBlock(cin, cskip, cout)
+    mb.load_state_dict(rb.state_dict())
+    h = _harness(mb).cuda().train()
+    h.ensure_arena()
+    x = torch.randn(2, cin, 6, 5).requires_grad_(True)
+    skip = torch.randn(2, cskip, 12, 10).requires_grad_(True) if cskip else None
+    out_ref = rb(x, skip)
+    d_out = torch.randn(out_ref.shape)
+    out_ref.backward(d_out)
+    P = Plan(h, True, True)
+    xd, sd = _nhwc(x.detach()), (_nhwc(skip.detach()) if cskip else None)
+    out, rec = mb.fwd(P, xd, sd)
+    check(_nchw(out), out_ref, "decoder block out", 1e-4)
+    P.begin_backward()
+    G = GradSlots()
+    G.put(out, _nhwc(d_out))
+    mb.bwd(P, G, rec, out)
+    check(_nchw(G.get(xd)), x.grad, "decoder block dx", 1e-3)
+    if cskip:
+        check(_nchw(G.get(sd)), skip.grad, "decoder block dskip", 1e-3)
+    gr = dict(rb.named_parameters())
+    for (k, p), g in zip(h.named_parameters(), h.grad_views(P.garena)):
+        check(g, gr[k[len("block."):]].grad, f"decoder grad {k}", 1e-3)
 
 
 def test_unet_eval_mode_and_state_dict_roundtrip(pkg):
@@ -135,13 +321,11 @@ def test_unet_foreign_gradient_layout(pkg):
     """A gradient that does not come from our CE kernel (plain torch ops on the logits) takes the copy path."""
     from oracle.adversarial_ref import synthetic_batch
     ref, net = _pair("resnet18")
-    x, _, _ = synthetic_batch(1, 32, 32, seed=5)
-    wmap = torch.randn(1, 23, 32, 32)
-    (ref(x) * wmap).sum().backward()
+    x, _, _ = synthetic_batch(2, 64, 64, seed=5)
+    wmap = torch.randn(2, 23, 64, 64)
+    net.debug_keep_tape = True
     (net(x.cuda()) * wmap.cuda()).sum().backward()
-    gref = dict(ref.named_parameters())
-    for k, p in net.named_parameters():
-        check(p.grad, gref[k].grad, f"grad {k}")
+    grads_vs_oracle(net, ref, x, lambda o: (o * wmap).sum(), "foreign-grad")
 
 
 def test_discriminator_vs_reference_vectors(pkg, golden_dir):

@@ -39,43 +39,47 @@ static StreamShape stream_shape(int64_t n4, int c4) {
   return s;
 }
 
-// Fold a per-thread float4 partial over the rows of the block and add it to dst[q*4 .. q*4+3] (f64 atomics).
-// Threads with equal (tid % c4) own the same channels when bs % c4 == 0; otherwise (c4 > bs) each is unique.
-__device__ __forceinline__ void block_fold_add(f32x4 v, double* dst, int c4, int q, float4* red) {
+// Fold a per-thread 4-channel f64 partial over the rows of the block and add it to dst[q*4 .. q*4+3] (f64 atomics).
+// Threads with equal (tid % c4) own the same channels when bs % c4 == 0; otherwise (c4 >= bs) each is unique.
+struct d4 {
+  double v[4];
+};
+__device__ __forceinline__ void block_fold_add(const d4& v, double* dst, int c4, int q, d4* red) {
   const int tid = threadIdx.x, bs = blockDim.x;
   if (c4 >= bs) {
-    atomicAdd(dst + q * 4 + 0, (double)v[0]);
-    atomicAdd(dst + q * 4 + 1, (double)v[1]);
-    atomicAdd(dst + q * 4 + 2, (double)v[2]);
-    atomicAdd(dst + q * 4 + 3, (double)v[3]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) atomicAdd(dst + q * 4 + e, v.v[e]);
     return;
   }
-  red[tid] = make_float4(v[0], v[1], v[2], v[3]);
+  red[tid] = v;
   __syncthreads();
   if (tid < c4) {
-    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    d4 s = {{0, 0, 0, 0}};
     for (int r = tid; r < bs; r += c4) {
-      const float4 t = red[r];
-      s0 += t.x; s1 += t.y; s2 += t.z; s3 += t.w;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s.v[e] += red[r].v[e];
     }
-    atomicAdd(dst + q * 4 + 0, s0);
-    atomicAdd(dst + q * 4 + 1, s1);
-    atomicAdd(dst + q * 4 + 2, s2);
-    atomicAdd(dst + q * 4 + 3, s3);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) atomicAdd(dst + q * 4 + e, s.v[e]);
   }
   __syncthreads();
 }
 
 __global__ void bn_stats_kernel(const f32x4* __restrict__ y, int64_t n4, int c4, double* __restrict__ sums) {
-  __shared__ float4 red[256];
+  // f64 accumulation: E[x^2] - mean^2 then loses nothing to the fp32 partials (the kernel is HBM-bound anyway)
+  __shared__ d4 red[256];
   const int64_t T = (int64_t)gridDim.x * blockDim.x;
   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int q = (int)(g % c4);
-  f32x4 s = {0, 0, 0, 0}, ss = {0, 0, 0, 0};
+  d4 s = {{0, 0, 0, 0}}, ss = {{0, 0, 0, 0}};
   for (int64_t i = g; i < n4; i += T) {
     const f32x4 v = y[i];
-    s += v;
-    ss += v * v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const double d = (double)v[e];
+      s.v[e] += d;
+      ss.v[e] += d * d;
+    }
   }
   block_fold_add(s, sums, c4, q, red);
   block_fold_add(ss, sums + (size_t)c4 * 4, c4, q, red);
@@ -165,7 +169,7 @@ __global__ void bn_bwd_reduce_kernel(const f32x4* __restrict__ dz, const f32x4* 
                                      const f32x4* __restrict__ y, const float* __restrict__ save_mean,
                                      const float* __restrict__ save_rstd, int64_t n4, int c4,
                                      double* __restrict__ bsums, int act, float slope) {
-  __shared__ float4 red[256];
+  __shared__ d4 red[256];
   const int64_t T = (int64_t)gridDim.x * blockDim.x;
   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int q = (int)(g % c4);
@@ -175,7 +179,7 @@ __global__ void bn_bwd_reduce_kernel(const f32x4* __restrict__ dz, const f32x4* 
     mean[e] = save_mean[q * 4 + e];
     rstd[e] = save_rstd[q * 4 + e];
   }
-  f32x4 sg = {0, 0, 0, 0}, sgx = {0, 0, 0, 0};
+  d4 sg = {{0, 0, 0, 0}}, sgx = {{0, 0, 0, 0}};
   for (int64_t i = g; i < n4; i += T) {
     f32x4 gz = dz[i];
     if (act != UDASEG_ACT_NONE) {
@@ -184,8 +188,11 @@ __global__ void bn_bwd_reduce_kernel(const f32x4* __restrict__ dz, const f32x4* 
       for (int e = 0; e < 4; ++e) gz[e] *= act_grad(zz[e], act, slope);
     }
     const f32x4 xh = (y[i] - mean) * rstd;
-    sg += gz;
-    sgx += gz * xh;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      sg.v[e] += (double)gz[e];
+      sgx.v[e] += (double)gz[e] * (double)xh[e];
+    }
   }
   block_fold_add(sg, bsums, c4, q, red);
   block_fold_add(sgx, bsums + (size_t)c4 * 4, c4, q, red);

@@ -43,7 +43,8 @@ class _DiscFunction(torch.autograd.Function):
     def backward(ctx, dp):
         net, tape = ctx.net, ctx.tape
         ctx.tape = None
-        return (None, None) + tuple(net._backward_plan(tape, dp))
+        net._backward_plan(tape, dp)              # delivers .grad itself (arena views)
+        return (None, None) + (None,) * len(net._param_list)
 
 
 class DomainDiscriminator(ArenaModule):
@@ -110,4 +111,4 @@ class DomainDiscriminator(ArenaModule):
             dz = dx
         K.act_bwd(dz, a0, dz, ACT_LEAKY, SLOPE, P.st)    # through conv0's fused LeakyReLU, in place
         P.conv_bwd(conv0, d0, x4, dz, dx=None)
-        return self.grad_views(P.garena)
+        self.deliver_grads(P.garena)

@@ -185,6 +185,29 @@ class ArenaModule(nn.Module):
         """{(id(module), name): (offset, numel, phys_shape)}"""
         return self._idx
 
+    def deliver_grads(self, garena):
+        """Hand a finished gradient arena to the parameters' ``.grad`` (what autograd's AccumulateGrad would do, minus its
+        clone of non-dense views): first backward since zero_grad -> ``.grad`` become views of ``garena``; later ones add
+        onto the arena those views live in with one axpy."""
+        ps = self._param_list
+        if all(p.grad is None for p in ps):
+            for p, g in zip(ps, self.grad_views(garena)):
+                p.grad = g
+            self._grad_arena = garena
+            return
+        ga = getattr(self, "_grad_arena", None)
+        if (ga is not None and ga.numel() == garena.numel() and all(p.grad is not None for p in ps)
+                and ps[0].grad.data_ptr() == ga.data_ptr() + 4 * self._entries[0][1]
+                and ps[-1].grad.data_ptr() == ga.data_ptr() + 4 * self._entries[-1][1]):
+            K.axpy(ga, garena, 1.0)
+            return
+        with torch.no_grad():
+            for p, g in zip(ps, self.grad_views(garena)):
+                if p.grad is None:
+                    p.grad = g.clone()
+                else:
+                    p.grad.add_(g)
+
     def grad_views(self, garena):
         """Logical-shape gradient views (one per parameter, in ``self._param_list`` order) over a grad arena."""
         outs = []

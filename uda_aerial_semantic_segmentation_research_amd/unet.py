@@ -187,8 +187,8 @@ class _UnetFunction(torch.autograd.Function):
         if tape is None:
             raise RuntimeError("Unet: backward needs a training-mode forward with grad enabled")
         ctx.tape = None
-        grads = net._backward_plan(tape, dlogits)
-        return (None, None) + tuple(grads)
+        net._backward_plan(tape, dlogits)         # delivers .grad itself (arena views), see deliver_grads
+        return (None, None) + (None,) * len(net._param_list)
 
 
 class Unet(ArenaModule):
@@ -212,6 +212,8 @@ class Unet(ArenaModule):
         nn.init.constant_(head.bias, 0)
         self.segmentation_head = nn.Sequential(head)
         self.grad_ready_hook = None               # set by ddp.GradAllReducer: called with the lowest finished offset
+        self.debug_keep_tape = False              # tests: keep the last forward's activations in self._last_tape
+        self._last_tape = None
         if isinstance(encoder_weights, str) and encoder_weights not in ("imagenet",):
             self.load_state_dict(torch.load(encoder_weights, map_location="cpu"), strict=False)
         elif encoder_weights == "imagenet":
@@ -262,7 +264,10 @@ class Unet(ArenaModule):
             self.tick_batchnorm_counters()
         if not save:
             return logits, None
-        return logits, (P, tape, (r_stem, f1, pooled, pidx), (head, d_head, h))
+        tape_all = (P, tape, (r_stem, f1, pooled, pidx), (head, d_head, h))
+        if self.debug_keep_tape:
+            self._last_tape = tape_all
+        return logits, tape_all
 
     # ----------------------------------------------------------------------------------------------- backward
     def _backward_plan(self, tape_all, dlogits):
@@ -296,7 +301,7 @@ class Unet(ArenaModule):
         P.conv_bn_act_bwd(r_stem, d_f1, dx=None)
         if hook is not None:
             hook(P, 0)
-        return self.grad_views(P.garena)
+        self.deliver_grads(P.garena)
 
 
 def create_model(encoder_name="resnet50", encoder_weights=None, in_channels=3, classes=23):
