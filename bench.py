@@ -1,0 +1,181 @@
+#!/usr/bin/env python
+"""bench.py -- training images/sec at 512x512 on N MI355X (BASELINE.json metric), one process per GPU.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+           bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): ResNet-18 encoder + Unet decoder, source-only cross entropy, batch 8 x 3 x 512 x 512
+per GPU, fp32, synthetic N(0,1) images / uniform labels, seeded random-init weights.  A "step" is the reference's timed
+region src/models/train.py:340-344: zero_grad -> forward -> CrossEntropy -> backward -> (gradient all-reduce) ->
+Adam step.  Weak scaling: per-GPU batch fixed; `value` = images processed by all ranks / max-over-ranks wall time.
+
+One JSON line on rank 0, with `roofline` (conv implicit-GEMM kernel family, HIP-event timed on the launch stream in a
+separate profiling leg after the timed region) and `cpu_baseline` (the CPU oracle timed on the host cores, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+R18_CONV_GFLOP_PER_IMAGE = 133.30  # fwd + dgrad + wgrad conv FLOPs per source image, r18-Unet @512^2
+
+
+def synthetic(n, h, w, classes, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, 3, h, w, generator=g)
+    g = torch.Generator().manual_seed(seed + 1)
+    y = torch.randint(0, classes, (n, h, w), generator=g, dtype=torch.int64)
+    return x.to(device), y.to(device)
+
+
+def cpu_baseline(encoder, classes, hw, budget_s=25.0):
+    """The CPU oracle (pure-torch restatement of the reference path) on this box's host cores: same step, bounded sample."""
+    from oracle.unet_ref import UnetRef
+    from oracle.adversarial_ref import segmentation_step
+    cores = min(os.cpu_count() or 1, 16)          # the GPU box grants ~16 host cores per GPU
+    torch.set_num_threads(cores)
+    torch.manual_seed(1234)
+    model = UnetRef(encoder, classes=classes).train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    n = 2
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(n, 3, hw, hw, generator=g)
+    y = torch.randint(0, classes, (n, hw, hw), generator=torch.Generator().manual_seed(1), dtype=torch.int64)
+    t0 = time.perf_counter()
+    segmentation_step(model, opt, x, y)            # warm-up (oneDNN primitive creation)
+    warm = time.perf_counter() - t0
+    steps, t0 = 0, time.perf_counter()
+    while steps < 1 or (time.perf_counter() - t0 + warm < budget_s and steps < 8):
+        segmentation_step(model, opt, x, y)
+        steps += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(n * steps / dt, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} steps of batch {n}x3x{hw}x{hw} fp32 after 1 warm-up, torch {torch.__version__} CPU, "
+                      f"oracle/unet_ref.py UnetRef({encoder}) + torch.optim.Adam"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--encoder", default="resnet18")
+    ap.add_argument("--batch", type=int, default=8, help="per-GPU batch")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--classes", type=int, default=23)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from uda_aerial_semantic_segmentation_research_amd import kernels as K
+    from uda_aerial_semantic_segmentation_research_amd.ddp import GradAllReducer, broadcast_parameters
+    from uda_aerial_semantic_segmentation_research_amd.optim import FusedAdam
+    from uda_aerial_semantic_segmentation_research_amd.train import SegmentationTrainer
+    from uda_aerial_semantic_segmentation_research_amd.unet import Unet
+
+    torch.manual_seed(1234)
+    model = Unet(encoder_name=args.encoder, encoder_weights=None, in_channels=3, classes=args.classes)
+    trainer = SegmentationTrainer(model, dev)
+    model.train()
+    model.ensure_arena()
+    if world > 1:
+        broadcast_parameters(model)
+        trainer.grad_reducer = GradAllReducer(model)
+    opt = FusedAdam(model.parameters(), lr=1e-4)
+    x, y = synthetic(args.batch, args.size, args.size, args.classes, seed=100 * rank, device=dev)
+
+    def step():
+        return trainer.train_step(x, y, opt)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    final_loss = float(loss.item())
+
+    roofline = None
+    if not args.no_roofline and rank == 0:
+        # separate leg: HIP events around every conv-kernel launch on the launch stream (C-ABI udaseg_prof_*)
+        K.prof_reset()
+        K.prof_enable(True)
+        psteps = 3
+        for _ in range(psteps):
+            step()
+        torch.cuda.synchronize()
+        K.prof_enable(False)
+        ms0, fl0, n0 = K.prof_read(0)
+        ms1, fl1, n1 = K.prof_read(1)
+        K.prof_reset()
+        achieved = fl0 / (ms0 * 1e-3) / 1e12 if ms0 > 0 else 0.0
+        roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel (fwd + dgrad implicit GEMM, fp32 MFMA)",
+                    "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": n0 // psteps, "avg_launch_ms": round(ms0 / max(n0, 1), 4),
+                    "gflop_per_step": round(fl0 / psteps / 1e9, 1),
+                    "wgrad": {"achieved": round(fl1 / (ms1 * 1e-3) / 1e12, 2) if ms1 > 0 else 0.0,
+                              "launches_per_step": n1 // psteps, "gflop_per_step": round(fl1 / psteps / 1e9, 1),
+                              "ms_per_step": round(ms1 / psteps, 3)},
+                    "igemm_ms_per_step": round(ms0 / psteps, 3)}
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        imgs = args.batch * world * args.steps
+        value = imgs / dt
+        conv_tflops = value * R18_CONV_GFLOP_PER_IMAGE / 1e3 / world if args.encoder == "resnet18" and args.size == 512 else None
+        out = {
+            "metric": "training images/sec at 512x512", "value": round(value, 2), "unit": "images/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
+            "config": {"workload": f"{args.encoder}-Unet source-only CE train step (zero_grad,fwd,CE,bwd,allreduce,Adam), "
+                                   f"batch {args.batch}x3x{args.size}x{args.size} per GPU, {args.classes} classes, random init",
+                       "global_batch": args.batch * world, "image": f"{args.size}x{args.size}", "parallelism": f"dp{world}",
+                       "final_loss": round(final_loss, 5),
+                       "conv_mfma_util_per_gpu": round(conv_tflops / FP32_MFMA_PEAK_TFLOPS, 4) if conv_tflops else None},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.encoder, args.classes, args.size)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
