@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--classes", type=int, default=23)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--layer-table", action="store_true", help="print TFLOP/s per conv shape (stderr)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -141,6 +142,18 @@ def main():
         K.prof_enable(False)
         ms0, fl0, n0 = K.prof_read(0)
         ms1, fl1, n1 = K.prof_read(1)
+        if args.layer_table:
+            agg = {}
+            for fam in (0, 1):
+                for ms, fl, kind, d in K.prof_records(fam):
+                    a = agg.setdefault((kind, d), [0.0, 0.0, 0])
+                    a[0] += ms
+                    a[1] += fl
+                    a[2] += 1
+            print("kind  n  hi  wi   ci   co k s |  calls/step  ms/call   GFLOP   TFLOP/s", file=sys.stderr)
+            for (kind, d), (ms, fl, cnt) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+                print(f"{('fwd', 'dgrad', 'wgrad')[kind]:5s} {d[0]:2d} {d[1]:3d} {d[2]:3d} {d[3]:4d} {d[6]:4d} {d[7]} {d[9]} | "
+                      f"{cnt / psteps:5.1f} {ms / cnt:9.4f} {fl / cnt / 1e9:8.2f} {fl / ms / 1e9:8.1f}", file=sys.stderr)
         K.prof_reset()
         achieved = fl0 / (ms0 * 1e-3) / 1e12 if ms0 > 0 else 0.0
         roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel (fwd + dgrad implicit GEMM, fp32 MFMA)",

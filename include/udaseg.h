@@ -72,7 +72,9 @@ double udaseg_conv_flops(const udaseg_conv_desc* d);
 int udaseg_nchw_to_nhwc(const float* x, float* y, int n, int c, int h, int w, int cpad, void* stream);
 
 /* ---- batch norm (training mode) + activation: torch.nn.BatchNorm2d/ReLU/LeakyReLU inside smp.Unet and
- *      discriminator.py:21-33.  sums = [2][c] doubles (sum, sum of squares), zeroed by the caller. ---- */
+ *      discriminator.py:21-33.  sums / bsums = [R][2][c] doubles (R = udaseg_bn_replicas() replicated accumulators of
+ *      sum and sum of squares, spread to avoid same-address atomic serialisation), zeroed by the caller. ---- */
+int udaseg_bn_replicas(void);
 int udaseg_bn_stats(const float* y, int64_t pixels, int c, double* sums, void* stream);
 /* z = act(gamma*(y-mean)*rstd + beta (+ residual)); writes save_mean/save_rstd [c]; updates running stats
  * (momentum, unbiased variance) when running_mean != NULL.  residual may be NULL. */
@@ -150,6 +152,8 @@ int udaseg_prof_enable(int on);
 int udaseg_prof_reset(void);
 /* family: 0 = igemm fwd/dgrad, 1 = wgrad.  Synchronises the recorded events (call outside timed regions). */
 int udaseg_prof_read(int family, double* total_ms, double* total_flops, int64_t* launches);
+/* Per-launch records: ms, flops, kind (0 fwd, 1 dgrad, 2 wgrad) and the 11 ints of the conv desc. Returns the count. */
+int udaseg_prof_records(int family, int max_records, double* ms, double* flops, int* kind, int* desc11);
 
 #ifdef __cplusplus
 }

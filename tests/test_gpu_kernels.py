@@ -157,7 +157,7 @@ def test_conv_large_tiles(K):
 @pytest.mark.parametrize("c", [16, 64, 24, 512, 2048])
 @pytest.mark.parametrize("act,slope,with_res", [(0, 0.0, False), (1, 0.0, True), (1, 0.2, False)])
 def test_bn_train_fwd_bwd(K, c, act, slope, with_res):
-    n, h, w = 2, 6, 10
+    n, h, w = (2, 6, 10) if c > 64 else (4, 40, 52)       # the wide case spans many blocks -> all replicas in use
     g = torch.Generator().manual_seed(c + act)
     x = (torch.randn(n, c, h, w, generator=g) * 2 + 0.5).requires_grad_(True)
     res = torch.randn(n, c, h, w, generator=g).requires_grad_(True) if with_res else None
@@ -177,7 +177,7 @@ def test_bn_train_fwd_bwd(K, c, act, slope, with_res):
     z_ref.backward(dz)
 
     yd = nhwc(x.detach())
-    sums = torch.zeros(2 * c, dtype=torch.float64, device="cuda")
+    sums = torch.zeros(2 * c * K.bn_replicas(), dtype=torch.float64, device="cuda")
     K.bn_stats(yd, sums)
     z = torch.empty_like(yd)
     rm, rv = dev(rm0), dev(rv0)
@@ -189,7 +189,7 @@ def test_bn_train_fwd_bwd(K, c, act, slope, with_res):
     assert_close(rm.cpu(), bn.running_mean, "running_mean", 1e-5)
     assert_close(rv.cpu(), bn.running_var, "running_var", 1e-5)
 
-    bs = torch.zeros(2 * c, dtype=torch.float64, device="cuda")
+    bs = torch.zeros(2 * c * K.bn_replicas(), dtype=torch.float64, device="cuda")
     dzd = nhwc(dz)
     K.bn_bwd_reduce(dzd, z, yd, sm, sr, bs, act, slope)
     dy = torch.empty_like(yd)

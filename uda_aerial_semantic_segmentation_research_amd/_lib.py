@@ -35,6 +35,7 @@ SIGNATURES = {
     "udaseg_pack_dgrad_weights": (_I, [_D, _P, _P, _P]),
     "udaseg_conv_flops": (C.c_double, [_D]),
     "udaseg_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "udaseg_bn_replicas": (_I, []),
     "udaseg_bn_stats": (_I, [_P, _L, _I, _P, _P]),
     "udaseg_bn_apply": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _F, _F, _P, _P, _P, _P, _I, _F, _P]),
     "udaseg_bn_apply_eval": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _F, _P]),
@@ -60,6 +61,7 @@ SIGNATURES = {
     "udaseg_prof_enable": (_I, [_I]),
     "udaseg_prof_reset": (_I, []),
     "udaseg_prof_read": (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "udaseg_prof_records": (_I, [_I, _I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
 }
 
 _lib = None

@@ -24,6 +24,8 @@ int hip_fail(hipError_t e, const char* what) {
 struct ProfRec {
   hipEvent_t a, b;
   double flops;
+  int kind;  // 0 fwd, 1 dgrad, 2 wgrad
+  udaseg_conv_desc d;
 };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_recs[2];
@@ -44,15 +46,17 @@ static hipEvent_t get_event() {
 void prof_begin(int family, hipStream_t s) {
   if (!g_prof_on) return;
   g_open[family] = get_event();
-  if (g_open[family]) hipEventRecord(g_open[family], s);
+  if (g_open[family]) (void)hipEventRecord(g_open[family], s);
 }
 
-void prof_end(int family, hipStream_t s, double flops) {
+void prof_end(int family, hipStream_t s, double flops, int kind, const udaseg_conv_desc* d) {
   if (!g_prof_on || !g_open[family]) return;
   hipEvent_t b = get_event();
   if (!b) return;
-  hipEventRecord(b, s);
-  g_recs[family].push_back({g_open[family], b, flops});
+  (void)hipEventRecord(b, s);
+  ProfRec r = {g_open[family], b, flops, kind, {}};
+  if (d) r.d = *d;
+  g_recs[family].push_back(r);
   g_open[family] = nullptr;
 }
 
@@ -101,4 +105,24 @@ extern "C" int udaseg_prof_read(int family, double* total_ms, double* total_flop
   *total_flops = fl;
   *launches = (int64_t)g_recs[family].size();
   return UDASEG_OK;
+}
+
+extern "C" int udaseg_prof_records(int family, int max_records, double* ms, double* flops, int* kind, int* desc11) {
+  UDASEG_CHECK_ARG(family >= 0 && family < 2 && ms && flops && kind && desc11 && max_records >= 0, "prof_records: bad arguments");
+  int n = 0;
+  for (auto& r : g_recs[family]) {
+    if (n >= max_records) break;
+    hipError_t e = hipEventSynchronize(r.b);
+    if (e != hipSuccess) return hip_fail(e, "hipEventSynchronize(prof)");
+    float t = 0.f;
+    e = hipEventElapsedTime(&t, r.a, r.b);
+    if (e != hipSuccess) return hip_fail(e, "hipEventElapsedTime(prof)");
+    ms[n] = t;
+    flops[n] = r.flops;
+    kind[n] = r.kind;
+    const int v[11] = {r.d.n, r.d.hi, r.d.wi, r.d.ci, r.d.ho, r.d.wo, r.d.co, r.d.kh, r.d.kw, r.d.stride, r.d.pad};
+    for (int i = 0; i < 11; ++i) desc11[n * 11 + i] = v[i];
+    ++n;
+  }
+  return n;
 }

@@ -64,6 +64,6 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 
 // live launch timing (bench.py roofline leg)
 void prof_begin(int family, hipStream_t s);
-void prof_end(int family, hipStream_t s, double flops);
+void prof_end(int family, hipStream_t s, double flops, int kind, const udaseg_conv_desc* d);
 
 }  // namespace udaseg

@@ -313,7 +313,7 @@ extern "C" int udaseg_conv2d_fwd(const udaseg_conv_desc* d, const float* x, cons
   hipStream_t st = as_stream(stream);
   prof_begin(0, st);
   rc = launch_igemm(a, st);
-  prof_end(0, st, udaseg_conv_flops(d));
+  prof_end(0, st, udaseg_conv_flops(d), 0, d);
   return rc;
 }
 
@@ -356,6 +356,6 @@ extern "C" int udaseg_conv2d_dgrad(const udaseg_conv_desc* d, const float* dy, c
       if (rc) return rc;
     }
   // dgrad FLOPs equal the forward's (every (pixel, tap, ci, co) product appears once)
-  prof_end(0, st, udaseg_conv_flops(d));
+  prof_end(0, st, udaseg_conv_flops(d), 1, d);
   return UDASEG_OK;
 }

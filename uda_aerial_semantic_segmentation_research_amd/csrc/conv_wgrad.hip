@@ -202,7 +202,7 @@ extern "C" int udaseg_conv2d_wgrad(const udaseg_conv_desc* d, const float* x, co
   int rc;
   if (d->co > 32) rc = launch_wgrad<64, 64, 2, 2>(a, accumulate, st);
   else rc = launch_wgrad<32, 128, 1, 4>(a, accumulate, st);
-  prof_end(1, st, udaseg_conv_flops(d));
+  prof_end(1, st, udaseg_conv_flops(d), 2, d);
   return rc;
 }
 

@@ -11,6 +11,12 @@
 
 namespace udaseg {
 
+// Per-channel f64 accumulators are replicated BN_REPLICAS times ([R][2][C]); block b adds into replica b % R and the
+// consumer sums the replicas.  Same-address memory-side atomics serialise (~100 ns each): 2048 blocks on one address
+// cost ~130 us per launch (measured, profiles/r01_kernel_stats_first.csv); 512 blocks over 16 replicas = 32 per address.
+constexpr int BN_REPLICAS = 16;
+constexpr int REDUCE_MAX_BLOCKS = 512;
+
 struct StreamShape {
   int bs;      // threads per block (multiple of 64... or of C4 when C4 is not a power of two)
   int grid;
@@ -18,7 +24,7 @@ struct StreamShape {
 };
 
 // Choose block/grid so grid*bs is a multiple of c4 (see header comment).
-static StreamShape stream_shape(int64_t n4, int c4) {
+static StreamShape stream_shape(int64_t n4, int c4, int max_blocks = 2048) {
   StreamShape s;
   s.c4 = c4;
   int unit;  // grid must be a multiple of `unit`
@@ -31,7 +37,7 @@ static StreamShape stream_shape(int64_t n4, int c4) {
     while ((unit * 256) % c4 != 0) ++unit;  // c4 = 512 -> 2
   }
   int64_t want = (n4 + (int64_t)s.bs * 4 - 1) / ((int64_t)s.bs * 4);  // ~4 float4 per thread
-  if (want > 2048) want = 2048;
+  if (want > max_blocks) want = max_blocks;
   if (want < 1) want = 1;
   s.grid = (int)(((want + unit - 1) / unit) * unit);
   // every channel quad needs an owning thread among the first c4 global threads
@@ -81,8 +87,9 @@ __global__ void bn_stats_kernel(const f32x4* __restrict__ y, int64_t n4, int c4,
       ss.v[e] += d * d;
     }
   }
-  block_fold_add(s, sums, c4, q, red);
-  block_fold_add(ss, sums + (size_t)c4 * 4, c4, q, red);
+  double* rep = sums + (size_t)(blockIdx.x % BN_REPLICAS) * 2 * c4 * 4;
+  block_fold_add(s, rep, c4, q, red);
+  block_fold_add(ss, rep + (size_t)c4 * 4, c4, q, red);
 }
 
 struct BnCoef {
@@ -96,8 +103,14 @@ __device__ __forceinline__ BnCoef bn_coef_from_sums(const double* sums, const fl
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int c = q * 4 + e;
-    const double m = sums[c] * inv;
-    double var = sums[(size_t)c4 * 4 + c] * inv - m * m;
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int r = 0; r < BN_REPLICAS; ++r) {
+      s1 += sums[(size_t)r * 2 * c4 * 4 + c];
+      s2 += sums[(size_t)r * 2 * c4 * 4 + (size_t)c4 * 4 + c];
+    }
+    const double m = s1 * inv;
+    double var = s2 * inv - m * m;
     var = var > 0.0 ? var : 0.0;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     k.mean[e] = (float)m;
@@ -194,8 +207,9 @@ __global__ void bn_bwd_reduce_kernel(const f32x4* __restrict__ dz, const f32x4* 
       sgx.v[e] += (double)gz[e] * (double)xh[e];
     }
   }
-  block_fold_add(sg, bsums, c4, q, red);
-  block_fold_add(sgx, bsums + (size_t)c4 * 4, c4, q, red);
+  double* rep = bsums + (size_t)(blockIdx.x % BN_REPLICAS) * 2 * c4 * 4;
+  block_fold_add(sg, rep, c4, q, red);
+  block_fold_add(sgx, rep + (size_t)c4 * 4, c4, q, red);
 }
 
 __global__ void bn_bwd_apply_kernel(const f32x4* __restrict__ dz, const f32x4* __restrict__ z,
@@ -215,10 +229,16 @@ __global__ void bn_bwd_apply_kernel(const f32x4* __restrict__ dz, const f32x4* _
     mean[e] = save_mean[c];
     rstd[e] = save_rstd[c];
     scale[e] = gamma[c] * rstd[e];
-    mg[e] = (float)(bsums[c] * inv);
-    mgx[e] = (float)(bsums[(size_t)c4 * 4 + c] * inv);
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int r = 0; r < BN_REPLICAS; ++r) {
+      s1 += bsums[(size_t)r * 2 * c4 * 4 + c];
+      s2 += bsums[(size_t)r * 2 * c4 * 4 + (size_t)c4 * 4 + c];
+    }
+    mg[e] = (float)(s1 * inv);
+    mgx[e] = (float)(s2 * inv);
     if (g < c4) {
-      const float db = (float)bsums[c], dg = (float)bsums[(size_t)c4 * 4 + c];
+      const float db = (float)s1, dg = (float)s2;
       if (dbeta) dbeta[c] = acc_param ? dbeta[c] + db : db;
       if (dgamma) dgamma[c] = acc_param ? dgamma[c] + dg : dg;
     }
@@ -293,12 +313,14 @@ static int check_pc(int64_t pixels, int c, const char* who) {
 
 using namespace udaseg;
 
+extern "C" int udaseg_bn_replicas(void) { return BN_REPLICAS; }
+
 extern "C" int udaseg_bn_stats(const float* y, int64_t pixels, int c, double* sums, void* stream) {
   int rc = check_pc(pixels, c, "bn_stats");
   if (rc) return rc;
   UDASEG_CHECK_ARG(y && sums, "bn_stats: NULL pointer");
   const int64_t n4 = pixels * (c / 4);
-  const StreamShape s = stream_shape(n4, c / 4);
+  const StreamShape s = stream_shape(n4, c / 4, REDUCE_MAX_BLOCKS);
   hipLaunchKernelGGL(bn_stats_kernel, dim3(s.grid), dim3(s.bs), 0, as_stream(stream), (const f32x4*)y, n4, s.c4, sums);
   UDASEG_LAUNCH_CHECK("bn_stats launch");
   return UDASEG_OK;
@@ -343,7 +365,7 @@ extern "C" int udaseg_bn_bwd_reduce(const float* dz, const float* z, const float
   UDASEG_CHECK_ARG(dz && y && save_mean && save_rstd && bsums, "bn_bwd_reduce: NULL pointer");
   UDASEG_CHECK_ARG(act == UDASEG_ACT_NONE || z, "bn_bwd_reduce: z required when an activation follows the norm");
   const int64_t n4 = pixels * (c / 4);
-  const StreamShape s = stream_shape(n4, c / 4);
+  const StreamShape s = stream_shape(n4, c / 4, REDUCE_MAX_BLOCKS);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(s.grid), dim3(s.bs), 0, as_stream(stream), (const f32x4*)dz, (const f32x4*)z,
                      (const f32x4*)y, save_mean, save_rstd, n4, s.c4, bsums, act, slope);
   UDASEG_LAUNCH_CHECK("bn_bwd_reduce launch");

@@ -226,10 +226,11 @@ class Plan:
         self.st = K.stream()
         self.idx = net.entry_index()
         dev = net._arena.device
+        self.R = K.bn_replicas()
         nbn = net._nbn
         self.dev = dev
         if training:
-            self.stats = torch.zeros(max(nbn, 2), dtype=torch.float64, device=dev)      # [sum | sumsq] per BN
+            self.stats = torch.zeros(max(nbn, 2) * self.R, dtype=torch.float64, device=dev)  # [R][sum | sumsq] per BN
             self.saved_stats = torch.empty(max(nbn, 2), dtype=torch.float32, device=dev)  # [mean | rstd] per BN
         self._stat_off = 0
         self.garena = None
@@ -277,7 +278,7 @@ class Plan:
         if self.training:
             o = self._stat_off
             self._stat_off += 2 * c
-            sums = self.stats[o:o + 2 * c]
+            sums = self.stats[o * self.R:(o + 2 * c) * self.R]
             mean, rstd = self.saved_stats[o:o + c], self.saved_stats[o + c:o + 2 * c]
             K.bn_stats(y, sums, self.st)
             K.bn_apply(y, sums, gamma, beta, residual, z, bn.eps, bn.momentum, bn.running_mean, bn.running_var, mean, rstd,
@@ -299,7 +300,7 @@ class Plan:
         self.st = K.stream()
         self.garena = torch.zeros_like(net._arena)
         nbn = net._nbn
-        self.bstats = torch.zeros(max(nbn, 2), dtype=torch.float64, device=self.dev)
+        self.bstats = torch.zeros(max(nbn, 2) * self.R, dtype=torch.float64, device=self.dev)
         self._bstat_off = 0
 
     def packed_wt(self, conv):
@@ -322,7 +323,7 @@ class Plan:
         c = ceil4(bn.c)
         o = self._bstat_off
         self._bstat_off += 2 * c
-        bs = self.bstats[o:o + 2 * c]
+        bs = self.bstats[o * self.R:(o + 2 * c) * self.R]
         mean, rstd = ms
         gamma = self.pvec(bn, "weight")
         K.bn_bwd_reduce(dz, z, y, mean, rstd, bs, act, slope, self.st)

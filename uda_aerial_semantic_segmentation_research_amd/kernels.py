@@ -62,6 +62,16 @@ def nchw_to_nhwc(x, cpad=None, st=None):
     return y
 
 
+_BN_R = None
+
+
+def bn_replicas():
+    global _BN_R
+    if _BN_R is None:
+        _BN_R = _lib.load().udaseg_bn_replicas()
+    return _BN_R
+
+
 def bn_stats(y, sums, st=None):
     c = y.shape[-1]
     check(_lib.load().udaseg_bn_stats(y.data_ptr(), y.numel() // c, c, sums.data_ptr(),
@@ -210,3 +220,14 @@ def prof_read(family):
     ms, fl, n = _lib.C.c_double(), _lib.C.c_double(), _lib.C.c_int64()
     check(_lib.load().udaseg_prof_read(family, _byref(ms), _byref(fl), _byref(n)), "prof_read")
     return ms.value, fl.value, n.value
+
+
+def prof_records(family, max_records=4096):
+    """[(ms, flops, kind, (n,hi,wi,ci,ho,wo,co,kh,kw,stride,pad))] of the recorded launches of one kernel family."""
+    C = _lib.C
+    ms, fl = (C.c_double * max_records)(), (C.c_double * max_records)()
+    kind, desc = (C.c_int * max_records)(), (C.c_int * (11 * max_records))()
+    n = _lib.load().udaseg_prof_records(family, max_records, ms, fl, kind, desc)
+    if n < 0:
+        check(n, "prof_records")
+    return [(ms[i], fl[i], kind[i], tuple(desc[11 * i:11 * i + 11])) for i in range(n)]
