@@ -19,6 +19,7 @@
 #ifndef UDASEG_H
 #define UDASEG_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -141,6 +142,10 @@ int udaseg_bce_logits_bwd(const float* x, int n, float label, float weight, cons
  * flat fp32 arrays; bc1 = 1-beta1^t, bc2 = 1-beta2^t computed by the caller. */
 int udaseg_adam_flat(float* p, const float* g, float* m, float* v, int64_t count, float lr, float beta1, float beta2,
                      float eps, float bc1, float bc2, void* stream);
+
+/* ---- scratch: one caller-owned device buffer the library may use for split partial results (currently the
+ *      small-channel weight gradient, <= 10 MiB).  Without it those calls take the generic atomics path. ---- */
+int udaseg_set_workspace(void* ptr, size_t bytes);
 
 /* ---- small utilities ---- */
 int udaseg_fill_f32(float* p, int64_t count, float value, void* stream);

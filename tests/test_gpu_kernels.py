@@ -18,6 +18,7 @@ RTOL = 1e-3
 def K():
     from uda_aerial_semantic_segmentation_research_amd import _lib, kernels
     _lib.require_gpu()
+    kernels.ensure_workspace(torch.device("cuda", 0))
     return kernels
 
 
@@ -70,6 +71,10 @@ CONV_CASES = [
     (1, 5, 5, 8, 8, 3, 2, 1),         # odd extent with stride 2
     (2, 16, 16, 64, 256, 1, 1, 0),    # bottleneck 1x1
     (1, 64, 64, 64, 64, 3, 1, 1),     # 128x64 tile path? (M = 4096 -> small) keep for coverage
+    (2, 40, 20, 16, 16, 3, 1, 1),     # small-channel direct kernel, ragged 16x16 tiles
+    (1, 33, 47, 32, 16, 3, 1, 1),     # direct kernel, two K groups, odd extents
+    (2, 16, 16, 8, 32, 3, 1, 1),      # direct kernel, partial K group (ci = 8), two output tiles
+    (1, 64, 64, 16, 24, 3, 1, 1),     # head shape through the direct kernel
 ]
 
 

@@ -56,6 +56,7 @@ SIGNATURES = {
     "udaseg_bce_logits_fwd": (_I, [_P, _I, _F, _F, _P, _I, _P]),
     "udaseg_bce_logits_bwd": (_I, [_P, _I, _F, _F, _P, _P, _I, _P]),
     "udaseg_adam_flat": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _P]),
+    "udaseg_set_workspace": (_I, [_P, C.c_size_t]),
     "udaseg_fill_f32": (_I, [_P, _L, _F, _P]),
     "udaseg_axpy_f32": (_I, [_P, _P, _L, _F, _P]),
     "udaseg_prof_enable": (_I, [_I]),

@@ -294,6 +294,13 @@ extern "C" int udaseg_conv2d_fwd(const udaseg_conv_desc* d, const float* x, cons
   int rc = check_desc(d);
   if (rc) return rc;
   UDASEG_CHECK_ARG(x && w && y, "conv2d_fwd: NULL pointer");
+  if (d->kh == d->kw && small_conv_applicable(d->kh, d->stride, d->pad, d->ci, d->co)) {
+    hipStream_t st = as_stream(stream);
+    prof_begin(0, st);
+    rc = launch_small_conv(x, w, bias, y, d->n, d->hi, d->wi, d->ci, d->co, 0, accumulate, act, slope, st);
+    prof_end(0, st, udaseg_conv_flops(d), 0, d);
+    return rc;
+  }
   IgemmArgs a = {};
   a.x = x; a.w = w; a.bias = bias; a.y = y;
   a.hi = d->hi; a.wi = d->wi; a.ci = d->ci;
@@ -325,6 +332,12 @@ extern "C" int udaseg_conv2d_dgrad(const udaseg_conv_desc* d, const float* dy, c
   hipStream_t st = as_stream(stream);
   const int s = d->stride;
   prof_begin(0, st);
+  if (d->kh == d->kw && small_conv_applicable(d->kh, d->stride, d->pad, d->co, d->ci)) {
+    // dx = correlation of dy with the flipped taps; w_t is already [ci][9][co]
+    rc = launch_small_conv(dy, w_t, nullptr, dx, d->n, d->hi, d->wi, d->co, d->ci, 1, accumulate, UDASEG_ACT_NONE, 0.f, st);
+    prof_end(0, st, udaseg_conv_flops(d), 1, d);
+    return rc;
+  }
   for (int ph = 0; ph < s; ++ph)
     for (int pw = 0; pw < s; ++pw) {
       IgemmArgs a = {};

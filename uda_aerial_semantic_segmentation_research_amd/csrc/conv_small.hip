@@ -1,0 +1,391 @@
+// Direct 3x3 / stride 1 / pad 1 convolution for SMALL channel counts (<= 32), NHWC fp32, on v_mfma_f32_16x16x4_f32.
+//
+// Serves the decoder tail and segmentation head of smp.Unet (reference src/models/train.py:341,343): dec.4.conv1
+// 32->16, dec.4.conv2 16->16, head 16->23(+1) at full image resolution, their data gradients and weight gradients.
+// These 9 launches are 12 % of the step's conv FLOPs; through the generic implicit-GEMM kernel they ran at 23-45
+// TFLOP/s (half of every 32-wide MFMA tile was padding at 16 output channels, and a K of 144-288 is 5-9 short K-tiles
+// of latency per block).  Here:
+//   * one block = one 16x16 pixel tile; its 18x18 input halo is staged ONCE in LDS (no 9x im2col re-gather);
+//   * the 16-wide MFMA (16 pixels x 16 channels x 4) has no padding waste at 16 channels;
+//   * forward/dgrad keep the whole weight tensor in registers (36-72 VGPRs) -- LDS traffic is A fragments only;
+//   * each lane's 16-byte LDS read feeds 4 MFMAs (K order permuted identically for A and B);
+//   * blocks are persistent over tiles; wgrad accumulates in registers across all its tiles and writes ONE partial
+//     per block (no atomics on the 2-5 K hot addresses), a second tiny kernel folds the partials.
+#include "common.h"
+
+namespace udaseg {
+
+constexpr int ST = 16;            // tile edge (pixels)
+constexpr int SH = ST + 2;        // halo edge
+
+static void* g_workspace = nullptr;
+static size_t g_workspace_bytes = 0;
+
+struct SmallArgs {
+  const float* x;     // gathered operand [n][h][w][ci]
+  const float* w;     // [co][9][ci]
+  const float* bias;  // [co] or null
+  float* y;           // [n][h][w][co]
+  int n, h, wd, ci, co;
+  int flip;           // 0: tap (r,s) reads (y+r-1, x+s-1) (forward); 1: (y+1-r, x+1-s) (data gradient)
+  int accumulate, act;
+  float slope;
+  int tiles_x, tiles_y, ntiles;
+};
+
+// Halo staging in two halves so the global loads of ALL of a thread's pieces are in flight together (a load->write
+// loop with a dynamic trip count serialises one global-load latency per iteration) and so the next tile's loads can
+// fly during the current tile's MFMA phase.
+template <int CIP>
+struct HaloRegs {
+  static constexpr int Q = CIP / 4;                        // float4 per pixel
+  static constexpr int TOTAL = SH * SH * Q;
+  static constexpr int ITER = (TOTAL + 255) / 256;
+  f32x4 v[ITER];
+
+  __device__ __forceinline__ void issue(const float* __restrict__ x, int ni, int ty0, int tx0, int h, int w, int ci) {
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int idx = threadIdx.x + 256 * it;
+      const int pos = idx / Q, cq = idx - pos * Q;
+      const int hy = pos / SH, hx = pos - hy * SH;
+      const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
+      f32x4 t = {0.f, 0.f, 0.f, 0.f};
+      if (idx < TOTAL && (unsigned)gy < (unsigned)h && (unsigned)gx < (unsigned)w && cq * 4 < ci)
+        t = *reinterpret_cast<const f32x4*>(x + ((size_t)(ni * h + gy) * w + gx) * (size_t)ci + cq * 4);
+      v[it] = t;
+    }
+  }
+  __device__ __forceinline__ void commit(float* __restrict__ halo) const {
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int idx = threadIdx.x + 256 * it;
+      if (idx < TOTAL) *reinterpret_cast<f32x4*>(halo + idx * 4) = v[it];   // pos*CIP + cq*4 == idx*4
+    }
+  }
+};
+
+// 16x16 tile of dy (no halo)
+template <int COP>
+struct TileRegs {
+  static constexpr int Q = COP / 4;
+  static constexpr int TOTAL = ST * ST * Q;
+  static constexpr int ITER = (TOTAL + 255) / 256;
+  f32x4 v[ITER];
+
+  __device__ __forceinline__ void issue(const float* __restrict__ dy, int ni, int ty0, int tx0, int h, int w, int co) {
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int idx = threadIdx.x + 256 * it;
+      const int pos = idx / Q, cq = idx - pos * Q;
+      const int py = pos / ST, px = pos - py * ST;
+      const int gy = ty0 + py, gx = tx0 + px;
+      f32x4 t = {0.f, 0.f, 0.f, 0.f};
+      if (idx < TOTAL && gy < h && gx < w && cq * 4 < co)
+        t = *reinterpret_cast<const f32x4*>(dy + ((size_t)(ni * h + gy) * w + gx) * (size_t)co + cq * 4);
+      v[it] = t;
+    }
+  }
+  __device__ __forceinline__ void commit(float* __restrict__ tile) const {
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int idx = threadIdx.x + 256 * it;
+      if (idx < TOTAL) *reinterpret_cast<f32x4*>(tile + idx * 4) = v[it];
+    }
+  }
+};
+
+struct TileCoord {
+  int ni, ty0, tx0;
+};
+__device__ __forceinline__ TileCoord tile_coord(int tile, int tiles_x, int tiles_y) {
+  const int tx = tile % tiles_x, r1 = tile / tiles_x;
+  return TileCoord{r1 / tiles_y, (r1 % tiles_y) * ST, tx * ST};
+}
+
+// G = 16-channel K groups of the gathered operand, CO_T = 16-wide output-channel tiles.
+template <int G, int CO_T>
+__global__ __launch_bounds__(256) void conv3x3_small_kernel(const SmallArgs a) {
+  constexpr int CIP = 16 * G;
+  __shared__ __attribute__((aligned(16))) float halo[SH * SH * CIP];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+
+  // whole weight tensor in registers: B[k = 16g + 4kq + e][j = co] for tap t
+  f32x4 wreg[9][G][CO_T];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int ct = 0; ct < CO_T; ++ct) {
+        const int co = 16 * ct + li, c0 = 16 * g + 4 * kq;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (co < a.co && c0 < a.ci) v = *reinterpret_cast<const f32x4*>(a.w + ((size_t)co * 9 + t) * a.ci + c0);
+        wreg[t][g][ct] = v;
+      }
+  float bias[CO_T];
+#pragma unroll
+  for (int ct = 0; ct < CO_T; ++ct) bias[ct] = (a.bias && 16 * ct + li < a.co) ? a.bias[16 * ct + li] : 0.f;
+
+  HaloRegs<CIP> stage;
+  int tile = blockIdx.x;
+  if (tile < a.ntiles) {
+    const TileCoord c = tile_coord(tile, a.tiles_x, a.tiles_y);
+    stage.issue(a.x, c.ni, c.ty0, c.tx0, a.h, a.wd, a.ci);
+  }
+  for (; tile < a.ntiles; tile += gridDim.x) {
+    const TileCoord tc = tile_coord(tile, a.tiles_x, a.tiles_y);
+    const int ni = tc.ni, ty0 = tc.ty0, tx0 = tc.tx0;
+    __syncthreads();  // previous tile's readers are done with the halo
+    stage.commit(halo);
+    __syncthreads();
+    if (tile + (int)gridDim.x < a.ntiles) {  // next tile's halo flies during this tile's MFMA phase
+      const TileCoord c = tile_coord(tile + gridDim.x, a.tiles_x, a.tiles_y);
+      stage.issue(a.x, c.ni, c.ty0, c.tx0, a.h, a.wd, a.ci);
+    }
+
+    f32x4 acc[4][CO_T];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int ct = 0; ct < CO_T; ++ct) acc[r][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int tr = t / 3, ts = t % 3;
+      const int dy = a.flip ? 1 - tr : tr - 1, dx = a.flip ? 1 - ts : ts - 1;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        f32x4 af[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int hy = 4 * wave + r + 1 + dy, hx = li + 1 + dx;
+          af[r] = *reinterpret_cast<const f32x4*>(halo + (hy * SH + hx) * CIP + 16 * g + 4 * kq);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int ct = 0; ct < CO_T; ++ct)
+              acc[r][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r][e], wreg[t][g][ct][e], acc[r][ct], 0, 0, 0);
+      }
+    }
+
+    // D reg v of lane (li, kq): pixel x = 4*kq + v of the row, channel 16*ct + li
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int gy = ty0 + 4 * wave + r;
+      if (gy >= a.h) continue;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int gx = tx0 + 4 * kq + v;
+        if (gx >= a.wd) continue;
+        float* dst = a.y + ((size_t)(ni * a.h + gy) * a.wd + gx) * (size_t)a.co;
+#pragma unroll
+        for (int ct = 0; ct < CO_T; ++ct) {
+          const int co = 16 * ct + li;
+          if (co < a.co) {
+            float val = act_apply(acc[r][ct][v] + bias[ct], a.act, a.slope);
+            if (a.accumulate) val += dst[co];
+            dst[co] = val;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+struct SmallWgradArgs {
+  const float* x;    // [n][h][w][ci]
+  const float* dy;   // [n][h][w][co]
+  float* partial;    // [gridDim.x][COP*9*CIP]
+  int n, h, w, ci, co;
+  int tiles_x, tiles_y, ntiles;
+};
+
+template <int G, int CO_T>
+__global__ __launch_bounds__(256) void conv3x3_small_wgrad_kernel(const SmallWgradArgs a) {
+  constexpr int CIP = 16 * G, COP = 16 * CO_T;
+  constexpr int OUT = COP * 9 * CIP;
+  constexpr int HALO = SH * SH * CIP;
+  constexpr int LDSF = (HALO + ST * ST * COP) > OUT ? (HALO + ST * ST * COP) : OUT;
+  __shared__ __attribute__((aligned(16))) float lds[LDSF];
+  float* halo = lds;
+  float* dyt = lds + HALO;  // [16*16][COP]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+
+  f32x4 acc[9][G][CO_T];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int ct = 0; ct < CO_T; ++ct) acc[t][g][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  HaloRegs<CIP> hx;
+  TileRegs<COP> hd;
+  int tile = blockIdx.x;
+  if (tile < a.ntiles) {
+    const TileCoord c = tile_coord(tile, a.tiles_x, a.tiles_y);
+    hx.issue(a.x, c.ni, c.ty0, c.tx0, a.h, a.w, a.ci);
+    hd.issue(a.dy, c.ni, c.ty0, c.tx0, a.h, a.w, a.co);
+  }
+  for (; tile < a.ntiles; tile += gridDim.x) {
+    __syncthreads();  // previous tile's readers are done
+    hx.commit(halo);
+    hd.commit(dyt);
+    __syncthreads();
+    if (tile + (int)gridDim.x < a.ntiles) {  // next tile's operands fly during this tile's MFMA phase
+      const TileCoord c = tile_coord(tile + gridDim.x, a.tiles_x, a.tiles_y);
+      hx.issue(a.x, c.ni, c.ty0, c.tx0, a.h, a.w, a.ci);
+      hd.issue(a.dy, c.ni, c.ty0, c.tx0, a.h, a.w, a.co);
+    }
+
+    // GEMM: dW[co][t][ci] += sum_pix dy[pix][co] * x[pix + tap][ci];  M = co (lane li), N = ci (lane li), K = 4 pixels (kq)
+#pragma unroll 1   // keep the live range to one row: full unrolling hoists 144+ LDS reads and overflows 256 VGPRs
+    for (int r = 0; r < 4; ++r) {
+      const int py = 4 * wave + r;
+#pragma unroll 2
+      for (int q = 0; q < 4; ++q) {
+        const int px = 4 * q + kq;
+        float af[CO_T];
+#pragma unroll
+        for (int ct = 0; ct < CO_T; ++ct) af[ct] = dyt[(py * ST + px) * COP + 16 * ct + li];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int hy = py + t / 3, hx = px + t % 3;  // halo coords of (py + r - 1, px + s - 1)
+#pragma unroll
+          for (int g = 0; g < G; ++g) {
+            const float bf = halo[(hy * SH + hx) * CIP + 16 * g + li];
+#pragma unroll
+            for (int ct = 0; ct < CO_T; ++ct)
+              acc[t][g][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ct], bf, acc[t][g][ct], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  // fold the 4 waves through LDS, then one partial per block.  D reg v of lane (li, kq): co = 16ct + 4kq + v, ci = 16g + li
+  __syncthreads();
+  for (int wv = 0; wv < 4; ++wv) {
+    if (wave == wv) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+          for (int ct = 0; ct < CO_T; ++ct)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              const int idx = ((16 * ct + 4 * kq + v) * 9 + t) * CIP + 16 * g + li;
+              lds[idx] = (wv == 0 ? 0.f : lds[idx]) + acc[t][g][ct][v];
+            }
+    }
+    __syncthreads();
+  }
+  float* dst = a.partial + (size_t)blockIdx.x * OUT;
+  for (int idx = threadIdx.x; idx < OUT; idx += 256) dst[idx] = lds[idx];
+}
+
+// dw[co][9][ci] += sum over blocks of partial[b][COP][9][CIP].  gridDim.y slices of the block range, 8 loads in flight
+// per thread, one atomic per (element, slice): 16 adds per address.
+constexpr int FOLD_SLICES = 16;
+__global__ void small_wgrad_fold_kernel(const float* __restrict__ partial, int nblocks, int cop, int cip, int co, int ci,
+                                        float* __restrict__ dw) {
+  const int out = cop * 9 * cip;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= out) return;
+  const int c = idx % cip, t = (idx / cip) % 9, o = idx / (cip * 9);
+  if (c >= ci || o >= co) return;
+  const int per = (nblocks + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = min(nblocks, b0 + per);
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int b = b0;
+  for (; b + 8 <= b1; b += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s[u] += partial[(size_t)(b + u) * out + idx];
+  }
+  for (; b < b1; ++b) s[0] += partial[(size_t)b * out + idx];
+  const float tot = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+  if (b1 > b0) atomicAdd(dw + ((size_t)o * 9 + t) * ci + c, tot);
+}
+
+static int small_grid(int ntiles, int blocks_per_cu) {
+  int g = 256 * blocks_per_cu;
+  return ntiles < g ? ntiles : g;
+}
+
+// ---- dispatch helpers used by conv_igemm.hip / conv_wgrad.hip ----------------------------------------------------
+bool small_conv_applicable(int k, int stride, int pad, int ci_gather, int co_out) {
+  if (k != 3 || stride != 1 || pad != 1) return false;
+  const int G = (ci_gather + 15) / 16, T = (co_out + 15) / 16;
+  return G * T <= 2;
+}
+
+int launch_small_conv(const float* x, const float* w, const float* bias, float* y, int n, int h, int wd, int ci, int co,
+                      int flip, int accumulate, int act, float slope, hipStream_t s) {
+  SmallArgs a = {};
+  a.x = x; a.w = w; a.bias = bias; a.y = y;
+  a.n = n; a.h = h; a.wd = wd; a.ci = ci; a.co = co;
+  a.flip = flip; a.accumulate = accumulate; a.act = act; a.slope = slope;
+  a.tiles_x = cdiv(wd, ST); a.tiles_y = cdiv(h, ST); a.ntiles = n * a.tiles_x * a.tiles_y;
+  const int G = cdiv(ci, 16), T = cdiv(co, 16);
+  dim3 block(256);
+  if (G == 1 && T == 1) hipLaunchKernelGGL((conv3x3_small_kernel<1, 1>), dim3(small_grid(a.ntiles, 6)), block, 0, s, a);
+  else if (G == 2 && T == 1) hipLaunchKernelGGL((conv3x3_small_kernel<2, 1>), dim3(small_grid(a.ntiles, 3)), block, 0, s, a);
+  else if (G == 1 && T == 2) hipLaunchKernelGGL((conv3x3_small_kernel<1, 2>), dim3(small_grid(a.ntiles, 6)), block, 0, s, a);
+  else {
+    set_error("small conv: unsupported channel groups G=%d T=%d", G, T);
+    return UDASEG_E_UNSUPPORTED;
+  }
+  UDASEG_LAUNCH_CHECK("conv3x3_small launch");
+  return UDASEG_OK;
+}
+
+bool small_wgrad_applicable(int k, int stride, int pad, int ci, int co, int ntiles) {
+  if (!small_conv_applicable(k, stride, pad, ci, co)) return false;
+  const int G = (ci + 15) / 16, T = (co + 15) / 16;
+  const size_t need = (size_t)small_grid(ntiles, 2) * (16 * T) * 9 * (16 * G) * sizeof(float);
+  return g_workspace != nullptr && g_workspace_bytes >= need;
+}
+
+int launch_small_wgrad(const float* x, const float* dy, float* dw, int n, int h, int wd, int ci, int co, int accumulate,
+                       hipStream_t s) {
+  SmallWgradArgs a = {};
+  a.x = x; a.dy = dy; a.partial = static_cast<float*>(g_workspace);
+  a.n = n; a.h = h; a.w = wd; a.ci = ci; a.co = co;
+  a.tiles_x = cdiv(wd, ST); a.tiles_y = cdiv(h, ST); a.ntiles = n * a.tiles_x * a.tiles_y;
+  const int G = cdiv(ci, 16), T = cdiv(co, 16);
+  const int grid = small_grid(a.ntiles, 2);
+  dim3 block(256);
+  if (G == 1 && T == 1) hipLaunchKernelGGL((conv3x3_small_wgrad_kernel<1, 1>), dim3(grid), block, 0, s, a);
+  else if (G == 2 && T == 1) hipLaunchKernelGGL((conv3x3_small_wgrad_kernel<2, 1>), dim3(grid), block, 0, s, a);
+  else if (G == 1 && T == 2) hipLaunchKernelGGL((conv3x3_small_wgrad_kernel<1, 2>), dim3(grid), block, 0, s, a);
+  else {
+    set_error("small wgrad: unsupported channel groups G=%d T=%d", G, T);
+    return UDASEG_E_UNSUPPORTED;
+  }
+  UDASEG_LAUNCH_CHECK("conv3x3_small_wgrad launch");
+  const int out = 16 * T * 9 * 16 * G;
+  if (!accumulate) {
+    hipError_t e = hipMemsetAsync(dw, 0, (size_t)co * 9 * ci * sizeof(float), s);
+    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(small wgrad)");
+  }
+  hipLaunchKernelGGL(small_wgrad_fold_kernel, dim3(cdiv(out, 256), FOLD_SLICES), dim3(256), 0, s, a.partial, grid, 16 * T, 16 * G,
+                     co, ci, dw);
+  UDASEG_LAUNCH_CHECK("small_wgrad_fold launch");
+  return UDASEG_OK;
+}
+
+}  // namespace udaseg
+
+extern "C" int udaseg_set_workspace(void* ptr, size_t bytes) {
+  udaseg::g_workspace = ptr;
+  udaseg::g_workspace_bytes = ptr ? bytes : 0;
+  return UDASEG_OK;
+}

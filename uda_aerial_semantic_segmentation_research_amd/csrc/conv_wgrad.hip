@@ -200,7 +200,10 @@ extern "C" int udaseg_conv2d_wgrad(const udaseg_conv_desc* d, const float* x, co
   hipStream_t st = as_stream(stream);
   prof_begin(1, st);
   int rc;
-  if (d->co > 32) rc = launch_wgrad<64, 64, 2, 2>(a, accumulate, st);
+  if (d->kh == d->kw &&
+      small_wgrad_applicable(d->kh, d->stride, d->pad, d->ci, d->co, d->n * cdiv(d->hi, 16) * cdiv(d->wi, 16)))
+    rc = launch_small_wgrad(x, dy, dw, d->n, d->hi, d->wi, d->ci, d->co, accumulate, st);
+  else if (d->co > 32) rc = launch_wgrad<64, 64, 2, 2>(a, accumulate, st);
   else rc = launch_wgrad<32, 128, 1, 4>(a, accumulate, st);
   prof_end(1, st, udaseg_conv_flops(d), 2, d);
   return rc;

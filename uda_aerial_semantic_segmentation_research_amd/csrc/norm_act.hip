@@ -92,61 +92,58 @@ __global__ void bn_stats_kernel(const f32x4* __restrict__ y, int64_t n4, int c4,
   block_fold_add(ss, rep + (size_t)c4 * 4, c4, q, red);
 }
 
-struct BnCoef {
-  f32x4 scale, shift, mean, rstd;
-};
+constexpr int MAX_C4 = 1024;  // channels <= 4096
 
-__device__ __forceinline__ BnCoef bn_coef_from_sums(const double* sums, const float* gamma, const float* beta, int c4,
-                                                    int q, int64_t pixels, float eps, f32x4* var_out) {
-  BnCoef k;
-  const double inv = 1.0 / (double)pixels;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int c = q * 4 + e;
-    double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-    for (int r = 0; r < BN_REPLICAS; ++r) {
-      s1 += sums[(size_t)r * 2 * c4 * 4 + c];
-      s2 += sums[(size_t)r * 2 * c4 * 4 + (size_t)c4 * 4 + c];
-    }
-    const double m = s1 * inv;
-    double var = s2 * inv - m * m;
-    var = var > 0.0 ? var : 0.0;
-    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-    k.mean[e] = (float)m;
-    k.rstd[e] = rstd;
-    k.scale[e] = gamma[c] * rstd;
-    k.shift[e] = beta[c] - (float)m * k.scale[e];
-    (*var_out)[e] = (float)var;
-  }
-  return k;
-}
-
+// Per-channel-quad coefficients are computed ONCE per block (threads q < c4, strided) into LDS; every thread then picks
+// the quad it streams.  (Summing the 16 replicas in every thread cost more than the streaming itself on small tensors.)
 __global__ void bn_apply_kernel(const f32x4* __restrict__ y, const double* __restrict__ sums,
                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                 const f32x4* __restrict__ residual, f32x4* __restrict__ z, int64_t n4, int c4,
                                 int64_t pixels, float eps, float momentum, float* running_mean, float* running_var,
                                 float* save_mean, float* save_rstd, int act, float slope) {
-  const int64_t T = (int64_t)gridDim.x * blockDim.x;
-  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int q = (int)(g % c4);
-  f32x4 var;
-  const BnCoef k = bn_coef_from_sums(sums, gamma, beta, c4, q, pixels, eps, &var);
-  if (g < c4) {  // exactly one owner per channel quad
+  extern __shared__ __attribute__((aligned(16))) float4 coef[];  // [2][c4]: scale, shift
+  const double inv = 1.0 / (double)pixels;
+  for (int q = threadIdx.x; q < c4; q += blockDim.x) {
+    float4 sc, sh;
+    float* scp = reinterpret_cast<float*>(&sc);
+    float* shp = reinterpret_cast<float*>(&sh);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int c = q * 4 + e;
-      if (save_mean) save_mean[c] = k.mean[e];
-      if (save_rstd) save_rstd[c] = k.rstd[e];
-      if (running_mean) {
-        const float unb = pixels > 1 ? var[e] * ((float)pixels / (float)(pixels - 1)) : var[e];
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * k.mean[e];
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+      double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+      for (int r = 0; r < BN_REPLICAS; ++r) {
+        s1 += sums[(size_t)r * 2 * c4 * 4 + c];
+        s2 += sums[(size_t)r * 2 * c4 * 4 + (size_t)c4 * 4 + c];
+      }
+      const double m = s1 * inv;
+      double var = s2 * inv - m * m;
+      var = var > 0.0 ? var : 0.0;
+      const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+      scp[e] = gamma[c] * rstd;
+      shp[e] = beta[c] - (float)m * scp[e];
+      if (blockIdx.x == 0) {  // one owner per channel
+        if (save_mean) save_mean[c] = (float)m;
+        if (save_rstd) save_rstd[c] = rstd;
+        if (running_mean) {
+          const float v = (float)var;
+          const float unb = pixels > 1 ? v * ((float)pixels / (float)(pixels - 1)) : v;
+          running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+          running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+        }
       }
     }
+    coef[q] = sc;
+    coef[c4 + q] = sh;
   }
+  __syncthreads();
+  const int64_t T = (int64_t)gridDim.x * blockDim.x;
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int q = (int)(g % c4);
+  const float4 sc4 = coef[q], sh4 = coef[c4 + q];
+  const f32x4 scale = {sc4.x, sc4.y, sc4.z, sc4.w}, shift = {sh4.x, sh4.y, sh4.z, sh4.w};
   for (int64_t i = g; i < n4; i += T) {
-    f32x4 v = y[i] * k.scale + k.shift;
+    f32x4 v = y[i] * scale + shift;
     if (residual) v += residual[i];
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], act, slope);
@@ -218,30 +215,46 @@ __global__ void bn_bwd_apply_kernel(const f32x4* __restrict__ dz, const f32x4* _
                                     const double* __restrict__ bsums, f32x4* __restrict__ dy, f32x4* __restrict__ dres,
                                     float* dgamma, float* dbeta, int64_t n4, int c4, int64_t pixels, int act,
                                     float slope, int acc_dy, int acc_dres, int acc_param) {
+  extern __shared__ __attribute__((aligned(16))) float4 coef[];  // [5][c4]: mean, rstd, scale, mean(g), mean(g*xhat)
+  const double inv = 1.0 / (double)pixels;
+  for (int q = threadIdx.x; q < c4; q += blockDim.x) {
+    float4 v[5];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = q * 4 + e;
+      double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+      for (int r = 0; r < BN_REPLICAS; ++r) {
+        s1 += bsums[(size_t)r * 2 * c4 * 4 + c];
+        s2 += bsums[(size_t)r * 2 * c4 * 4 + (size_t)c4 * 4 + c];
+      }
+      const float rs = save_rstd[c];
+      reinterpret_cast<float*>(&v[0])[e] = save_mean[c];
+      reinterpret_cast<float*>(&v[1])[e] = rs;
+      reinterpret_cast<float*>(&v[2])[e] = gamma[c] * rs;
+      reinterpret_cast<float*>(&v[3])[e] = (float)(s1 * inv);
+      reinterpret_cast<float*>(&v[4])[e] = (float)(s2 * inv);
+      if (blockIdx.x == 0) {
+        const float db = (float)s1, dg = (float)s2;
+        if (dbeta) dbeta[c] = acc_param ? dbeta[c] + db : db;
+        if (dgamma) dgamma[c] = acc_param ? dgamma[c] + dg : dg;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) coef[k * c4 + q] = v[k];
+  }
+  __syncthreads();
   const int64_t T = (int64_t)gridDim.x * blockDim.x;
   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int q = (int)(g % c4);
   f32x4 mean, rstd, scale, mg, mgx;
-  const double inv = 1.0 / (double)pixels;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int c = q * 4 + e;
-    mean[e] = save_mean[c];
-    rstd[e] = save_rstd[c];
-    scale[e] = gamma[c] * rstd[e];
-    double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-    for (int r = 0; r < BN_REPLICAS; ++r) {
-      s1 += bsums[(size_t)r * 2 * c4 * 4 + c];
-      s2 += bsums[(size_t)r * 2 * c4 * 4 + (size_t)c4 * 4 + c];
-    }
-    mg[e] = (float)(s1 * inv);
-    mgx[e] = (float)(s2 * inv);
-    if (g < c4) {
-      const float db = (float)s1, dg = (float)s2;
-      if (dbeta) dbeta[c] = acc_param ? dbeta[c] + db : db;
-      if (dgamma) dgamma[c] = acc_param ? dgamma[c] + dg : dg;
-    }
+  {
+    const float4 a0 = coef[q], a1 = coef[c4 + q], a2 = coef[2 * c4 + q], a3 = coef[3 * c4 + q], a4 = coef[4 * c4 + q];
+    mean = f32x4{a0.x, a0.y, a0.z, a0.w};
+    rstd = f32x4{a1.x, a1.y, a1.z, a1.w};
+    scale = f32x4{a2.x, a2.y, a2.z, a2.w};
+    mg = f32x4{a3.x, a3.y, a3.z, a3.w};
+    mgx = f32x4{a4.x, a4.y, a4.z, a4.w};
   }
   for (int64_t i = g; i < n4; i += T) {
     f32x4 gz = dz[i];
@@ -336,7 +349,7 @@ extern "C" int udaseg_bn_apply(const float* y, const double* sums, const float* 
   UDASEG_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "bn_apply: running_mean/var must come together");
   const int64_t n4 = pixels * (c / 4);
   const StreamShape s = stream_shape(n4, c / 4);
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(s.grid), dim3(s.bs), 0, as_stream(stream), (const f32x4*)y, sums, gamma, beta,
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(s.grid), dim3(s.bs), (size_t)2 * s.c4 * sizeof(float4), as_stream(stream), (const f32x4*)y, sums, gamma, beta,
                      (const f32x4*)residual, (f32x4*)z, n4, s.c4, pixels, eps, momentum, running_mean, running_var,
                      save_mean, save_rstd, act, slope);
   UDASEG_LAUNCH_CHECK("bn_apply launch");
@@ -383,7 +396,7 @@ extern "C" int udaseg_bn_bwd_apply(const float* dz, const float* z, const float*
   UDASEG_CHECK_ARG(act == UDASEG_ACT_NONE || z, "bn_bwd_apply: z required when an activation follows the norm");
   const int64_t n4 = pixels * (c / 4);
   const StreamShape s = stream_shape(n4, c / 4);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(s.grid), dim3(s.bs), 0, as_stream(stream), (const f32x4*)dz, (const f32x4*)z,
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(s.grid), dim3(s.bs), (size_t)5 * s.c4 * sizeof(float4), as_stream(stream), (const f32x4*)dz, (const f32x4*)z,
                      (const f32x4*)y, save_mean, save_rstd, gamma, bsums, (f32x4*)dy, (f32x4*)dres, dgamma, dbeta, n4, s.c4,
                      pixels, act, slope, accumulate_dy, accumulate_dres, accumulate_param);
   UDASEG_LAUNCH_CHECK("bn_bwd_apply launch");

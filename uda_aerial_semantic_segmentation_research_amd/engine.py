@@ -227,6 +227,7 @@ class Plan:
         self.idx = net.entry_index()
         dev = net._arena.device
         self.R = K.bn_replicas()
+        K.ensure_workspace(dev)
         nbn = net._nbn
         self.dev = dev
         if training:

@@ -16,6 +16,19 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+_WORKSPACE = {}
+
+
+def ensure_workspace(device, nbytes=16 << 20):
+    """Hand the library its scratch buffer (once per device; PyTorch owns the memory)."""
+    key = str(device)
+    if key not in _WORKSPACE:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        check(_lib.load().udaseg_set_workspace(buf.data_ptr(), nbytes), "set_workspace")
+        _WORKSPACE[key] = buf
+    return _WORKSPACE[key]
+
+
 def _ptr(t):
     return None if t is None else t.data_ptr()
 
