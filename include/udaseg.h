@@ -157,6 +157,11 @@ int udaseg_prof_enable(int on);
 int udaseg_prof_reset(void);
 /* family: 0 = igemm fwd/dgrad, 1 = wgrad.  Synchronises the recorded events (call outside timed regions). */
 int udaseg_prof_read(int family, double* total_ms, double* total_flops, int64_t* launches);
+/* Per KERNEL SYMBOL (one id per template instantiation; names match rocprofv3's kernel trace): total HIP-event time,
+ * algorithmic GEMM FLOPs (2*M*N*K of every launch) and launch count while profiling was enabled. */
+int udaseg_prof_kernel_count(void);
+const char* udaseg_prof_kernel_name(int kid);
+int udaseg_prof_kernel_read(int kid, double* total_ms, double* total_flops, int64_t* launches);
 /* Per-launch records: ms, flops, kind (0 fwd, 1 dgrad, 2 wgrad) and the 11 ints of the conv desc. Returns the count. */
 int udaseg_prof_records(int family, int max_records, double* ms, double* flops, int* kind, int* desc11);
 

@@ -62,6 +62,9 @@ SIGNATURES = {
     "udaseg_prof_enable": (_I, [_I]),
     "udaseg_prof_reset": (_I, []),
     "udaseg_prof_read": (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "udaseg_prof_kernel_count": (_I, []),
+    "udaseg_prof_kernel_name": (C.c_char_p, [_I]),
+    "udaseg_prof_kernel_read": (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "udaseg_prof_records": (_I, [_I, _I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
 }
 

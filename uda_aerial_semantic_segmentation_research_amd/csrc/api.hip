@@ -28,6 +28,16 @@ struct ProfRec {
   udaseg_conv_desc d;
 };
 static bool g_prof_on = false;
+struct KRec {
+  hipEvent_t a, b;
+  double flops;
+};
+static const char* const g_knames[PROF_NKERNELS] = {
+    "conv_igemm_kernel<128, 128, 2, 2>", "conv_igemm_kernel<128, 64, 2, 2>", "conv_igemm_kernel<64, 64, 2, 2>",
+    "conv_igemm_kernel<128, 32, 4, 1>",  "conv3x3_small_kernel<1, 1>",       "conv3x3_small_kernel<2, 1>",
+    "conv3x3_small_kernel<1, 2>",        "conv_wgrad_kernel<64, 64, 2, 2>",  "conv_wgrad_kernel<32, 128, 1, 4>",
+    "conv3x3_small_wgrad_kernel<1, 1>",  "conv3x3_small_wgrad_kernel<2, 1>", "conv3x3_small_wgrad_kernel<1, 2>"};
+static std::vector<KRec> g_krecs[PROF_NKERNELS];
 static std::vector<ProfRec> g_recs[2];
 static std::vector<hipEvent_t> g_pool;
 static hipEvent_t g_open[2];
@@ -41,6 +51,21 @@ static hipEvent_t get_event() {
   hipEvent_t e;
   if (hipEventCreate(&e) != hipSuccess) return nullptr;
   return e;
+}
+
+hipEvent_t kprof_begin(hipStream_t s) {
+  if (!g_prof_on) return nullptr;
+  hipEvent_t a = get_event();
+  if (a) (void)hipEventRecord(a, s);
+  return a;
+}
+
+void kprof_end(int kid, hipEvent_t a, hipStream_t s, double flops) {
+  if (!a) return;
+  hipEvent_t b = get_event();
+  if (!b) return;
+  (void)hipEventRecord(b, s);
+  g_krecs[kid].push_back({a, b, flops});
 }
 
 void prof_begin(int family, hipStream_t s) {
@@ -86,6 +111,13 @@ extern "C" int udaseg_prof_reset(void) {
     }
     g_recs[f].clear();
   }
+  for (int k = 0; k < PROF_NKERNELS; ++k) {
+    for (auto& r : g_krecs[k]) {
+      g_pool.push_back(r.a);
+      g_pool.push_back(r.b);
+    }
+    g_krecs[k].clear();
+  }
   return UDASEG_OK;
 }
 
@@ -125,4 +157,25 @@ extern "C" int udaseg_prof_records(int family, int max_records, double* ms, doub
     ++n;
   }
   return n;
+}
+
+extern "C" int udaseg_prof_kernel_count(void) { return PROF_NKERNELS; }
+extern "C" const char* udaseg_prof_kernel_name(int kid) { return (kid >= 0 && kid < PROF_NKERNELS) ? g_knames[kid] : ""; }
+
+extern "C" int udaseg_prof_kernel_read(int kid, double* total_ms, double* total_flops, int64_t* launches) {
+  UDASEG_CHECK_ARG(kid >= 0 && kid < PROF_NKERNELS && total_ms && total_flops && launches, "prof_kernel_read: bad arguments");
+  double ms = 0.0, fl = 0.0;
+  for (auto& r : g_krecs[kid]) {
+    hipError_t e = hipEventSynchronize(r.b);
+    if (e != hipSuccess) return hip_fail(e, "hipEventSynchronize(kprof)");
+    float t = 0.f;
+    e = hipEventElapsedTime(&t, r.a, r.b);
+    if (e != hipSuccess) return hip_fail(e, "hipEventElapsedTime(kprof)");
+    ms += t;
+    fl += r.flops;
+  }
+  *total_ms = ms;
+  *total_flops = fl;
+  *launches = (int64_t)g_krecs[kid].size();
+  return UDASEG_OK;
 }

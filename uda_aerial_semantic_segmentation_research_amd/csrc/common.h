@@ -70,7 +70,10 @@ bool small_wgrad_applicable(int k, int stride, int pad, int ci, int co, int ntil
 int launch_small_wgrad(const float* x, const float* dy, float* dw, int n, int h, int wd, int ci, int co, int accumulate,
                        hipStream_t s);
 
-// live launch timing (bench.py roofline leg)
+// live launch timing (bench.py roofline leg): per API call (prof_*) and per kernel launch (kprof_*)
+constexpr int PROF_NKERNELS = 12;
+hipEvent_t kprof_begin(hipStream_t s);
+void kprof_end(int kid, hipEvent_t a, hipStream_t s, double flops);
 void prof_begin(int family, hipStream_t s);
 void prof_end(int family, hipStream_t s, double flops, int kind, const udaseg_conv_desc* d);
 

@@ -19,6 +19,8 @@
 // one barrier per K-tile.  LDS rows are K-contiguous with a 4-float pad: ds_read_b128 conflict-free.
 // Each lane's 16-byte LDS read feeds 4 consecutive MFMAs (the K order inside a tile is permuted identically
 // for A and B, which a GEMM does not care about).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace udaseg {
@@ -244,14 +246,34 @@ static int launch_cfg(const IgemmArgs& a, hipStream_t s) {
   }
   const int mt = cdiv(a.M, BM), nt = cdiv(a.co, BN);
   dim3 grid((unsigned)(mt * nt)), block(256);
+  constexpr int kid = (BM == 128 && BN == 128) ? 0 : (BM == 128 && BN == 64) ? 1 : (BM == 64) ? 2 : 3;
+  hipEvent_t ev = kprof_begin(s);
   hipLaunchKernelGGL(kern, grid, block, lds, s, a);
+  kprof_end(kid, ev, s, 2.0 * (double)a.M * a.co * a.K);
   UDASEG_LAUNCH_CHECK("conv_igemm launch");
   return UDASEG_OK;
+}
+
+static int tile_override() {
+  // tuning aid: UDASEG_IGEMM_TILE = 1 (128x128) | 2 (128x64) | 3 (64x64) | 4 (128x32); unset/0 = heuristic
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("UDASEG_IGEMM_TILE");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
 }
 
 static int launch_igemm(const IgemmArgs& a, hipStream_t s) {
   if (a.M <= 0) return UDASEG_OK;
   const long long tiles128 = (long long)cdiv(a.M, 128);
+  switch (tile_override()) {
+    case 1: return launch_cfg<128, 128, 2, 2>(a, s);
+    case 2: return launch_cfg<128, 64, 2, 2>(a, s);
+    case 3: return launch_cfg<64, 64, 2, 2>(a, s);
+    case 4: return launch_cfg<128, 32, 4, 1>(a, s);
+    default: break;
+  }
   // tile choice: widest N tile the channel count fills; fall back to 64x64 when a 128-row tiling would
   // leave most of the 256 CUs idle (deep, low-resolution layers).
   if (a.co > 64) {

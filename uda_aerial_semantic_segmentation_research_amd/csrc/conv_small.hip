@@ -336,10 +336,18 @@ int launch_small_conv(const float* x, const float* w, const float* bias, float* 
   a.tiles_x = cdiv(wd, ST); a.tiles_y = cdiv(h, ST); a.ntiles = n * a.tiles_x * a.tiles_y;
   const int G = cdiv(ci, 16), T = cdiv(co, 16);
   dim3 block(256);
-  if (G == 1 && T == 1) hipLaunchKernelGGL((conv3x3_small_kernel<1, 1>), dim3(small_grid(a.ntiles, 6)), block, 0, s, a);
-  else if (G == 2 && T == 1) hipLaunchKernelGGL((conv3x3_small_kernel<2, 1>), dim3(small_grid(a.ntiles, 3)), block, 0, s, a);
-  else if (G == 1 && T == 2) hipLaunchKernelGGL((conv3x3_small_kernel<1, 2>), dim3(small_grid(a.ntiles, 6)), block, 0, s, a);
-  else {
+  const double fl = 2.0 * (double)n * h * wd * co * 9.0 * ci;
+  hipEvent_t ev = kprof_begin(s);
+  if (G == 1 && T == 1) {
+    hipLaunchKernelGGL((conv3x3_small_kernel<1, 1>), dim3(small_grid(a.ntiles, 6)), block, 0, s, a);
+    kprof_end(4, ev, s, fl);
+  } else if (G == 2 && T == 1) {
+    hipLaunchKernelGGL((conv3x3_small_kernel<2, 1>), dim3(small_grid(a.ntiles, 3)), block, 0, s, a);
+    kprof_end(5, ev, s, fl);
+  } else if (G == 1 && T == 2) {
+    hipLaunchKernelGGL((conv3x3_small_kernel<1, 2>), dim3(small_grid(a.ntiles, 6)), block, 0, s, a);
+    kprof_end(6, ev, s, fl);
+  } else {
     set_error("small conv: unsupported channel groups G=%d T=%d", G, T);
     return UDASEG_E_UNSUPPORTED;
   }
@@ -363,10 +371,18 @@ int launch_small_wgrad(const float* x, const float* dy, float* dw, int n, int h,
   const int G = cdiv(ci, 16), T = cdiv(co, 16);
   const int grid = small_grid(a.ntiles, 2);
   dim3 block(256);
-  if (G == 1 && T == 1) hipLaunchKernelGGL((conv3x3_small_wgrad_kernel<1, 1>), dim3(grid), block, 0, s, a);
-  else if (G == 2 && T == 1) hipLaunchKernelGGL((conv3x3_small_wgrad_kernel<2, 1>), dim3(grid), block, 0, s, a);
-  else if (G == 1 && T == 2) hipLaunchKernelGGL((conv3x3_small_wgrad_kernel<1, 2>), dim3(grid), block, 0, s, a);
-  else {
+  const double fl = 2.0 * (double)n * h * wd * co * 9.0 * ci;
+  hipEvent_t ev = kprof_begin(s);
+  if (G == 1 && T == 1) {
+    hipLaunchKernelGGL((conv3x3_small_wgrad_kernel<1, 1>), dim3(grid), block, 0, s, a);
+    kprof_end(9, ev, s, fl);
+  } else if (G == 2 && T == 1) {
+    hipLaunchKernelGGL((conv3x3_small_wgrad_kernel<2, 1>), dim3(grid), block, 0, s, a);
+    kprof_end(10, ev, s, fl);
+  } else if (G == 1 && T == 2) {
+    hipLaunchKernelGGL((conv3x3_small_wgrad_kernel<1, 2>), dim3(grid), block, 0, s, a);
+    kprof_end(11, ev, s, fl);
+  } else {
     set_error("small wgrad: unsupported channel groups G=%d T=%d", G, T);
     return UDASEG_E_UNSUPPORTED;
   }

@@ -174,7 +174,9 @@ static int launch_wgrad(WgradArgs a, int accumulate, hipStream_t s) {
     if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(dw)");
   }
   dim3 grid((unsigned)tiles, (unsigned)splits), block(256);
+  hipEvent_t ev = kprof_begin(s);
   hipLaunchKernelGGL((conv_wgrad_kernel<BMW, BNW, WAVES_M, WAVES_N>), grid, block, 0, s, a);
+  kprof_end(BMW == 64 ? 7 : 8, ev, s, 2.0 * (double)a.M * a.co * a.J);
   UDASEG_LAUNCH_CHECK("conv_wgrad launch");
   return UDASEG_OK;
 }

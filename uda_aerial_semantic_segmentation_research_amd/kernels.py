@@ -244,3 +244,14 @@ def prof_records(family, max_records=4096):
     if n < 0:
         check(n, "prof_records")
     return [(ms[i], fl[i], kind[i], tuple(desc[11 * i:11 * i + 11])) for i in range(n)]
+
+
+def prof_kernels():
+    """[(kernel symbol, total ms, total flops, launches)] for every conv kernel instantiation."""
+    lib = _lib.load()
+    out = []
+    for kid in range(lib.udaseg_prof_kernel_count()):
+        ms, fl, n = _lib.C.c_double(), _lib.C.c_double(), _lib.C.c_int64()
+        check(lib.udaseg_prof_kernel_read(kid, _byref(ms), _byref(fl), _byref(n)), "prof_kernel_read")
+        out.append((lib.udaseg_prof_kernel_name(kid).decode(), ms.value, fl.value, n.value))
+    return out
