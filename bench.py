@@ -161,8 +161,8 @@ def main():
             for (kind, d), (ms, fl, cnt) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
                 print(f"{('fwd', 'dgrad', 'wgrad')[kind]:5s} {d[0]:2d} {d[1]:3d} {d[2]:3d} {d[3]:4d} {d[6]:4d} {d[7]} {d[9]} | "
                       f"{cnt / psteps:5.1f} {ms / cnt:9.4f} {fl / cnt / 1e9:8.2f} {fl / ms / 1e9:8.1f}", file=sys.stderr)
-        K.prof_reset()
         kern = [k for k in K.prof_kernels() if k[3] > 0]
+        K.prof_reset()
         kern.sort(key=lambda k: -k[1])
         dom = kern[0]                                   # the kernel symbol with the most device time
         achieved = dom[2] / (dom[1] * 1e-3) / 1e12

@@ -65,6 +65,9 @@ int udaseg_conv2d_wgrad(const udaseg_conv_desc* d, const float* x, const float* 
                         void* stream);
 /* w[co][kh*kw][ci] -> w_t[ci][kh*kw][co] */
 int udaseg_pack_dgrad_weights(const udaseg_conv_desc* d, const float* w, float* w_t, void* stream);
+/* The same for every convolution of a network in one launch: table[i] = {src float-offset into arena, dst float-offset
+ * into packed, co, kh*kw, ci} (int32, device memory). */
+int udaseg_pack_dgrad_batched(const float* arena, float* packed, const int* table, int entries, void* stream);
 /* Conv FLOPs (2*MAC) of one call, for roofline accounting. */
 double udaseg_conv_flops(const udaseg_conv_desc* d);
 
@@ -120,9 +123,11 @@ int udaseg_upsample2x_concat_bwd(const float* dout, float* da, float* dskip, int
 int udaseg_ce_partials(void);
 int udaseg_ce_fwd(const float* logits, const int64_t* target, int64_t pixels, int classes, int ldc, float* lse,
                   double* partials, float* loss, void* stream);
-/* dlogits[p][ldc] = (softmax - onehot) * (*grad_out) / pixels; pad channels written as 0 */
+/* dlogits[p][ldc] = (softmax - onehot) * (*grad_out) / pixels; pad channels written as 0.
+ * Optional (ldc <= 32): colsum[ldc] = per-class sum of dlogits over all pixels (= the head conv's bias gradient, reference
+ * src/models/train.py:343), produced in the same pass; colsum_partials = scratch of udaseg_ce_partials()*ldc floats. */
 int udaseg_ce_bwd(const float* logits, const int64_t* target, const float* lse, const float* grad_out, int64_t pixels,
-                  int classes, int ldc, float* dlogits, void* stream);
+                  int classes, int ldc, float* dlogits, float* colsum_partials, float* colsum, void* stream);
 
 /* ---- discriminator tail + adversarial BCE: discriminator.py:37-42, losses.py:18-51 ---- */
 /* pooled[n][c] = mean over hw of z; p[n] = sigmoid(dot(pooled[n], w) + b).  partial: [n][splits][c] floats */

@@ -133,13 +133,37 @@ def grads_vs_oracle(net, ref32, x, loss_fn, label):
     return nflip
 
 
-@pytest.mark.parametrize("name", ["resnet18", "resnet34", "resnet50"])
-def test_unet_forward_backward_adam_vs_oracle(pkg, name, golden_dir):
+@pytest.mark.parametrize("name", ["resnet18", "resnet50"])
+def test_unet_train_forward_vs_golden_fixture(pkg, name, golden_dir):
+    """Train-mode forward + CE at the committed fixture's size (tests/golden/unet_oracle.npz, made by the oracle in the
+    build container): loss, logits sample, per-stage encoder features."""
+    from oracle.adversarial_ref import synthetic_batch
+    from uda_aerial_semantic_segmentation_research_amd.losses import CrossEntropyLoss
+    g = np.load(os.path.join(golden_dir, "unet_oracle.npz"))
+    _, net = _pair(name)
+    x, y, _ = synthetic_batch(2, 64, 64, seed=0)
+    with torch.no_grad():
+        logits = net(x.cuda())
+        loss = CrossEntropyLoss()(logits, y.cuda())
+    assert abs(loss.item() - float(g[f"{name}/loss"])) <= 1e-4 * float(g[f"{name}/loss"])
+    step = max(1, logits.numel() // 64)
+    got = logits.detach().cpu().contiguous().flatten()[::step][:64].numpy()
+    want = g[f"{name}/logits/sample"]
+    assert np.abs(got - want).max() <= RTOL * np.abs(want).max()
+    st = np.array([logits.double().sum().item(), logits.double().abs().sum().item()])
+    ws = g[f"{name}/logits/stats"]
+    assert abs(st[1] - ws[1]) <= RTOL * ws[1] and abs(st[0] - ws[0]) <= RTOL * ws[1]
+
+
+# r50 is checked at 128x128: at 64x64 its layer4 BatchNorm sees 8 values per channel, an ill-conditioned regime in which
+# a change of fp32 summation ORDER alone moves layer4 gradients by ~1e-3
+@pytest.mark.parametrize("name,size", [("resnet18", 64), ("resnet34", 64), ("resnet50", 128)])
+def test_unet_forward_backward_adam_vs_oracle(pkg, name, size):
     from oracle.adversarial_ref import synthetic_batch
     from uda_aerial_semantic_segmentation_research_amd.losses import CrossEntropyLoss
     from uda_aerial_semantic_segmentation_research_amd.optim import FusedAdam
     ref, net = _pair(name)
-    x, y, _ = synthetic_batch(2, 64, 64, seed=0)
+    x, y, _ = synthetic_batch(2, size, size, seed=0)
 
     opt_ref = torch.optim.Adam(ref.parameters(), lr=1e-4)
     opt_ref.zero_grad()
@@ -151,7 +175,7 @@ def test_unet_forward_backward_adam_vs_oracle(pkg, name, golden_dir):
     opt.zero_grad()
     net.debug_keep_tape = True
     logits = net(x.cuda())
-    assert logits.shape == (2, 23, 64, 64)
+    assert logits.shape == (2, 23, size, size)
     loss = CrossEntropyLoss()(logits, y.cuda())
     assert loss.dim() == 0 and loss.grad_fn is not None
     loss.backward()
@@ -168,14 +192,6 @@ def test_unet_forward_backward_adam_vs_oracle(pkg, name, golden_dir):
             check(sd[k], sdr[k], k, 1e-4)
         if "num_batches" in k:
             assert int(sd[k]) == int(sdr[k]) == 1
-    # golden fixture (made by the oracle in the build container)
-    if name in ("resnet18", "resnet50"):
-        g = np.load(os.path.join(golden_dir, "unet_oracle.npz"))
-        assert abs(loss.item() - float(g[f"{name}/loss"])) <= RTOL * float(g[f"{name}/loss"])
-        step = max(1, logits.numel() // 64)
-        got = logits.detach().cpu().contiguous().flatten()[::step][:64].numpy()
-        want = g[f"{name}/logits/sample"]
-        assert np.abs(got - want).max() <= RTOL * np.abs(logits_ref.detach().numpy()).max()
     # one optimizer step: fused flat Adam vs torch.optim.Adam.  Adam moves every weight by ~lr whatever the size of
     # its gradient, so compare the UPDATE on entries whose gradient agrees in sign and is far above the noise.
     before = {k: v.detach().clone() for k, v in ref.named_parameters()}

@@ -33,6 +33,7 @@ SIGNATURES = {
     "udaseg_conv2d_dgrad": (_I, [_D, _P, _P, _P, _I, _P]),
     "udaseg_conv2d_wgrad": (_I, [_D, _P, _P, _P, _I, _P]),
     "udaseg_pack_dgrad_weights": (_I, [_D, _P, _P, _P]),
+    "udaseg_pack_dgrad_batched": (_I, [_P, _P, _P, _I, _P]),
     "udaseg_conv_flops": (C.c_double, [_D]),
     "udaseg_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "udaseg_bn_replicas": (_I, []),
@@ -49,7 +50,7 @@ SIGNATURES = {
     "udaseg_upsample2x_concat_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "udaseg_ce_partials": (_I, []),
     "udaseg_ce_fwd": (_I, [_P, _P, _L, _I, _I, _P, _P, _P, _P]),
-    "udaseg_ce_bwd": (_I, [_P, _P, _P, _P, _L, _I, _I, _P, _P]),
+    "udaseg_ce_bwd": (_I, [_P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _P]),
     "udaseg_gap_splits": (_I, [_I]),
     "udaseg_gap_linear_sigmoid_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "udaseg_gap_linear_sigmoid_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

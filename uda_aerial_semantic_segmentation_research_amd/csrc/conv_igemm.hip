@@ -25,6 +25,8 @@
 
 namespace udaseg {
 
+constexpr int NCLS = 4;  // classes per launch: dgrad parity classes of a strided conv, or K-slices (tap ranges)
+
 struct IgemmArgs {
   const float* x;
   const float* w;
@@ -32,13 +34,19 @@ struct IgemmArgs {
   float* y;
   int hi, wi, ci;
   int ho, wo, co;
-  int JY, JX, M;
-  int cy, cx, sy_o, sx_o, sy_i, sx_i;
-  int ntaps, tfull, K;
-  float inv_ci, inv_jx, inv_jy;
+  int sy_o, sx_o, sy_i, sx_i;
+  int tfull;
+  float inv_ci;
   int accumulate, act;
   float slope;
   int dense_out;
+  int atomic_out;   // K-slices of one output: epilogue adds with global_atomic_add_f32 (output pre-zeroed or accumulated)
+  int nclass;
+  // per class
+  int JY[NCLS], JX[NCLS], M[NCLS], cy[NCLS], cx[NCLS];
+  int ntaps[NCLS], K[NCLS], tap_off[NCLS];
+  int tile_begin[NCLS + 1];   // prefix sums of the classes' tile counts (blockIdx.x ranges)
+  float inv_jx[NCLS], inv_jy[NCLS];
   signed char dy[64];
   signed char dx[64];
   unsigned char wt[64];
@@ -69,17 +77,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
   const int lr = lane & 31, lh = lane >> 5;
   const int wm = (wave / WAVES_N) * WM, wn = (wave % WAVES_N) * WN;
 
-  // ---- block -> tile, XCD-aware: blocks that share blockIdx%8 (one XCD's L2) take a contiguous run of
-  // tiles, N-tiles innermost, so an XCD re-reads its own A rows / halos from its own L2.
+  // ---- block -> (class, tile).  Within a class the tile order is XCD-aware: blocks that share blockIdx%8 (one XCD's
+  // L2) take a contiguous run of tiles, N-tiles innermost, so an XCD re-reads its own A rows / halos from its own L2.
+  int cls = 0;
+#pragma unroll
+  for (int c = 1; c < NCLS; ++c)
+    if (c < a.nclass && (int)blockIdx.x >= a.tile_begin[c]) cls = c;
   const int ntn = (a.co + BN - 1) / BN;
-  const int nblk = gridDim.x;
-  int bid = blockIdx.x;
+  const int nblk = a.tile_begin[cls + 1] - a.tile_begin[cls];
+  int bid = blockIdx.x - a.tile_begin[cls];
   {
     const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
   const int m0 = (bid / ntn) * BM;
   const int n0 = (bid % ntn) * BN;
+  const int cM = a.M[cls], cJX = a.JX[cls], cJY = a.JY[cls], cK = a.K[cls], cnt = a.ntaps[cls], toff = a.tap_off[cls];
+  const float cinv_jx = a.inv_jx[cls], cinv_jy = a.inv_jy[cls];
 
   if (tid < 64) {
     taps[tid] = a.dy[tid];
@@ -93,11 +107,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
 #pragma unroll
   for (int p = 0; p < A_PASS; ++p) {
     const int m = m0 + lrow + 32 * p;
-    if (m < a.M) {
-      const int t1 = fast_div(m, a.JX, a.inv_jx);
-      const int jx = m - t1 * a.JX;
-      const int ni = fast_div(t1, a.JY, a.inv_jy);
-      const int jy = t1 - ni * a.JY;
+    if (m < cM) {
+      const int t1 = fast_div(m, cJX, cinv_jx);
+      const int jx = m - t1 * cJX;
+      const int ni = fast_div(t1, cJY, cinv_jy);
+      const int jy = t1 - ni * cJY;
       a_base[p] = ni * a.hi * a.wi;
       a_iy[p] = jy * a.sy_i;
       a_ix[p] = jx * a.sx_i;
@@ -123,17 +137,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
       for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
 
   f32x4 ra[A_PASS], rb[B_PASS];
-  const int nkt = (a.K + BK - 1) / BK;
+  const int nkt = (cK + BK - 1) / BK;
 
   __syncthreads();  // tap table visible
 
   auto load_tile = [&](int kt) {
     const int kk = kt * BK + kq * 4;
-    const bool kvalid = kk < a.K;
+    const bool kvalid = kk < cK;
     int t = (int)(((float)kk + 0.5f) * a.inv_ci);
     const int c = kk - t * a.ci;
-    t = t < a.ntaps ? t : a.ntaps - 1;
-    t = t < 0 ? 0 : t;
+    t = t < cnt ? t : cnt - 1;
+    t = (t < 0 ? 0 : t) + toff;
     const int dyt = taps[t], dxt = taps[64 + t], wtt = taps[128 + t];
 #pragma unroll
     for (int p = 0; p < A_PASS; ++p) {
@@ -200,32 +214,37 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
   }
 
   // ---- epilogue: D[i][j] reg v of lane (lr, lh) = C[row = (v&3) + 8*(v>>2) + 4*lh][col = lr]
+  const int ccy = a.cy[cls], ccx = a.cx[cls];
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
       const int m = m0 + wm + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
-      if (m >= a.M) continue;
+      if (m >= cM) continue;
       size_t pix;
       if (a.dense_out) {
         pix = (size_t)m;
       } else {
-        const int t1 = fast_div(m, a.JX, a.inv_jx);
-        const int jx = m - t1 * a.JX;
-        const int ni = fast_div(t1, a.JY, a.inv_jy);
-        const int jy = t1 - ni * a.JY;
-        pix = ((size_t)ni * a.ho + (size_t)(a.cy + a.sy_o * jy)) * a.wo + (size_t)(a.cx + a.sx_o * jx);
+        const int t1 = fast_div(m, cJX, cinv_jx);
+        const int jx = m - t1 * cJX;
+        const int ni = fast_div(t1, cJY, cinv_jy);
+        const int jy = t1 - ni * cJY;
+        pix = ((size_t)ni * a.ho + (size_t)(ccy + a.sy_o * jy)) * a.wo + (size_t)(ccx + a.sx_o * jx);
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn + j * 32 + lr;
         if (n < a.co) {
-          float val = acc[i][j][v];
-          if (a.bias) val += a.bias[n];
-          val = act_apply(val, a.act, a.slope);
           float* dst = a.y + pix * (size_t)a.co + n;
-          if (a.accumulate) val += *dst;
-          *dst = val;
+          if (a.atomic_out) {
+            atomicAdd(dst, acc[i][j][v]);
+          } else {
+            float val = acc[i][j][v];
+            if (a.bias) val += a.bias[n];
+            val = act_apply(val, a.act, a.slope);
+            if (a.accumulate) val += *dst;
+            *dst = val;
+          }
         }
       }
     }
@@ -244,12 +263,21 @@ static int launch_cfg(const IgemmArgs& a, hipStream_t s) {
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv_igemm)");
     attr_done = true;
   }
-  const int mt = cdiv(a.M, BM), nt = cdiv(a.co, BN);
-  dim3 grid((unsigned)(mt * nt)), block(256);
+  IgemmArgs b = a;
+  const int nt = cdiv(a.co, BN);
+  double flops = 0.0;
+  b.tile_begin[0] = 0;
+  for (int c = 0; c < a.nclass; ++c) {
+    b.tile_begin[c + 1] = b.tile_begin[c] + cdiv(a.M[c], BM) * nt;
+    flops += 2.0 * (double)a.M[c] * a.co * a.K[c];
+  }
+  for (int c = a.nclass; c < NCLS; ++c) b.tile_begin[c + 1] = b.tile_begin[a.nclass];
+  if (b.tile_begin[a.nclass] == 0) return UDASEG_OK;
+  dim3 grid((unsigned)b.tile_begin[a.nclass]), block(256);
   constexpr int kid = (BM == 128 && BN == 128) ? 0 : (BM == 128 && BN == 64) ? 1 : (BM == 64) ? 2 : 3;
   hipEvent_t ev = kprof_begin(s);
-  hipLaunchKernelGGL(kern, grid, block, lds, s, a);
-  kprof_end(kid, ev, s, 2.0 * (double)a.M * a.co * a.K);
+  hipLaunchKernelGGL(kern, grid, block, lds, s, b);
+  kprof_end(kid, ev, s, flops);
   UDASEG_LAUNCH_CHECK("conv_igemm launch");
   return UDASEG_OK;
 }
@@ -265,8 +293,10 @@ static int tile_override() {
 }
 
 static int launch_igemm(const IgemmArgs& a, hipStream_t s) {
-  if (a.M <= 0) return UDASEG_OK;
-  const long long tiles128 = (long long)cdiv(a.M, 128);
+  long long rows = 0;
+  for (int c = 0; c < a.nclass; ++c) rows += a.M[c];
+  if (rows <= 0) return UDASEG_OK;
+  const long long tiles128 = (rows + 127) / 128;
   switch (tile_override()) {
     case 1: return launch_cfg<128, 128, 2, 2>(a, s);
     case 2: return launch_cfg<128, 64, 2, 2>(a, s);
@@ -274,8 +304,8 @@ static int launch_igemm(const IgemmArgs& a, hipStream_t s) {
     case 4: return launch_cfg<128, 32, 4, 1>(a, s);
     default: break;
   }
-  // tile choice: widest N tile the channel count fills; fall back to 64x64 when a 128-row tiling would
-  // leave most of the 256 CUs idle (deep, low-resolution layers).
+  // tile choice (measured per shape, profiles/r01_tile_ab.txt): 64x64 wins or ties whenever a 128-row tiling leaves
+  // fewer than ~1.5 blocks per CU; 128-wide tiles only for the big-M layers; 128x32 for <= 32 output channels.
   if (a.co > 64) {
     if (tiles128 * cdiv(a.co, 128) >= 384) return launch_cfg<128, 128, 2, 2>(a, s);
     return launch_cfg<64, 64, 2, 2>(a, s);
@@ -285,6 +315,29 @@ static int launch_igemm(const IgemmArgs& a, hipStream_t s) {
     return launch_cfg<64, 64, 2, 2>(a, s);
   }
   return launch_cfg<128, 32, 4, 1>(a, s);
+}
+
+// Common part of the launch description.
+static void base_args(IgemmArgs& a, const float* x, const float* w, const float* bias, float* y, int hi, int wi, int ci,
+                      int ho, int wo, int co, int tfull, int accumulate, int act, float slope) {
+  a.x = x; a.w = w; a.bias = bias; a.y = y;
+  a.hi = hi; a.wi = wi; a.ci = ci; a.ho = ho; a.wo = wo; a.co = co;
+  a.tfull = tfull; a.inv_ci = 1.0f / ci;
+  a.accumulate = accumulate; a.act = act; a.slope = slope;
+  a.atomic_out = 0; a.nclass = 0;
+}
+
+// Deep low-resolution layers have too few output tiles to fill 256 CUs (layer4 of r18 at 512^2: 256 tiles of 64x64):
+// split the taps of a single-class launch into K-slices that add into the output atomically.  Only for plain conv
+// outputs (no bias / activation) -- those are applied once, which a sliced sum cannot do.
+static int k_slices(int M, int co, int ntaps, bool plain) {
+  if (!plain || ntaps < 2) return 1;
+  const long long tiles = (long long)cdiv(M, 64) * cdiv(co, 64);
+  if (tiles >= 384) return 1;
+  int want = (int)((511 + tiles) / tiles);  // aim at >= 512 blocks
+  if (want > 2) want = 2;  // two adders onto a zeroed output commute exactly: the forward stays bitwise reproducible
+  if (want > ntaps) want = ntaps;
+  return want < 1 ? 1 : want;
 }
 
 static int check_desc(const udaseg_conv_desc* d) {
@@ -316,31 +369,41 @@ extern "C" int udaseg_conv2d_fwd(const udaseg_conv_desc* d, const float* x, cons
   int rc = check_desc(d);
   if (rc) return rc;
   UDASEG_CHECK_ARG(x && w && y, "conv2d_fwd: NULL pointer");
+  hipStream_t st = as_stream(stream);
   if (d->kh == d->kw && small_conv_applicable(d->kh, d->stride, d->pad, d->ci, d->co)) {
-    hipStream_t st = as_stream(stream);
     prof_begin(0, st);
     rc = launch_small_conv(x, w, bias, y, d->n, d->hi, d->wi, d->ci, d->co, 0, accumulate, act, slope, st);
     prof_end(0, st, udaseg_conv_flops(d), 0, d);
     return rc;
   }
   IgemmArgs a = {};
-  a.x = x; a.w = w; a.bias = bias; a.y = y;
-  a.hi = d->hi; a.wi = d->wi; a.ci = d->ci;
-  a.ho = d->ho; a.wo = d->wo; a.co = d->co;
-  a.JY = d->ho; a.JX = d->wo; a.M = d->n * d->ho * d->wo;
-  a.cy = 0; a.cx = 0; a.sy_o = 1; a.sx_o = 1; a.sy_i = d->stride; a.sx_i = d->stride;
-  a.ntaps = d->kh * d->kw; a.tfull = a.ntaps; a.K = a.ntaps * d->ci;
-  a.inv_ci = 1.0f / d->ci; a.inv_jx = 1.0f / a.JX; a.inv_jy = 1.0f / a.JY;
-  a.accumulate = accumulate; a.act = act; a.slope = slope; a.dense_out = 1;
+  const int ntaps = d->kh * d->kw;
+  base_args(a, x, w, bias, y, d->hi, d->wi, d->ci, d->ho, d->wo, d->co, ntaps, accumulate, act, slope);
+  a.sy_o = 1; a.sx_o = 1; a.sy_i = d->stride; a.sx_i = d->stride; a.dense_out = 1;
   for (int r = 0; r < d->kh; ++r)
-    for (int s = 0; s < d->kw; ++s) {
-      const int t = r * d->kw + s;
+    for (int q = 0; q < d->kw; ++q) {
+      const int t = r * d->kw + q;
       a.dy[t] = (signed char)(r - d->pad);
-      a.dx[t] = (signed char)(s - d->pad);
+      a.dx[t] = (signed char)(q - d->pad);
       a.wt[t] = (unsigned char)t;
     }
-  hipStream_t st = as_stream(stream);
+  const int M = d->n * d->ho * d->wo;
+  const int ns = k_slices(M, d->co, ntaps, bias == nullptr && act == UDASEG_ACT_NONE);
+  a.nclass = ns;
+  for (int c = 0; c < ns; ++c) {
+    const int t0 = (int)((long long)ntaps * c / ns), t1 = (int)((long long)ntaps * (c + 1) / ns);
+    a.JY[c] = d->ho; a.JX[c] = d->wo; a.M[c] = M; a.cy[c] = 0; a.cx[c] = 0;
+    a.ntaps[c] = t1 - t0; a.K[c] = (t1 - t0) * d->ci; a.tap_off[c] = t0;
+    a.inv_jx[c] = 1.0f / d->wo; a.inv_jy[c] = 1.0f / d->ho;
+  }
   prof_begin(0, st);
+  if (ns > 1) {
+    a.atomic_out = 1;
+    if (!accumulate) {
+      hipError_t e = hipMemsetAsync(y, 0, (size_t)M * d->co * sizeof(float), st);
+      if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(conv out)");
+    }
+  }
   rc = launch_igemm(a, st);
   prof_end(0, st, udaseg_conv_flops(d), 0, d);
   return rc;
@@ -360,37 +423,56 @@ extern "C" int udaseg_conv2d_dgrad(const udaseg_conv_desc* d, const float* dy, c
     prof_end(0, st, udaseg_conv_flops(d), 1, d);
     return rc;
   }
+  UDASEG_CHECK_ARG(s * s <= NCLS, "conv2d_dgrad: stride %d unsupported (at most %d parity classes)", s, NCLS);
+  IgemmArgs a = {};
+  // gathered operand: dy [n][ho][wo][co]; output: dx [n][hi][wi][ci]
+  base_args(a, dy, w_t, nullptr, dx, d->ho, d->wo, d->co, d->hi, d->wi, d->ci, d->kh * d->kw, accumulate, UDASEG_ACT_NONE, 0.f);
+  a.sy_o = s; a.sx_o = s; a.sy_i = 1; a.sx_i = 1; a.dense_out = (s == 1) ? 1 : 0;
+  int nc = 0, ntot = 0;
   for (int ph = 0; ph < s; ++ph)
     for (int pw = 0; pw < s; ++pw) {
-      IgemmArgs a = {};
-      a.x = dy; a.w = w_t; a.bias = nullptr; a.y = dx;
-      a.hi = d->ho; a.wi = d->wo; a.ci = d->co;   // gathered operand: dy
-      a.ho = d->hi; a.wo = d->wi; a.co = d->ci;   // output: dx
-      a.JY = (d->hi - ph + s - 1) / s;
-      a.JX = (d->wi - pw + s - 1) / s;
-      if (a.JY <= 0 || a.JX <= 0) continue;
-      a.M = d->n * a.JY * a.JX;
-      a.cy = ph; a.cx = pw; a.sy_o = s; a.sx_o = s; a.sy_i = 1; a.sx_i = 1;
-      int nt = 0;
+      const int JY = (d->hi - ph + s - 1) / s, JX = (d->wi - pw + s - 1) / s;
+      if (JY <= 0 || JX <= 0) continue;
+      const int t0 = ntot;
       for (int r = 0; r < d->kh; ++r) {
         if ((ph + d->pad - r) % s != 0) continue;
         for (int q = 0; q < d->kw; ++q) {
           if ((pw + d->pad - q) % s != 0) continue;
-          a.dy[nt] = (signed char)((ph + d->pad - r) / s);
-          a.dx[nt] = (signed char)((pw + d->pad - q) / s);
-          a.wt[nt] = (unsigned char)(r * d->kw + q);
-          ++nt;
+          a.dy[ntot] = (signed char)((ph + d->pad - r) / s);
+          a.dx[ntot] = (signed char)((pw + d->pad - q) / s);
+          a.wt[ntot] = (unsigned char)(r * d->kw + q);
+          ++ntot;
         }
       }
-      if (nt == 0 && accumulate) continue;  // nothing to add for this parity class
-      a.ntaps = nt; a.tfull = d->kh * d->kw; a.K = nt * d->co;
-      a.inv_ci = 1.0f / d->co; a.inv_jx = 1.0f / a.JX; a.inv_jy = 1.0f / a.JY;
-      a.accumulate = accumulate; a.act = UDASEG_ACT_NONE; a.slope = 0.f;
-      a.dense_out = (s == 1) ? 1 : 0;
-      rc = launch_igemm(a, st);
-      if (rc) return rc;
+      const int nt = ntot - t0;
+      if (nt == 0 && accumulate) continue;  // nothing to add for this parity class (with !accumulate it writes zeros)
+      a.JY[nc] = JY; a.JX[nc] = JX; a.M[nc] = d->n * JY * JX; a.cy[nc] = ph; a.cx[nc] = pw;
+      a.ntaps[nc] = nt; a.K[nc] = nt * d->co; a.tap_off[nc] = t0;
+      a.inv_jx[nc] = 1.0f / JX; a.inv_jy[nc] = 1.0f / JY;
+      ++nc;
     }
+  a.nclass = nc;
+  if (s == 1 && nc == 1) {
+    // single class: K-slices for the deep layers, as in the forward
+    const int ntaps = a.ntaps[0];
+    const int ns = k_slices(a.M[0], d->ci, ntaps, true);
+    if (ns > 1) {
+      for (int c = ns - 1; c >= 0; --c) {
+        const int t0 = (int)((long long)ntaps * c / ns), t1 = (int)((long long)ntaps * (c + 1) / ns);
+        a.JY[c] = a.JY[0]; a.JX[c] = a.JX[0]; a.M[c] = a.M[0]; a.cy[c] = 0; a.cx[c] = 0;
+        a.inv_jx[c] = a.inv_jx[0]; a.inv_jy[c] = a.inv_jy[0];
+        a.ntaps[c] = t1 - t0; a.K[c] = (t1 - t0) * d->co; a.tap_off[c] = t0;
+      }
+      a.nclass = ns;
+      a.atomic_out = 1;
+      if (!accumulate) {
+        hipError_t e = hipMemsetAsync(dx, 0, (size_t)d->n * d->hi * d->wi * d->ci * sizeof(float), st);
+        if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(dgrad out)");
+      }
+    }
+  }
+  rc = launch_igemm(a, st);
   // dgrad FLOPs equal the forward's (every (pixel, tap, ci, co) product appears once)
   prof_end(0, st, udaseg_conv_flops(d), 1, d);
-  return UDASEG_OK;
+  return rc;
 }

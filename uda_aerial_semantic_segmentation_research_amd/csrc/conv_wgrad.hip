@@ -226,6 +226,33 @@ __global__ void pack_dgrad_kernel(const float* __restrict__ w, float* __restrict
 }
 }  // namespace udaseg
 
+// All convolutions of a network in ONE launch: table[i] = {src offset, dst offset, co, taps, ci} (float offsets into the
+// parameter arena / the packed-weight scratch), blockIdx.y = table row.
+namespace udaseg {
+__global__ void pack_dgrad_batched_kernel(const float* __restrict__ arena, float* __restrict__ packed,
+                                          const int* __restrict__ table) {
+  const int* e = table + 5 * blockIdx.y;
+  const float* w = arena + e[0];
+  float* wt = packed + e[1];
+  const int co = e[2], T = e[3], ci = e[4];
+  const int total = co * T * ci;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int o = i % co;
+    const int r = i / co;
+    const int t = r % T;
+    const int c = r / T;
+    wt[i] = w[(o * T + t) * ci + c];
+  }
+}
+}  // namespace udaseg
+
+extern "C" int udaseg_pack_dgrad_batched(const float* arena, float* packed, const int* table, int entries, void* stream) {
+  UDASEG_CHECK_ARG(arena && packed && table && entries > 0, "pack_dgrad_batched: bad arguments");
+  hipLaunchKernelGGL(pack_dgrad_batched_kernel, dim3(64, entries), dim3(256), 0, as_stream(stream), arena, packed, table);
+  UDASEG_LAUNCH_CHECK("pack_dgrad_batched launch");
+  return UDASEG_OK;
+}
+
 extern "C" int udaseg_pack_dgrad_weights(const udaseg_conv_desc* d, const float* w, float* w_t, void* stream) {
   UDASEG_CHECK_ARG(d && w && w_t, "pack_dgrad_weights: NULL pointer");
   const long long total = (long long)d->co * d->kh * d->kw * d->ci;

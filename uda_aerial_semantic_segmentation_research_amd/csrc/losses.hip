@@ -62,10 +62,11 @@ __global__ void ce_finish_kernel(const double* __restrict__ partials, int n, int
   if (threadIdx.x == 0) *loss = (float)(s / (double)pixels);
 }
 
+// Generic fallback (ldc > 32): one thread per pixel, strided 16-B stores.
 template <int LDC4>
-__global__ __launch_bounds__(256) void ce_bwd_kernel(const f32x4* __restrict__ logits, const int64_t* __restrict__ target,
-                                                     const float* __restrict__ lse, const float* __restrict__ grad_out,
-                                                     int64_t pixels, int classes, f32x4* __restrict__ dlogits) {
+__global__ __launch_bounds__(256) void ce_bwd_simple_kernel(const f32x4* __restrict__ logits, const int64_t* __restrict__ target,
+                                                            const float* __restrict__ lse, const float* __restrict__ grad_out,
+                                                            int64_t pixels, int classes, f32x4* __restrict__ dlogits) {
   const float scale = (grad_out ? *grad_out : 1.f) / (float)pixels;
   const int64_t T = (int64_t)gridDim.x * blockDim.x;
   for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < pixels; p += T) {
@@ -78,13 +79,81 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const f32x4* __restrict__ l
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int c = k * 4 + e;
-        float d = 0.f;
-        if (c < classes) d = (expf(v[e] - l) - (c == t ? 1.f : 0.f)) * scale;
-        g[e] = d;
+        g[e] = c < classes ? (expf(v[e] - l) - (c == t ? 1.f : 0.f)) * scale : 0.f;
       }
       dlogits[p * LDC4 + k] = g;
     }
   }
+}
+
+// ldc <= 32: blocks walk 256-pixel chunks; gradients go through an LDS tile so the HBM stores are whole contiguous
+// lines (per-thread 96-B-strided 16-B stores ran at 1.7 TB/s), and the same tile yields the per-class column sums =
+// the segmentation head's bias gradient (saves a separate 200 MB pass).  colpart: [gridDim.x][LDC] or null.
+template <int LDC4>
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const f32x4* __restrict__ logits, const int64_t* __restrict__ target,
+                                                     const float* __restrict__ lse, const float* __restrict__ grad_out,
+                                                     int64_t pixels, int classes, f32x4* __restrict__ dlogits,
+                                                     float* __restrict__ colpart) {
+  constexpr int LDC = LDC4 * 4;
+  constexpr int NG = 256 / LDC;  // row groups for the column sums
+  __shared__ __attribute__((aligned(16))) float tile[256 * LDC];
+  __shared__ float colred[NG * LDC];
+  const int tid = threadIdx.x;
+  const float scale = (grad_out ? *grad_out : 1.f) / (float)pixels;
+  const int64_t nchunks = (pixels + 255) / 256;
+  const int cc = tid % LDC, rg = tid / LDC;
+  float colacc = 0.f;
+  for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    const int64_t p = chunk * 256 + tid;
+    if (p < pixels) {
+      const float l = lse[p];
+      const int t = (int)target[p];
+#pragma unroll
+      for (int k = 0; k < LDC4; ++k) {
+        const f32x4 v = logits[p * LDC4 + k];
+        f32x4 g;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c = k * 4 + e;
+          g[e] = c < classes ? (expf(v[e] - l) - (c == t ? 1.f : 0.f)) * scale : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(tile + tid * LDC + k * 4) = g;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < LDC4; ++k) *reinterpret_cast<f32x4*>(tile + tid * LDC + k * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+    const int64_t base4 = chunk * 256 * LDC4, lim4 = pixels * LDC4;
+#pragma unroll
+    for (int it = 0; it < LDC4; ++it) {
+      const int idx = it * 256 + tid;
+      if (base4 + idx < lim4) dlogits[base4 + idx] = reinterpret_cast<const f32x4*>(tile)[idx];
+    }
+    if (colpart && rg < NG) {
+      for (int r = rg; r < 256; r += NG) colacc += tile[r * LDC + cc];
+    }
+    __syncthreads();
+  }
+  if (colpart) {
+    if (rg < NG) colred[rg * LDC + cc] = colacc;
+    __syncthreads();
+    if (tid < LDC) {
+      float s = 0.f;
+      for (int g2 = 0; g2 < NG; ++g2) s += colred[g2 * LDC + tid];
+      colpart[(size_t)blockIdx.x * LDC + tid] = s;
+    }
+  }
+}
+
+// colsum[c] (+)= sum over blocks of colpart[b][c]; single block, deterministic
+__global__ void colsum_finish_kernel(const float* __restrict__ colpart, int nblocks, int ldc, float* __restrict__ colsum,
+                                     int accumulate) {
+  const int c = threadIdx.x;
+  if (c >= ldc) return;
+  float s = 0.f;
+  for (int b = 0; b < nblocks; ++b) s += colpart[(size_t)b * ldc + c];
+  colsum[c] = accumulate ? colsum[c] + s : s;
 }
 
 // ---- discriminator tail ---------------------------------------------------------------------------------------
@@ -221,18 +290,42 @@ extern "C" int udaseg_ce_fwd(const float* logits, const int64_t* target, int64_t
 }
 
 extern "C" int udaseg_ce_bwd(const float* logits, const int64_t* target, const float* lse, const float* grad_out,
-                             int64_t pixels, int classes, int ldc, float* dlogits, void* stream) {
+                             int64_t pixels, int classes, int ldc, float* dlogits, float* colsum_partials, float* colsum,
+                             void* stream) {
   UDASEG_CHECK_ARG(logits && target && lse && dlogits, "ce_bwd: NULL pointer");
   UDASEG_CHECK_ARG(pixels > 0 && classes > 0 && classes <= ldc && ldc % 4 == 0 && ldc <= CE_MAXC, "ce_bwd: bad shape");
+  UDASEG_CHECK_ARG((colsum == nullptr) == (colsum_partials == nullptr), "ce_bwd: colsum and colsum_partials come together");
+  UDASEG_CHECK_ARG(colsum == nullptr || ldc <= 32, "ce_bwd: fused column sums need ldc <= 32");
   hipStream_t st = as_stream(stream);
-  int grid = (int)((pixels + 255) / 256 > 4096 ? 4096 : (pixels + 255) / 256);
-#define CE_BWD_CASE(L)                                                                                                  \
-  case L:                                                                                                               \
+  if (ldc <= 32) {
+    const int64_t nchunks = (pixels + 255) / 256;
+    const int grid = (int)(nchunks > CE_BLOCKS ? CE_BLOCKS : nchunks);
+#define CE_BWD_CASE(L)                                                                                                   \
+  case L:                                                                                                                \
     hipLaunchKernelGGL(ce_bwd_kernel<L>, dim3(grid), dim3(256), 0, st, (const f32x4*)logits, target, lse, grad_out, pixels, \
-                       classes, (f32x4*)dlogits);                                                                       \
+                       classes, (f32x4*)dlogits, colsum_partials);                                                       \
+    break;
+    switch (ldc / 4) {
+      CE_BWD_CASE(1) CE_BWD_CASE(2) CE_BWD_CASE(3) CE_BWD_CASE(4) CE_BWD_CASE(5) CE_BWD_CASE(6) CE_BWD_CASE(7) CE_BWD_CASE(8)
+      default:
+        set_error("ce_bwd: unsupported ldc %d", ldc);
+        return UDASEG_E_UNSUPPORTED;
+    }
+#undef CE_BWD_CASE
+    UDASEG_LAUNCH_CHECK("ce_bwd launch");
+    if (colsum) {
+      hipLaunchKernelGGL(colsum_finish_kernel, dim3(1), dim3(64), 0, st, colsum_partials, grid, ldc, colsum, 0);
+      UDASEG_LAUNCH_CHECK("colsum_finish launch");
+    }
+    return UDASEG_OK;
+  }
+  int grid = (int)((pixels + 255) / 256 > 4096 ? 4096 : (pixels + 255) / 256);
+#define CE_BWD_CASE(L)                                                                                                   \
+  case L:                                                                                                                \
+    hipLaunchKernelGGL(ce_bwd_simple_kernel<L>, dim3(grid), dim3(256), 0, st, (const f32x4*)logits, target, lse, grad_out, \
+                       pixels, classes, (f32x4*)dlogits);                                                                \
     break;
   switch (ldc / 4) {
-    CE_BWD_CASE(1) CE_BWD_CASE(2) CE_BWD_CASE(3) CE_BWD_CASE(4) CE_BWD_CASE(5) CE_BWD_CASE(6) CE_BWD_CASE(7) CE_BWD_CASE(8)
     CE_BWD_CASE(9) CE_BWD_CASE(10) CE_BWD_CASE(11) CE_BWD_CASE(12) CE_BWD_CASE(13) CE_BWD_CASE(14) CE_BWD_CASE(15) CE_BWD_CASE(16)
     default:
       set_error("ce_bwd: unsupported ldc %d", ldc);

@@ -145,6 +145,11 @@ class ArenaModule(nn.Module):
                 self._wt_off[id(m)] = woff
                 woff += m.cout_p * m.k * m.k * m.cin_p
         self._wt_arena = torch.empty(max(woff, 4), device=device, dtype=torch.float32)
+        rows = []
+        for m in self.modules():
+            if isinstance(m, ConvP) and m.needs_dgrad:
+                rows.append([self._idx[(id(m), "weight")][0], self._wt_off[id(m)], m.cout_p, m.k * m.k, m.cin_p])
+        self._wt_table = torch.tensor(rows or [[0, 0, 0, 1, 0]], dtype=torch.int32, device=device)
         return self
 
     def _arena_ok(self, full=True):
@@ -303,21 +308,24 @@ class Plan:
         nbn = net._nbn
         self.bstats = torch.zeros(max(nbn, 2) * self.R, dtype=torch.float64, device=self.dev)
         self._bstat_off = 0
+        # dgrad needs the weights as [ci][taps][co]: one batched repack of the whole arena per backward
+        K.pack_dgrad_batched(net._arena, net._wt_arena, net._wt_table, self.st)
 
     def packed_wt(self, conv):
         o = self.net._wt_off[id(conv)]
         n = conv.cout_p * conv.k * conv.k * conv.cin_p
         return self.net._wt_arena[o:o + n]
 
-    def conv_bwd(self, conv, d, x, dy, dx=None, dx_acc=False):
-        """dW (+ dbias) into the grad arena; dx (+)= dgrad when dx is given."""
+    def conv_bwd(self, conv, d, x, dy, dx=None, dx_acc=False, dbias=None):
+        """dW (+ dbias) into the grad arena; dx (+)= dgrad when dx is given.  dbias: already-computed channel sums of dy."""
         K.conv2d_wgrad(d, x, dy, self.gw(conv), True, self.st)
         if conv.bias is not None:
-            K.channel_sum(dy, self.gvec(conv, "bias"), True, self.st)
+            if dbias is not None:
+                K.axpy(self.gvec(conv, "bias"), dbias, 1.0, self.st)
+            else:
+                K.channel_sum(dy, self.gvec(conv, "bias"), True, self.st)
         if dx is not None:
-            wt = self.packed_wt(conv)
-            K.pack_dgrad_weights(d, self.w(conv), wt, self.st)
-            K.conv2d_dgrad(d, dy, wt, dx, dx_acc, self.st)
+            K.conv2d_dgrad(d, dy, self.packed_wt(conv), dx, dx_acc, self.st)
 
     def bn_bwd(self, bn, y, z, ms, dz, act, slope, dres=None, dres_acc=False):
         """In place: dz becomes dy (grad w.r.t. the conv output).  dres (+)= masked grad for the residual branch."""

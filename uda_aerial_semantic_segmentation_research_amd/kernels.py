@@ -59,6 +59,11 @@ def pack_dgrad_weights(d, w, w_t, st=None):
                                                  st if st is not None else stream()), "pack_dgrad_weights")
 
 
+def pack_dgrad_batched(arena, packed, table, st=None):
+    check(_lib.load().udaseg_pack_dgrad_batched(arena.data_ptr(), packed.data_ptr(), table.data_ptr(), table.shape[0],
+                                                 st if st is not None else stream()), "pack_dgrad_batched")
+
+
 def conv_flops(d):
     return _lib.load().udaseg_conv_flops(_byref(d))
 
@@ -172,9 +177,10 @@ def ce_fwd(logits_base, target, pixels, classes, ldc, lse, partials, loss, st=No
                                      partials.data_ptr(), loss.data_ptr(), st if st is not None else stream()), "ce_fwd")
 
 
-def ce_bwd(logits_base, target, lse, grad_out, pixels, classes, ldc, dlogits, st=None):
+def ce_bwd(logits_base, target, lse, grad_out, pixels, classes, ldc, dlogits, colsum_partials=None, colsum=None, st=None):
     check(_lib.load().udaseg_ce_bwd(logits_base.data_ptr(), target.data_ptr(), lse.data_ptr(), _ptr(grad_out), pixels, classes,
-                                     ldc, dlogits.data_ptr(), st if st is not None else stream()), "ce_bwd")
+                                     ldc, dlogits.data_ptr(), _ptr(colsum_partials), _ptr(colsum),
+                                     st if st is not None else stream()), "ce_bwd")
 
 
 def gap_linear_sigmoid_fwd(z, w, b, st=None):

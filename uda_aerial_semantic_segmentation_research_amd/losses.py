@@ -13,6 +13,10 @@ from ._lib import load as _load
 from .engine import ceil4
 
 
+# data_ptr of the last dlogits buffer -> its per-class column sums (consumed once by Unet._backward_plan)
+COLSUM_SIDE_TABLE = {}
+
+
 def _padded_nhwc(logits):
     """[N,C,H,W] logits -> (tensor whose storage is the padded NHWC buffer [N,H,W,ldc], ldc).  Zero-copy when the
     logits come from ``Unet.forward``; otherwise one layout kernel."""
@@ -47,8 +51,18 @@ class _CrossEntropyFunction(torch.autograd.Function):
         n, c, h, w, ldc = ctx.meta
         dl = torch.empty((n, h, w, ldc), device=buf.device, dtype=torch.float32)
         g = grad_out.detach().to(torch.float32).contiguous()
-        K.ce_bwd(buf, tgt, lse, g, n * h * w, c, ldc, dl)
-        return dl.permute(0, 3, 1, 2)[:, :c], None
+        out = dl.permute(0, 3, 1, 2)[:, :c]
+        if ldc <= 32:
+            # per-class sums of the gradient come out of the same pass: the head conv's bias gradient (Unet's backward
+            # plan picks it up from the side table instead of re-reading the 200 MB gradient)
+            parts = torch.empty(_load().udaseg_ce_partials() * ldc, device=buf.device, dtype=torch.float32)
+            colsum = torch.empty(ldc, device=buf.device, dtype=torch.float32)
+            K.ce_bwd(buf, tgt, lse, g, n * h * w, c, ldc, dl, parts, colsum)
+            COLSUM_SIDE_TABLE.clear()
+            COLSUM_SIDE_TABLE[dl.data_ptr()] = colsum
+        else:
+            K.ce_bwd(buf, tgt, lse, g, n * h * w, c, ldc, dl)
+        return out, None
 
 
 class CrossEntropyLoss(nn.Module):

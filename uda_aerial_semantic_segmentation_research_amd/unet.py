@@ -285,7 +285,9 @@ class Unet(ArenaModule):
             dl = torch.zeros((n, hh, ww, cp), device=dlogits.device, dtype=torch.float32)
             dl.permute(0, 3, 1, 2)[:, : self.classes].copy_(dlogits)
         dh, _ = G.slot(h_last)
-        P.conv_bwd(head, d_head, h_last, dl, dx=dh, dx_acc=False)
+        from .losses import COLSUM_SIDE_TABLE
+        dbias = COLSUM_SIDE_TABLE.pop(dl.data_ptr(), None)     # made by ce_bwd in the same pass as dl, when it was
+        P.conv_bwd(head, d_head, h_last, dl, dx=dh, dx_acc=False, dbias=dbias)
         hook = self.grad_ready_hook
         if hook is not None:
             hook(P, P.offset_of(head))
