@@ -10,6 +10,10 @@
 // grid.x = (co tiles) * (j tiles), grid.y = K splits; each block reduces its pixel range in registers and
 // adds its tile to dW with global_atomic_add_f32 (one 128-B row segment per half-wave = full atomic rate),
 // or stores directly when there is a single split.
+//
+// Measured (profiles/r01_pmc_traffic.json): the L2 fetches 4-5x the algorithmic bytes here, because the tap tiles of one
+// pixel slab are dealt round-robin to the 8 XCD L2s.  An XCD-aware remap that keeps a slab's tiles on one L2 was tried
+// and ran 5 % SLOWER (80 -> 76 TFLOP/s): the re-fetches are served by the Infinity Cache and do not bound the kernel.
 #include "common.h"
 
 namespace udaseg {
