@@ -55,6 +55,10 @@ typedef struct {
 /* y[n,ho,wo,co] (+)= conv(x, w) + bias, then optional activation. bias may be NULL. */
 int udaseg_conv2d_fwd(const udaseg_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
                       int act, float slope, int accumulate, void* stream);
+/* y = conv(x, w) + bias AND the training-mode BatchNorm statistics of y in the same pass: stats[R][2][co] f64 (sum, sum of
+ * squares; R = udaseg_bn_replicas(), caller-zeroed) -- exactly what udaseg_bn_stats(y) would add, without re-reading y. */
+int udaseg_conv2d_fwd_bnstats(const udaseg_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
+                              double* stats, void* stream);
 /* dx[n,hi,wi,ci] (+)= conv_transpose(dy, w).  w_t is the dgrad packing [ci][kh][kw][co] made by
  * udaseg_pack_dgrad_weights.  Autograd of the convs above: loss.backward() at train.py:343. */
 int udaseg_conv2d_dgrad(const udaseg_conv_desc* d, const float* dy, const float* w_t, float* dx, int accumulate,

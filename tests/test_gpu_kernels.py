@@ -121,6 +121,30 @@ def test_conv_fwd_dgrad_wgrad(K, case):
     assert_close(dw2.cpu().permute(0, 3, 1, 2), wr.grad + 0.5, "wgrad+acc")
 
 
+@pytest.mark.parametrize("case", [(2, 24, 24, 64, 64, 3, 1, 1), (2, 20, 36, 16, 16, 3, 1, 1), (4, 40, 40, 32, 16, 3, 1, 1),
+                                  (1, 8, 8, 256, 256, 3, 1, 1), (2, 32, 32, 4, 64, 4, 2, 1), (8, 96, 96, 64, 128, 3, 1, 1)])
+def test_conv_fwd_with_fused_bn_statistics(K, case):
+    """conv epilogue statistics == what the separate bn_stats pass adds (igemm, small-channel and K-sliced paths)."""
+    n, h, w, ci, co, k, s, p = case
+    g = torch.Generator().manual_seed(ci * co)
+    x = torch.randn(n, h, w, ci, generator=g).cuda()
+    wt = (torch.randn(co, k, k, ci, generator=g) / math.sqrt(ci * k * k)).cuda()
+    bias = torch.randn(co, generator=g).cuda()
+    d = K.conv_desc(n, h, w, ci, co, k, s, p)
+    R = K.bn_replicas()
+    for b in (None, bias):
+        y = torch.empty((n, d.ho, d.wo, co), device="cuda")
+        st = torch.zeros(R * 2 * co, dtype=torch.float64, device="cuda")
+        K.conv2d_fwd_bnstats(d, x, wt, b, y, st)
+        y2 = torch.empty_like(y)
+        K.conv2d_fwd(d, x, wt, b, y2)
+        assert torch.equal(y, y2) or relerr(y.cpu(), y2.cpu()) < 1e-6
+        tot = st.view(R, 2, co).sum(0).cpu()
+        yd = y.double().reshape(-1, co).cpu()
+        assert_close(tot[0], yd.sum(0), "fused sum", 1e-5)
+        assert_close(tot[1], (yd * yd).sum(0), "fused sum of squares", 1e-5)
+
+
 def test_conv_identity_weights_asymmetric(K):
     """A = I check with an asymmetric operand: catches a transposed C-write or a swapped fragment map."""
     n, h, w, c = 1, 8, 8, 64

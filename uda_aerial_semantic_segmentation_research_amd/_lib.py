@@ -30,6 +30,7 @@ SIGNATURES = {
     "udaseg_last_error": (C.c_char_p, []),
     "udaseg_device_count": (_I, []),
     "udaseg_conv2d_fwd": (_I, [_D, _P, _P, _P, _P, _I, _F, _I, _P]),
+    "udaseg_conv2d_fwd_bnstats": (_I, [_D, _P, _P, _P, _P, _P, _P]),
     "udaseg_conv2d_dgrad": (_I, [_D, _P, _P, _P, _I, _P]),
     "udaseg_conv2d_wgrad": (_I, [_D, _P, _P, _P, _I, _P]),
     "udaseg_pack_dgrad_weights": (_I, [_D, _P, _P, _P]),

@@ -40,6 +40,7 @@ struct IgemmArgs {
   int accumulate, act;
   float slope;
   int dense_out;
+  double* stats;    // BN statistics of the output: [R][2][co] f64 accumulators (sum, sum of squares), or null
   int atomic_out;   // K-slices of one output: epilogue adds with global_atomic_add_f32 (output pre-zeroed or accumulated)
   int nclass;
   // per class
@@ -52,6 +53,7 @@ struct IgemmArgs {
   unsigned char wt[64];
 };
 
+constexpr int STATS_REPLICAS = 16;  // == udaseg_bn_replicas() (norm_act.hip)
 constexpr int BK = 32;
 constexpr int LDS_LD = BK + 4;
 
@@ -215,6 +217,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
 
   // ---- epilogue: D[i][j] reg v of lane (lr, lh) = C[row = (v&3) + 8*(v>>2) + 4*lh][col = lr]
   const int ccy = a.cy[cls], ccx = a.cx[cls];
+  float ssum[TN], ssq[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) ssum[j] = ssq[j] = 0.f;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -241,12 +246,42 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
           } else {
             float val = acc[i][j][v];
             if (a.bias) val += a.bias[n];
+            ssum[j] += val;            // BN statistics see the conv output (bias included), before any activation
+            ssq[j] += val * val;
             val = act_apply(val, a.act, a.slope);
             if (a.accumulate) val += *dst;
             *dst = val;
           }
         }
       }
+    }
+  }
+  if (a.stats) {
+    // fold the two half-waves (same column), then the WAVES_M waves that share a column through LDS (the K loop is
+    // over: its tiles are free), then one f64 atomic per (column, statistic) per block into replica blockIdx % R.
+    float* red = As;  // [2][4 waves][TN][32]
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const float s1 = ssum[j] + __shfl_xor(ssum[j], 32, 64), s2 = ssq[j] + __shfl_xor(ssq[j], 32, 64);
+      if (lh == 0) {
+        red[(wave * TN + j) * 32 + lr] = s1;
+        red[4 * TN * 32 + (wave * TN + j) * 32 + lr] = s2;
+      }
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < a.co) {
+      const int wc = tid / WN, jj = (tid % WN) / 32, l = tid % 32;  // wave column, tile, lane of this output column
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int wr = 0; wr < WAVES_M; ++wr) {
+        const int w = wr * WAVES_N + wc;
+        s1 += red[(w * TN + jj) * 32 + l];
+        s2 += red[4 * TN * 32 + (w * TN + jj) * 32 + l];
+      }
+      double* rep = a.stats + (size_t)(blockIdx.x % STATS_REPLICAS) * 2 * a.co;
+      atomicAdd(rep + n0 + tid, (double)s1);
+      atomicAdd(rep + a.co + n0 + tid, (double)s2);
     }
   }
 }
@@ -364,15 +399,15 @@ extern "C" double udaseg_conv_flops(const udaseg_conv_desc* d) {
   return 2.0 * (double)d->n * d->ho * d->wo * (double)d->co * (double)d->ci * d->kh * d->kw;
 }
 
-extern "C" int udaseg_conv2d_fwd(const udaseg_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
-                                 int act, float slope, int accumulate, void* stream) {
+static int conv2d_fwd_impl(const udaseg_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
+                           int act, float slope, int accumulate, double* stats, void* stream) {
   int rc = check_desc(d);
   if (rc) return rc;
   UDASEG_CHECK_ARG(x && w && y, "conv2d_fwd: NULL pointer");
   hipStream_t st = as_stream(stream);
   if (d->kh == d->kw && small_conv_applicable(d->kh, d->stride, d->pad, d->ci, d->co)) {
     prof_begin(0, st);
-    rc = launch_small_conv(x, w, bias, y, d->n, d->hi, d->wi, d->ci, d->co, 0, accumulate, act, slope, st);
+    rc = launch_small_conv(x, w, bias, y, d->n, d->hi, d->wi, d->ci, d->co, 0, accumulate, act, slope, stats, st);
     prof_end(0, st, udaseg_conv_flops(d), 0, d);
     return rc;
   }
@@ -389,6 +424,7 @@ extern "C" int udaseg_conv2d_fwd(const udaseg_conv_desc* d, const float* x, cons
     }
   const int M = d->n * d->ho * d->wo;
   const int ns = k_slices(M, d->co, ntaps, bias == nullptr && act == UDASEG_ACT_NONE);
+  a.stats = (ns == 1) ? stats : nullptr;  // squares of partial sums do not add up: sliced launches take the separate pass
   a.nclass = ns;
   for (int c = 0; c < ns; ++c) {
     const int t0 = (int)((long long)ntaps * c / ns), t1 = (int)((long long)ntaps * (c + 1) / ns);
@@ -406,7 +442,19 @@ extern "C" int udaseg_conv2d_fwd(const udaseg_conv_desc* d, const float* x, cons
   }
   rc = launch_igemm(a, st);
   prof_end(0, st, udaseg_conv_flops(d), 0, d);
+  if (rc == UDASEG_OK && stats && ns > 1) rc = udaseg_bn_stats(y, (int64_t)M, d->co, stats, stream);
   return rc;
+}
+
+extern "C" int udaseg_conv2d_fwd(const udaseg_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
+                                 int act, float slope, int accumulate, void* stream) {
+  return conv2d_fwd_impl(d, x, w, bias, y, act, slope, accumulate, nullptr, stream);
+}
+
+extern "C" int udaseg_conv2d_fwd_bnstats(const udaseg_conv_desc* d, const float* x, const float* w, const float* bias,
+                                         float* y, double* stats, void* stream) {
+  UDASEG_CHECK_ARG(stats != nullptr, "conv2d_fwd_bnstats: stats is NULL");
+  return conv2d_fwd_impl(d, x, w, bias, y, UDASEG_ACT_NONE, 0.f, 0, stats, stream);
 }
 
 extern "C" int udaseg_conv2d_dgrad(const udaseg_conv_desc* d, const float* dy, const float* w_t, float* dx,
@@ -419,7 +467,8 @@ extern "C" int udaseg_conv2d_dgrad(const udaseg_conv_desc* d, const float* dy, c
   prof_begin(0, st);
   if (d->kh == d->kw && small_conv_applicable(d->kh, d->stride, d->pad, d->co, d->ci)) {
     // dx = correlation of dy with the flipped taps; w_t is already [ci][9][co]
-    rc = launch_small_conv(dy, w_t, nullptr, dx, d->n, d->hi, d->wi, d->co, d->ci, 1, accumulate, UDASEG_ACT_NONE, 0.f, st);
+    rc = launch_small_conv(dy, w_t, nullptr, dx, d->n, d->hi, d->wi, d->co, d->ci, 1, accumulate, UDASEG_ACT_NONE, 0.f, nullptr,
+                           st);
     prof_end(0, st, udaseg_conv_flops(d), 1, d);
     return rc;
   }

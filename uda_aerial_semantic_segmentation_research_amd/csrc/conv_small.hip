@@ -27,6 +27,7 @@ struct SmallArgs {
   const float* bias;  // [co] or null
   float* y;           // [n][h][w][co]
   int n, h, wd, ci, co;
+  double* stats;      // BN statistics of the output, [R][2][co] f64 accumulators, or null
   int flip;           // 0: tap (r,s) reads (y+r-1, x+s-1) (forward); 1: (y+1-r, x+1-s) (data gradient)
   int accumulate, act;
   float slope;
@@ -128,6 +129,10 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(const SmallArgs a) {
 #pragma unroll
   for (int ct = 0; ct < CO_T; ++ct) bias[ct] = (a.bias && 16 * ct + li < a.co) ? a.bias[16 * ct + li] : 0.f;
 
+  float ssum[CO_T], ssq[CO_T];   // BN statistics of this lane's channel, running over all of the block's tiles
+#pragma unroll
+  for (int ct = 0; ct < CO_T; ++ct) ssum[ct] = ssq[ct] = 0.f;
+
   HaloRegs<CIP> stage;
   int tile = blockIdx.x;
   if (tile < a.ntiles) {
@@ -187,12 +192,44 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(const SmallArgs a) {
         for (int ct = 0; ct < CO_T; ++ct) {
           const int co = 16 * ct + li;
           if (co < a.co) {
-            float val = act_apply(acc[r][ct][v] + bias[ct], a.act, a.slope);
+            float val = acc[r][ct][v] + bias[ct];
+            ssum[ct] += val;
+            ssq[ct] += val * val;
+            val = act_apply(val, a.act, a.slope);
             if (a.accumulate) val += dst[co];
             dst[co] = val;
           }
         }
       }
+    }
+  }
+  if (a.stats) {
+    // lanes li, li+16, li+32, li+48 hold the same channel: fold them, then the 4 waves through LDS, then one f64 atomic
+    // per (channel, statistic) per block
+    __syncthreads();
+#pragma unroll
+    for (int ct = 0; ct < CO_T; ++ct) {
+      float s1 = ssum[ct], s2 = ssq[ct];
+      s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+      s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+      if (kq == 0) {
+        halo[(wave * CO_T + ct) * 16 + li] = s1;
+        halo[4 * CO_T * 16 + (wave * CO_T + ct) * 16 + li] = s2;
+      }
+    }
+    __syncthreads();
+    const int tid = threadIdx.x;
+    if (tid < 16 * CO_T && tid < a.co) {
+      const int ct = tid / 16, l = tid % 16;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        s1 += halo[(w * CO_T + ct) * 16 + l];
+        s2 += halo[4 * CO_T * 16 + (w * CO_T + ct) * 16 + l];
+      }
+      double* rep = a.stats + (size_t)(blockIdx.x % 16) * 2 * a.co;
+      atomicAdd(rep + tid, (double)s1);
+      atomicAdd(rep + a.co + tid, (double)s2);
     }
   }
 }
@@ -328,9 +365,9 @@ bool small_conv_applicable(int k, int stride, int pad, int ci_gather, int co_out
 }
 
 int launch_small_conv(const float* x, const float* w, const float* bias, float* y, int n, int h, int wd, int ci, int co,
-                      int flip, int accumulate, int act, float slope, hipStream_t s) {
+                      int flip, int accumulate, int act, float slope, double* stats, hipStream_t s) {
   SmallArgs a = {};
-  a.x = x; a.w = w; a.bias = bias; a.y = y;
+  a.x = x; a.w = w; a.bias = bias; a.y = y; a.stats = stats;
   a.n = n; a.h = h; a.wd = wd; a.ci = ci; a.co = co;
   a.flip = flip; a.accumulate = accumulate; a.act = act; a.slope = slope;
   a.tiles_x = cdiv(wd, ST); a.tiles_y = cdiv(h, ST); a.ntiles = n * a.tiles_x * a.tiles_y;

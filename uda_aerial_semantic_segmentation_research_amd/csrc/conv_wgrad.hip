@@ -14,6 +14,8 @@
 // Measured (profiles/r01_pmc_traffic.json): the L2 fetches 4-5x the algorithmic bytes here, because the tap tiles of one
 // pixel slab are dealt round-robin to the 8 XCD L2s.  An XCD-aware remap that keeps a slab's tiles on one L2 was tried
 // and ran 5 % SLOWER (80 -> 76 TFLOP/s): the re-fetches are served by the Infinity Cache and do not bound the kernel.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace udaseg {
@@ -164,8 +166,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 template <int BMW, int BNW, int WAVES_M, int WAVES_N>
 static int launch_wgrad(WgradArgs a, int accumulate, hipStream_t s) {
   const int tiles = cdiv(a.co, BMW) * cdiv(a.J, BNW);
-  // enough blocks for ~4 per CU, at least 256 pixels per split
-  int splits = cdiv(1024, tiles);
+  // enough blocks for ~4 per CU, at least 256 pixels per split (UDASEG_WGRAD_BLOCKS: tuning aid)
+  static int target = -1;
+  if (target < 0) {
+    const char* e = getenv("UDASEG_WGRAD_BLOCKS");
+    target = e ? atoi(e) : 3072;  // measured sweep 512..8192: 68.7 / 79.4 / 80.3 / 85.9 / 87.0 / 89.1 / 88.8 / 88.1 TFLOP/s
+    if (target < 64) target = 3072;
+  }
+  int splits = cdiv(target, tiles);
   const int max_splits = cdiv(a.M, 256);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;

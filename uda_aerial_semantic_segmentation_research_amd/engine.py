@@ -277,26 +277,42 @@ class Plan:
         K.conv2d_fwd(d, x, self.w(conv), self.b(conv) if conv.bias is not None else None, y, act, slope, False, self.st)
         return y, d
 
-    def bn(self, bn, y, act, slope, residual=None):
+    def bn(self, bn, y, act, slope, residual=None, sums=None):
+        """sums: this BN's statistic accumulators already filled by the producing conv's epilogue (else a stats pass)."""
         c = ceil4(bn.c)
         z = torch.empty_like(y)
         gamma, beta = self.pvec(bn, "weight"), self.pvec(bn, "bias")
         if self.training:
-            o = self._stat_off
-            self._stat_off += 2 * c
-            sums = self.stats[o * self.R:(o + 2 * c) * self.R]
+            if sums is None:
+                sums, o = self._next_stats(c)
+                K.bn_stats(y, sums, self.st)
+            else:
+                sums, o = sums
             mean, rstd = self.saved_stats[o:o + c], self.saved_stats[o + c:o + 2 * c]
-            K.bn_stats(y, sums, self.st)
             K.bn_apply(y, sums, gamma, beta, residual, z, bn.eps, bn.momentum, bn.running_mean, bn.running_var, mean, rstd,
                        act, slope, self.st)
             return z, (mean, rstd)
         K.bn_apply_eval(y, gamma, beta, bn.running_mean, bn.running_var, residual, z, bn.eps, act, slope, self.st)
         return z, None
 
+    def _next_stats(self, c):
+        o = self._stat_off
+        self._stat_off += 2 * c
+        return self.stats[o * self.R:(o + 2 * c) * self.R], o
+
     def conv_bn_act(self, conv, bn, x, act=ACT_LEAKY, slope=0.0, residual=None):
-        """z = act(bn(conv(x)) (+ residual)); returns (z, record for backward)."""
-        y, d = self.conv(conv, x)
-        z, ms = self.bn(bn, y, act, slope, residual)
+        """z = act(bn(conv(x)) (+ residual)); returns (z, record for backward).  In training the conv's epilogue also
+        accumulates the BN statistics of its output (no separate pass over y)."""
+        if self.training:
+            n, h, w, ci = x.shape
+            d = K.conv_desc(n, h, w, ci, conv.cout_p, conv.k, conv.stride, conv.pad)
+            y = torch.empty((n, d.ho, d.wo, conv.cout_p), device=x.device, dtype=torch.float32)
+            sums = self._next_stats(ceil4(bn.c))
+            K.conv2d_fwd_bnstats(d, x, self.w(conv), self.b(conv) if conv.bias is not None else None, y, sums[0], self.st)
+            z, ms = self.bn(bn, y, act, slope, residual, sums)
+        else:
+            y, d = self.conv(conv, x)
+            z, ms = self.bn(bn, y, act, slope, residual)
         rec = (conv, bn, d, x, y, z, ms, act, slope) if self.save else None
         return z, rec
 

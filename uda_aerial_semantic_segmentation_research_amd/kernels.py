@@ -44,6 +44,11 @@ def conv2d_fwd(d, x, w, bias, y, act=ACT_NONE, slope=0.0, accumulate=False, st=N
                                          int(accumulate), st if st is not None else stream()), "conv2d_fwd")
 
 
+def conv2d_fwd_bnstats(d, x, w, bias, y, stats, st=None):
+    check(_lib.load().udaseg_conv2d_fwd_bnstats(_byref(d), x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(),
+                                                 stats.data_ptr(), st if st is not None else stream()), "conv2d_fwd_bnstats")
+
+
 def conv2d_dgrad(d, dy, w_t, dx, accumulate=False, st=None):
     check(_lib.load().udaseg_conv2d_dgrad(_byref(d), dy.data_ptr(), w_t.data_ptr(), dx.data_ptr(), int(accumulate),
                                            st if st is not None else stream()), "conv2d_dgrad")
