@@ -59,6 +59,10 @@ int udaseg_conv2d_fwd(const udaseg_conv_desc* d, const float* x, const float* w,
  * squares; R = udaseg_bn_replicas(), caller-zeroed) -- exactly what udaseg_bn_stats(y) would add, without re-reading y. */
 int udaseg_conv2d_fwd_bnstats(const udaseg_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
                               double* stats, void* stream);
+/* Inference form: y = act(conv(x, w) + bias + residual) in one kernel (bias, residual optional).  With udaseg_bn_fold this
+ * is the whole conv+BN(+add)+ReLU block of an eval-mode forward (reference validate(): src/models/train.py:391-438). */
+int udaseg_conv2d_fwd_fused(const udaseg_conv_desc* d, const float* x, const float* w, const float* bias,
+                            const float* residual, float* y, int act, float slope, void* stream);
 /* dx[n,hi,wi,ci] (+)= conv_transpose(dy, w).  w_t is the dgrad packing [ci][kh][kw][co] made by
  * udaseg_pack_dgrad_weights.  Autograd of the convs above: loss.backward() at train.py:343. */
 int udaseg_conv2d_dgrad(const udaseg_conv_desc* d, const float* dy, const float* w_t, float* dx, int accumulate,
@@ -93,6 +97,10 @@ int udaseg_bn_apply(const float* y, const double* sums, const float* gamma, cons
 int udaseg_bn_apply_eval(const float* y, const float* gamma, const float* beta, const float* running_mean,
                          const float* running_var, const float* residual, float* z, int64_t pixels, int c, float eps,
                          int act, float slope, void* stream);
+/* eval mode, folded into the preceding conv: w_folded[co][row_len] = w * gamma/sqrt(var+eps);
+ * bias_folded[co] = beta + (bias - mean) * gamma/sqrt(var+eps).  bias may be NULL. */
+int udaseg_bn_fold(const float* w, const float* bias, const float* gamma, const float* beta, const float* running_mean,
+                   const float* running_var, float eps, int co, int row_len, float* w_folded, float* bias_folded, void* stream);
 /* backward, pass 1: g = dz * act'(z); bsums[0][c] += sum g, bsums[1][c] += sum g*xhat (doubles, caller-zeroed) */
 int udaseg_bn_bwd_reduce(const float* dz, const float* z, const float* y, const float* save_mean,
                          const float* save_rstd, int64_t pixels, int c, double* bsums, int act, float slope,
@@ -132,6 +140,12 @@ int udaseg_ce_fwd(const float* logits, const int64_t* target, int64_t pixels, in
  * src/models/train.py:343), produced in the same pass; colsum_partials = scratch of udaseg_ce_partials()*ldc floats. */
 int udaseg_ce_bwd(const float* logits, const int64_t* target, const float* lse, const float* grad_out, int64_t pixels,
                   int classes, int ldc, float* dlogits, float* colsum_partials, float* colsum, void* stream);
+
+/* ---- validation metrics (SegmentationTrainer.calculate_metrics, train.py:225-243; src/analysis/metrics.py:17-29):
+ * confusion[t*classes + argmax(logits[p])] += 1 over all pixels (int64, caller-zeroed); pred[p] = argmax (optional).
+ * classes <= 32, ldc <= 32. */
+int udaseg_argmax_confusion(const float* logits, const int64_t* target, int64_t pixels, int classes, int ldc,
+                            int64_t* confusion, int64_t* pred, void* stream);
 
 /* ---- discriminator tail + adversarial BCE: discriminator.py:37-42, losses.py:18-51 ---- */
 /* pooled[n][c] = mean over hw of z; p[n] = sigmoid(dot(pooled[n], w) + b).  partial: [n][splits][c] floats */

@@ -404,3 +404,51 @@ def test_bad_arguments_raise(K):
     t = torch.empty(1024, device="cuda")
     with pytest.raises(RuntimeError, match="multiples of 4"):
         K.conv2d_fwd(d, t, t, None, t)
+
+
+def test_argmax_confusion_matrix(K):
+    g = torch.Generator().manual_seed(21)
+    n, c, h, w, ldc = 3, 23, 17, 19, 24
+    logits = torch.randn(n, c, h, w, generator=g)
+    logits[0, 5, :, :4] = logits[0, 2, :, :4] = 9.0            # exact ties: first maximal index wins (torch.argmax)
+    tgt = torch.randint(0, c, (n, h, w), generator=g)
+    buf = torch.full((n, h, w, ldc), 50.0, device="cuda")       # pad channel holds a LARGER value: must be ignored
+    buf[..., :c] = logits.permute(0, 2, 3, 1).cuda()
+    cm = torch.zeros(c * c, dtype=torch.int64, device="cuda")
+    pred = torch.empty(n * h * w, dtype=torch.int64, device="cuda")
+    K.argmax_confusion(buf, tgt.cuda().reshape(-1), n * h * w, c, ldc, cm, pred)
+    pr = logits.argmax(dim=1)
+    assert torch.equal(pred.cpu().view(n, h, w), pr)
+    ref = torch.bincount((tgt * c + pr).reshape(-1), minlength=c * c)     # src/analysis/metrics.py:17-29
+    assert torch.equal(cm.cpu(), ref)
+
+
+def test_bn_fold_and_fused_inference_conv(K):
+    g = torch.Generator().manual_seed(22)
+    n, h, w, ci, co = 2, 12, 14, 64, 128
+    x = torch.randn(n, ci, h, w, generator=g)
+    res = torch.randn(n, co, h, w, generator=g)
+    conv = torch.nn.Conv2d(ci, co, 3, padding=1, bias=True)
+    bn = torch.nn.BatchNorm2d(co).eval()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(co, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(co, generator=g))
+        bn.running_mean.copy_(torch.randn(co, generator=g))
+        bn.running_var.copy_(torch.rand(co, generator=g) + 0.5)
+        ref = F.relu(bn(conv(x)) + res)
+    wd = w_ohwi(conv.weight.detach())
+    wf, bf = torch.empty_like(wd), torch.empty(co, device="cuda")
+    K.bn_fold(wd, dev(conv.bias.detach()), dev(bn.weight.detach()), dev(bn.bias.detach()), dev(bn.running_mean),
+              dev(bn.running_var), bn.eps, wf, bf)
+    d = K.conv_desc(n, h, w, ci, co, 3, 1, 1)
+    y = torch.empty((n, h, w, co), device="cuda")
+    K.conv2d_fwd_fused(d, nhwc(x), wf, bf, nhwc(res), y, act=1, slope=0.0)
+    assert_close(nchw(y), ref, "folded conv+bn+add+relu", 1e-4)
+    # small-channel direct kernel path with residual
+    conv2 = torch.nn.Conv2d(16, 16, 3, padding=1, bias=False)
+    x2, r2 = torch.randn(1, 16, 20, 20, generator=g), torch.randn(1, 16, 20, 20, generator=g)
+    d2 = K.conv_desc(1, 20, 20, 16, 16, 3, 1, 1)
+    y2 = torch.empty((1, 20, 20, 16), device="cuda")
+    K.conv2d_fwd_fused(d2, nhwc(x2), w_ohwi(conv2.weight.detach()), None, nhwc(r2), y2, act=1, slope=0.1)
+    with torch.no_grad():
+        assert_close(nchw(y2), F.leaky_relu(conv2(x2) + r2, 0.1), "small conv + residual + leaky", 1e-4)

@@ -31,6 +31,7 @@ SIGNATURES = {
     "udaseg_device_count": (_I, []),
     "udaseg_conv2d_fwd": (_I, [_D, _P, _P, _P, _P, _I, _F, _I, _P]),
     "udaseg_conv2d_fwd_bnstats": (_I, [_D, _P, _P, _P, _P, _P, _P]),
+    "udaseg_conv2d_fwd_fused": (_I, [_D, _P, _P, _P, _P, _P, _I, _F, _P]),
     "udaseg_conv2d_dgrad": (_I, [_D, _P, _P, _P, _I, _P]),
     "udaseg_conv2d_wgrad": (_I, [_D, _P, _P, _P, _I, _P]),
     "udaseg_pack_dgrad_weights": (_I, [_D, _P, _P, _P]),
@@ -41,6 +42,7 @@ SIGNATURES = {
     "udaseg_bn_stats": (_I, [_P, _L, _I, _P, _P]),
     "udaseg_bn_apply": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _F, _F, _P, _P, _P, _P, _I, _F, _P]),
     "udaseg_bn_apply_eval": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _F, _P]),
+    "udaseg_bn_fold": (_I, [_P, _P, _P, _P, _P, _P, _F, _I, _I, _P, _P, _P]),
     "udaseg_bn_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _L, _I, _P, _I, _F, _P]),
     "udaseg_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _I, _I, _I, _P]),
     "udaseg_act_bwd": (_I, [_P, _P, _P, _L, _I, _F, _P]),
@@ -52,6 +54,7 @@ SIGNATURES = {
     "udaseg_ce_partials": (_I, []),
     "udaseg_ce_fwd": (_I, [_P, _P, _L, _I, _I, _P, _P, _P, _P]),
     "udaseg_ce_bwd": (_I, [_P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _P]),
+    "udaseg_argmax_confusion": (_I, [_P, _P, _L, _I, _I, _P, _P, _P]),
     "udaseg_gap_splits": (_I, [_I]),
     "udaseg_gap_linear_sigmoid_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "udaseg_gap_linear_sigmoid_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

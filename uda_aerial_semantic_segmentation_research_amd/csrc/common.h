@@ -65,7 +65,7 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 // small-channel direct 3x3 kernels (conv_small.hip)
 bool small_conv_applicable(int k, int stride, int pad, int ci_gather, int co_out);
 int launch_small_conv(const float* x, const float* w, const float* bias, float* y, int n, int h, int wd, int ci, int co,
-                      int flip, int accumulate, int act, float slope, double* stats, hipStream_t s);
+                      int flip, int accumulate, int act, float slope, double* stats, const float* residual, hipStream_t s);
 bool small_wgrad_applicable(int k, int stride, int pad, int ci, int co, int ntiles);
 int launch_small_wgrad(const float* x, const float* dy, float* dw, int n, int h, int wd, int ci, int co, int accumulate,
                        hipStream_t s);

@@ -40,6 +40,7 @@ struct IgemmArgs {
   int accumulate, act;
   float slope;
   int dense_out;
+  const float* residual;  // same layout as y: added before the activation (eval-mode residual blocks), or null
   double* stats;    // BN statistics of the output: [R][2][co] f64 accumulators (sum, sum of squares), or null
   int atomic_out;   // K-slices of one output: epilogue adds with global_atomic_add_f32 (output pre-zeroed or accumulated)
   int nclass;
@@ -248,6 +249,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
             if (a.bias) val += a.bias[n];
             ssum[j] += val;            // BN statistics see the conv output (bias included), before any activation
             ssq[j] += val * val;
+            if (a.residual) val += a.residual[pix * (size_t)a.co + n];
             val = act_apply(val, a.act, a.slope);
             if (a.accumulate) val += *dst;
             *dst = val;
@@ -400,14 +402,14 @@ extern "C" double udaseg_conv_flops(const udaseg_conv_desc* d) {
 }
 
 static int conv2d_fwd_impl(const udaseg_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
-                           int act, float slope, int accumulate, double* stats, void* stream) {
+                           int act, float slope, int accumulate, double* stats, const float* residual, void* stream) {
   int rc = check_desc(d);
   if (rc) return rc;
   UDASEG_CHECK_ARG(x && w && y, "conv2d_fwd: NULL pointer");
   hipStream_t st = as_stream(stream);
   if (d->kh == d->kw && small_conv_applicable(d->kh, d->stride, d->pad, d->ci, d->co)) {
     prof_begin(0, st);
-    rc = launch_small_conv(x, w, bias, y, d->n, d->hi, d->wi, d->ci, d->co, 0, accumulate, act, slope, stats, st);
+    rc = launch_small_conv(x, w, bias, y, d->n, d->hi, d->wi, d->ci, d->co, 0, accumulate, act, slope, stats, residual, st);
     prof_end(0, st, udaseg_conv_flops(d), 0, d);
     return rc;
   }
@@ -423,7 +425,8 @@ static int conv2d_fwd_impl(const udaseg_conv_desc* d, const float* x, const floa
       a.wt[t] = (unsigned char)t;
     }
   const int M = d->n * d->ho * d->wo;
-  const int ns = k_slices(M, d->co, ntaps, bias == nullptr && act == UDASEG_ACT_NONE);
+  a.residual = residual;
+  const int ns = k_slices(M, d->co, ntaps, bias == nullptr && act == UDASEG_ACT_NONE && residual == nullptr);
   a.stats = (ns == 1) ? stats : nullptr;  // squares of partial sums do not add up: sliced launches take the separate pass
   a.nclass = ns;
   for (int c = 0; c < ns; ++c) {
@@ -448,13 +451,18 @@ static int conv2d_fwd_impl(const udaseg_conv_desc* d, const float* x, const floa
 
 extern "C" int udaseg_conv2d_fwd(const udaseg_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
                                  int act, float slope, int accumulate, void* stream) {
-  return conv2d_fwd_impl(d, x, w, bias, y, act, slope, accumulate, nullptr, stream);
+  return conv2d_fwd_impl(d, x, w, bias, y, act, slope, accumulate, nullptr, nullptr, stream);
+}
+
+extern "C" int udaseg_conv2d_fwd_fused(const udaseg_conv_desc* d, const float* x, const float* w, const float* bias,
+                                       const float* residual, float* y, int act, float slope, void* stream) {
+  return conv2d_fwd_impl(d, x, w, bias, y, act, slope, 0, nullptr, residual, stream);
 }
 
 extern "C" int udaseg_conv2d_fwd_bnstats(const udaseg_conv_desc* d, const float* x, const float* w, const float* bias,
                                          float* y, double* stats, void* stream) {
   UDASEG_CHECK_ARG(stats != nullptr, "conv2d_fwd_bnstats: stats is NULL");
-  return conv2d_fwd_impl(d, x, w, bias, y, UDASEG_ACT_NONE, 0.f, 0, stats, stream);
+  return conv2d_fwd_impl(d, x, w, bias, y, UDASEG_ACT_NONE, 0.f, 0, stats, nullptr, stream);
 }
 
 extern "C" int udaseg_conv2d_dgrad(const udaseg_conv_desc* d, const float* dy, const float* w_t, float* dx,
@@ -468,7 +476,7 @@ extern "C" int udaseg_conv2d_dgrad(const udaseg_conv_desc* d, const float* dy, c
   if (d->kh == d->kw && small_conv_applicable(d->kh, d->stride, d->pad, d->co, d->ci)) {
     // dx = correlation of dy with the flipped taps; w_t is already [ci][9][co]
     rc = launch_small_conv(dy, w_t, nullptr, dx, d->n, d->hi, d->wi, d->co, d->ci, 1, accumulate, UDASEG_ACT_NONE, 0.f, nullptr,
-                           st);
+                           nullptr, st);
     prof_end(0, st, udaseg_conv_flops(d), 1, d);
     return rc;
   }

@@ -27,6 +27,7 @@ struct SmallArgs {
   const float* bias;  // [co] or null
   float* y;           // [n][h][w][co]
   int n, h, wd, ci, co;
+  const float* residual;  // added before the activation, same layout as y, or null
   double* stats;      // BN statistics of the output, [R][2][co] f64 accumulators, or null
   int flip;           // 0: tap (r,s) reads (y+r-1, x+s-1) (forward); 1: (y+1-r, x+1-s) (data gradient)
   int accumulate, act;
@@ -195,6 +196,7 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(const SmallArgs a) {
             float val = acc[r][ct][v] + bias[ct];
             ssum[ct] += val;
             ssq[ct] += val * val;
+            if (a.residual) val += a.residual[((size_t)(ni * a.h + gy) * a.wd + gx) * (size_t)a.co + co];
             val = act_apply(val, a.act, a.slope);
             if (a.accumulate) val += dst[co];
             dst[co] = val;
@@ -365,9 +367,9 @@ bool small_conv_applicable(int k, int stride, int pad, int ci_gather, int co_out
 }
 
 int launch_small_conv(const float* x, const float* w, const float* bias, float* y, int n, int h, int wd, int ci, int co,
-                      int flip, int accumulate, int act, float slope, double* stats, hipStream_t s) {
+                      int flip, int accumulate, int act, float slope, double* stats, const float* residual, hipStream_t s) {
   SmallArgs a = {};
-  a.x = x; a.w = w; a.bias = bias; a.y = y; a.stats = stats;
+  a.x = x; a.w = w; a.bias = bias; a.y = y; a.stats = stats; a.residual = residual;
   a.n = n; a.h = h; a.wd = wd; a.ci = ci; a.co = co;
   a.flip = flip; a.accumulate = accumulate; a.act = act; a.slope = slope;
   a.tiles_x = cdiv(wd, ST); a.tiles_y = cdiv(h, ST); a.ntiles = n * a.tiles_x * a.tiles_y;

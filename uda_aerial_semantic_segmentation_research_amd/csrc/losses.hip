@@ -156,6 +156,41 @@ __global__ void colsum_finish_kernel(const float* __restrict__ colpart, int nblo
   colsum[c] = accumulate ? colsum[c] + s : s;
 }
 
+// ---- validation metrics: per-pixel argmax + confusion matrix (SegmentationTrainer.calculate_metrics, reference
+// src/models/train.py:225-243; confusion-matrix definition src/analysis/metrics.py:17-29: bincount(C*true + pred)).
+// One thread per pixel, row in registers; the block's histogram lives in LDS (classes <= 32 -> 4 KiB of counters), one
+// global atomic per non-empty cell per block.  argmax tie rule = torch.argmax: first maximal index.
+template <int LDC4>
+__global__ __launch_bounds__(256) void argmax_confusion_kernel(const f32x4* __restrict__ logits, const int64_t* __restrict__ target,
+                                                               int64_t pixels, int classes, unsigned long long* __restrict__ cm,
+                                                               int64_t* __restrict__ pred_out) {
+  __shared__ unsigned int hist[32 * 32];
+  for (int i = threadIdx.x; i < classes * classes; i += 256) hist[i] = 0;
+  __syncthreads();
+  const int64_t T = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < pixels; p += T) {
+    float best = -INFINITY;
+    int bi = 0;
+#pragma unroll
+    for (int k = 0; k < LDC4; ++k) {
+      const f32x4 v = logits[p * LDC4 + k];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = k * 4 + e;
+        if (c < classes && (v[e] > best || (c == 0))) {
+          if (c == 0 || v[e] > best) { best = v[e]; bi = c; }
+        }
+      }
+    }
+    if (pred_out) pred_out[p] = bi;
+    const int t = (int)target[p];
+    if ((unsigned)t < (unsigned)classes) atomicAdd(&hist[t * classes + bi], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < classes * classes; i += 256)
+    if (hist[i]) atomicAdd(&cm[i], (unsigned long long)hist[i]);
+}
+
 // ---- discriminator tail ---------------------------------------------------------------------------------------
 constexpr int GAP_SPLITS = 32;
 
@@ -333,6 +368,29 @@ extern "C" int udaseg_ce_bwd(const float* logits, const int64_t* target, const f
   }
 #undef CE_BWD_CASE
   UDASEG_LAUNCH_CHECK("ce_bwd launch");
+  return UDASEG_OK;
+}
+
+extern "C" int udaseg_argmax_confusion(const float* logits, const int64_t* target, int64_t pixels, int classes, int ldc,
+                                       int64_t* confusion, int64_t* pred, void* stream) {
+  UDASEG_CHECK_ARG(logits && target && confusion, "argmax_confusion: NULL pointer");
+  UDASEG_CHECK_ARG(pixels > 0 && classes > 0 && classes <= 32 && classes <= ldc && ldc % 4 == 0 && ldc <= 32,
+                   "argmax_confusion: need classes <= 32, ldc %% 4 == 0 (classes=%d ldc=%d)", classes, ldc);
+  hipStream_t st = as_stream(stream);
+  int grid = (int)((pixels + 255) / 256 > 1024 ? 1024 : (pixels + 255) / 256);
+#define AMX_CASE(L)                                                                                                      \
+  case L:                                                                                                                \
+    hipLaunchKernelGGL(argmax_confusion_kernel<L>, dim3(grid), dim3(256), 0, st, (const f32x4*)logits, target, pixels,   \
+                       classes, (unsigned long long*)confusion, pred);                                                   \
+    break;
+  switch (ldc / 4) {
+    AMX_CASE(1) AMX_CASE(2) AMX_CASE(3) AMX_CASE(4) AMX_CASE(5) AMX_CASE(6) AMX_CASE(7) AMX_CASE(8)
+    default:
+      set_error("argmax_confusion: unsupported ldc %d", ldc);
+      return UDASEG_E_UNSUPPORTED;
+  }
+#undef AMX_CASE
+  UDASEG_LAUNCH_CHECK("argmax_confusion launch");
   return UDASEG_OK;
 }
 

@@ -315,6 +315,18 @@ __global__ void channel_sum_kernel(const f32x4* __restrict__ x, int64_t n4, int 
   }
 }
 
+// Eval mode: fold BatchNorm into the preceding conv.  w'[co][j] = w[co][j] * gamma/sqrt(var+eps); b'[co] = beta +
+// (bias - mean) * gamma/sqrt(var+eps).  Row-wise over the OHWI weight (j = taps*ci).
+__global__ void bn_fold_kernel(const float* __restrict__ w, const float* __restrict__ bias, const float* __restrict__ gamma,
+                               const float* __restrict__ beta, const float* __restrict__ rm, const float* __restrict__ rv,
+                               float eps, int co, int J, float* __restrict__ wf, float* __restrict__ bf) {
+  const int o = blockIdx.x;
+  if (o >= co) return;
+  const float s = gamma[o] / sqrtf(rv[o] + eps);
+  for (int j = threadIdx.x; j < J; j += blockDim.x) wf[(size_t)o * J + j] = w[(size_t)o * J + j] * s;
+  if (threadIdx.x == 0) bf[o] = beta[o] + ((bias ? bias[o] : 0.f) - rm[o]) * s;
+}
+
 static int check_pc(int64_t pixels, int c, const char* who) {
   UDASEG_CHECK_ARG(pixels > 0 && c > 0 && c % 4 == 0, "%s: need pixels > 0 and channels a positive multiple of 4 (got %lld, %d)",
                    who, (long long)pixels, c);
@@ -400,6 +412,17 @@ extern "C" int udaseg_bn_bwd_apply(const float* dz, const float* z, const float*
                      (const f32x4*)y, save_mean, save_rstd, gamma, bsums, (f32x4*)dy, (f32x4*)dres, dgamma, dbeta, n4, s.c4,
                      pixels, act, slope, accumulate_dy, accumulate_dres, accumulate_param);
   UDASEG_LAUNCH_CHECK("bn_bwd_apply launch");
+  return UDASEG_OK;
+}
+
+extern "C" int udaseg_bn_fold(const float* w, const float* bias, const float* gamma, const float* beta,
+                              const float* running_mean, const float* running_var, float eps, int co, int row_len, float* w_folded,
+                              float* bias_folded, void* stream) {
+  UDASEG_CHECK_ARG(w && gamma && beta && running_mean && running_var && w_folded && bias_folded && co > 0 && row_len > 0,
+                   "bn_fold: bad arguments");
+  hipLaunchKernelGGL(bn_fold_kernel, dim3(co), dim3(256), 0, as_stream(stream), w, bias, gamma, beta, running_mean, running_var,
+                     eps, co, row_len, w_folded, bias_folded);
+  UDASEG_LAUNCH_CHECK("bn_fold launch");
   return UDASEG_OK;
 }
 

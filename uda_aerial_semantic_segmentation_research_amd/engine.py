@@ -238,6 +238,11 @@ class Plan:
         if training:
             self.stats = torch.zeros(max(nbn, 2) * self.R, dtype=torch.float64, device=dev)  # [R][sum | sumsq] per BN
             self.saved_stats = torch.empty(max(nbn, 2), dtype=torch.float32, device=dev)  # [mean | rstd] per BN
+        else:
+            # inference: BatchNorm is folded into the conv weights (scratch refreshed per forward: one pass over the weights)
+            self.fold_w = torch.empty_like(net._arena)
+            self.fold_b = torch.empty(max(nbn // 2, 4), dtype=torch.float32, device=dev)
+            self._fold_off = 0
         self._stat_off = 0
         self.garena = None
         self.bstats = None
@@ -311,8 +316,19 @@ class Plan:
             K.conv2d_fwd_bnstats(d, x, self.w(conv), self.b(conv) if conv.bias is not None else None, y, sums[0], self.st)
             z, ms = self.bn(bn, y, act, slope, residual, sums)
         else:
-            y, d = self.conv(conv, x)
-            z, ms = self.bn(bn, y, act, slope, residual)
+            # eval mode: ONE kernel per conv+BN(+add)+activation block
+            n, h, w, ci = x.shape
+            d = K.conv_desc(n, h, w, ci, conv.cout_p, conv.k, conv.stride, conv.pad)
+            o, nel, shp = self.idx[(id(conv), "weight")]
+            wf = self.fold_w[o:o + nel].view(shp)
+            c = ceil4(bn.c)
+            bf = self.fold_b[self._fold_off:self._fold_off + c]
+            self._fold_off += c
+            K.bn_fold(self.w(conv), self.b(conv) if conv.bias is not None else None, self.pvec(bn, "weight"),
+                      self.pvec(bn, "bias"), bn.running_mean, bn.running_var, bn.eps, wf, bf, self.st)
+            z = torch.empty((n, d.ho, d.wo, conv.cout_p), device=x.device, dtype=torch.float32)
+            K.conv2d_fwd_fused(d, x, wf, bf, residual, z, act, slope, self.st)
+            return z, None
         rec = (conv, bn, d, x, y, z, ms, act, slope) if self.save else None
         return z, rec
 

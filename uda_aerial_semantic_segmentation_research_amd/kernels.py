@@ -49,6 +49,24 @@ def conv2d_fwd_bnstats(d, x, w, bias, y, stats, st=None):
                                                  stats.data_ptr(), st if st is not None else stream()), "conv2d_fwd_bnstats")
 
 
+def conv2d_fwd_fused(d, x, w, bias, residual, y, act=ACT_NONE, slope=0.0, st=None):
+    check(_lib.load().udaseg_conv2d_fwd_fused(_byref(d), x.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), y.data_ptr(),
+                                               act, slope, st if st is not None else stream()), "conv2d_fwd_fused")
+
+
+def bn_fold(w, bias, gamma, beta, running_mean, running_var, eps, w_folded, bias_folded, st=None):
+    co = w.shape[0]
+    check(_lib.load().udaseg_bn_fold(w.data_ptr(), _ptr(bias), gamma.data_ptr(), beta.data_ptr(), running_mean.data_ptr(),
+                                      running_var.data_ptr(), eps, co, w.numel() // co, w_folded.data_ptr(),
+                                      bias_folded.data_ptr(), st if st is not None else stream()), "bn_fold")
+
+
+def argmax_confusion(logits_base, target, pixels, classes, ldc, confusion, pred=None, st=None):
+    check(_lib.load().udaseg_argmax_confusion(logits_base.data_ptr(), target.data_ptr(), pixels, classes, ldc,
+                                               confusion.data_ptr(), _ptr(pred), st if st is not None else stream()),
+          "argmax_confusion")
+
+
 def conv2d_dgrad(d, dy, w_t, dx, accumulate=False, st=None):
     check(_lib.load().udaseg_conv2d_dgrad(_byref(d), dy.data_ptr(), w_t.data_ptr(), dx.data_ptr(), int(accumulate),
                                            st if st is not None else stream()), "conv2d_dgrad")

@@ -60,24 +60,37 @@ class DomainAdaptationMetrics:
         }
 
 
+def confusion_matrix(outputs, masks, num_classes):
+    """[num_classes, num_classes] int64 confusion matrix (rows = target, cols = argmax prediction) on the device:
+    one HIP kernel (per-pixel argmax + LDS histogram), no intermediate argmax tensor."""
+    from . import kernels as K
+    from .losses import _padded_nhwc
+    if outputs.device.type != "cuda":
+        raise RuntimeError("confusion_matrix: logits must live on the GPU (no CPU path in this build)")
+    buf, ldc = _padded_nhwc(outputs.detach())
+    cm = torch.zeros(num_classes * num_classes, dtype=torch.int64, device=outputs.device)
+    tgt = masks.reshape(-1)
+    if tgt.dtype != torch.int64:
+        tgt = tgt.long()
+    K.argmax_confusion(buf, tgt.contiguous(), tgt.numel(), num_classes, ldc, cm)
+    return cm.view(num_classes, num_classes)
+
+
 def segmentation_metrics(outputs, masks, num_classes):
     """{'iou': macro Jaccard over the classes present, 'accuracy', 'iou_class_k': binary Jaccard of class k}.
 
     Definitions follow torchmetrics' JaccardIndex (multiclass macro: classes absent from both prediction and target
     carry no weight; binary: tp / (tp + fp + fn), 0 when empty), which the reference instantiates at
-    ``src/models/train.py:209-222``.  One bincount confusion matrix on the device, one transfer.
+    ``src/models/train.py:209-222``.  The confusion matrix comes from one HIP kernel; ONE 23x23 transfer to the host.
     """
-    pred = outputs.argmax(dim=1)
-    k = num_classes
-    cm = torch.bincount((masks.reshape(-1) * k + pred.reshape(-1)), minlength=k * k).reshape(k, k).double()
+    cm = confusion_matrix(outputs, masks, num_classes).cpu().double()
     tp = cm.diag()
     denom = cm.sum(0) + cm.sum(1) - tp
     iou_c = torch.where(denom > 0, tp / denom.clamp_min(1), torch.zeros_like(tp))
     present = (cm.sum(0) + cm.sum(1)) > 0
-    macro = (iou_c * present).sum() / present.sum().clamp_min(1)
-    acc = tp.sum() / cm.sum().clamp_min(1)
-    host = torch.cat([macro.reshape(1), acc.reshape(1), iou_c]).cpu().tolist()
-    out = {"iou": host[0], "accuracy": host[1]}
-    for c in range(k):
-        out[f"iou_class_{c}"] = host[2 + c]
+    macro = float((iou_c * present).sum() / present.sum().clamp_min(1))
+    acc = float(tp.sum() / cm.sum().clamp_min(1))
+    out = {"iou": macro, "accuracy": acc}
+    for c in range(num_classes):
+        out[f"iou_class_{c}"] = float(iou_c[c])
     return out
