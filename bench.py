@@ -166,6 +166,14 @@ def main():
     roofline = None
     if not args.no_roofline and rank == 0:
         # separate leg: HIP events around every conv-kernel launch on the launch stream (C-ABI udaseg_prof_*)
+        # single stream for this leg: with the weight gradients on their side stream, concurrent kernels stretch each
+        # other's durations and a per-kernel rate would under-state the kernel (the timed region above keeps the overlap)
+        from uda_aerial_semantic_segmentation_research_amd import engine as _engine
+        was_side = _engine.SIDE_STREAM_WGRAD
+        _engine.SIDE_STREAM_WGRAD = False
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
         K.prof_reset()
         K.prof_enable(True)
         psteps = 3
@@ -173,6 +181,7 @@ def main():
             step()
         torch.cuda.synchronize()
         K.prof_enable(False)
+        _engine.SIDE_STREAM_WGRAD = was_side
         ms0, fl0, n0 = K.prof_read(0)
         ms1, fl1, n1 = K.prof_read(1)
         if args.layer_table:

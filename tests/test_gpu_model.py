@@ -271,6 +271,7 @@ def test_residual_block_plan(pkg, kind, cin, planes, stride):
     prior = torch.randn(xd.shape, device="cuda")          # an earlier consumer already wrote into dx
     G.put(xd, prior.clone())
     mb.bwd(P, G, rec, out)
+    P.join_side_stream()                                    # weight gradients are produced on a side stream
     check(_nchw(G.get(xd) - prior), x.grad, "block dx", 1e-3)
     gr = dict(rb.named_parameters())
     for (k, p), g in zip(h.named_parameters(), h.grad_views(P.garena)):
@@ -301,6 +302,7 @@ def test_decoder_block_plan(pkg, cin, cskip, cout):
     G = GradSlots()
     G.put(out, _nhwc(d_out))
     mb.bwd(P, G, rec, out)
+    P.join_side_stream()
     check(_nchw(G.get(xd)), x.grad, "decoder block dx", 1e-3)
     if cskip:
         check(_nchw(G.get(sd)), skip.grad, "decoder block dskip", 1e-3)

@@ -146,14 +146,20 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const f32x4* __restrict__ l
   }
 }
 
-// colsum[c] (+)= sum over blocks of colpart[b][c]; single block, deterministic
-__global__ void colsum_finish_kernel(const float* __restrict__ colpart, int nblocks, int ldc, float* __restrict__ colsum,
-                                     int accumulate) {
-  const int c = threadIdx.x;
-  if (c >= ldc) return;
+// colsum[c] (+)= sum over blocks of colpart[b][c]: one 256-thread block per column, fixed-order tree => deterministic
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ colpart, int nblocks, int ldc,
+                                                            float* __restrict__ colsum, int accumulate) {
+  __shared__ float red[4];
+  const int c = blockIdx.x;
   float s = 0.f;
-  for (int b = 0; b < nblocks; ++b) s += colpart[(size_t)b * ldc + c];
-  colsum[c] = accumulate ? colsum[c] + s : s;
+  for (int b = threadIdx.x; b < nblocks; b += 256) s += colpart[(size_t)b * ldc + c];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float t = (red[0] + red[1]) + (red[2] + red[3]);
+    colsum[c] = accumulate ? colsum[c] + t : t;
+  }
 }
 
 // ---- validation metrics: per-pixel argmax + confusion matrix (SegmentationTrainer.calculate_metrics, reference
@@ -349,7 +355,7 @@ extern "C" int udaseg_ce_bwd(const float* logits, const int64_t* target, const f
 #undef CE_BWD_CASE
     UDASEG_LAUNCH_CHECK("ce_bwd launch");
     if (colsum) {
-      hipLaunchKernelGGL(colsum_finish_kernel, dim3(1), dim3(64), 0, st, colsum_partials, grid, ldc, colsum, 0);
+      hipLaunchKernelGGL(colsum_finish_kernel, dim3(ldc), dim3(256), 0, st, colsum_partials, grid, ldc, colsum, 0);
       UDASEG_LAUNCH_CHECK("colsum_finish launch");
     }
     return UDASEG_OK;

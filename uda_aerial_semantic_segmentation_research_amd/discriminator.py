@@ -111,4 +111,5 @@ class DomainDiscriminator(ArenaModule):
             dz = dx
         K.act_bwd(dz, a0, dz, ACT_LEAKY, SLOPE, P.st)    # through conv0's fused LeakyReLU, in place
         P.conv_bwd(conv0, d0, x4, dz, dx=None)
+        P.join_side_stream()
         self.deliver_grads(P.garena)

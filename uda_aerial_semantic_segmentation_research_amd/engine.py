@@ -9,6 +9,7 @@ Design (MI355X-first):
   (no per-op autograd graph, no per-op allocator traffic beyond activations).
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -17,6 +18,9 @@ from . import kernels as K
 from ._lib import ACT_LEAKY, ACT_NONE
 
 ALIGN = 64  # floats; every arena entry starts on a 256-byte boundary
+# Weight gradients run on a side HIP stream (see Plan.begin_backward).  UDASEG_SERIAL=1 keeps everything on one stream:
+# per-kernel durations are then free of overlap slow-down (bench.py's roofline leg and the committed rocprof stats use it).
+SIDE_STREAM_WGRAD = os.environ.get("UDASEG_SERIAL", "0") != "1"
 
 
 def ceil4(c):
@@ -166,6 +170,13 @@ class ArenaModule(nn.Module):
         """Cheap per-forward check (first/last entry); anything that re-homes parameters goes through _apply."""
         if not self._arena_ok(full=False):
             self.build_arena()
+
+    def _side_stream(self):
+        st = getattr(self, "_side", None)
+        if st is None or st.device != self._arena.device:
+            st = torch.cuda.Stream(device=self._arena.device)
+            self._side = st
+        return st
 
     def tick_batchnorm_counters(self):
         self._nbt.add_(1)
@@ -336,12 +347,18 @@ class Plan:
     def begin_backward(self):
         net = self.net
         self.st = K.stream()
+        self.main_stream = torch.cuda.current_stream()
+        # weight gradients are off the backward critical path (only Adam / the all-reduce consume them): they run on a
+        # side HIP stream and fill the matrix cores while the main chain sits in HBM-bound BatchNorm-backward kernels
+        self.side_stream = net._side_stream() if SIDE_STREAM_WGRAD else None
         self.garena = torch.zeros_like(net._arena)
         nbn = net._nbn
         self.bstats = torch.zeros(max(nbn, 2) * self.R, dtype=torch.float64, device=self.dev)
         self._bstat_off = 0
         # dgrad needs the weights as [ci][taps][co]: one batched repack of the whole arena per backward
         K.pack_dgrad_batched(net._arena, net._wt_arena, net._wt_table, self.st)
+        if self.side_stream is not None:
+            self.side_stream.wait_stream(self.main_stream)      # zeroed gradient arena is visible to the side stream
 
     def packed_wt(self, conv):
         o = self.net._wt_off[id(conv)]
@@ -350,12 +367,21 @@ class Plan:
 
     def conv_bwd(self, conv, d, x, dy, dx=None, dx_acc=False, dbias=None):
         """dW (+ dbias) into the grad arena; dx (+)= dgrad when dx is given.  dbias: already-computed channel sums of dy."""
-        K.conv2d_wgrad(d, x, dy, self.gw(conv), True, self.st)
+        side = self.side_stream
+        if side is not None:
+            ev = torch.cuda.Event()
+            ev.record(self.main_stream)                         # dy is final here
+            side.wait_event(ev)
+            wst = side.cuda_stream
+            dy.record_stream(side)                              # the caching allocator must not recycle dy under the side stream
+        else:
+            wst = self.st
+        K.conv2d_wgrad(d, x, dy, self.gw(conv), True, wst)
         if conv.bias is not None:
             if dbias is not None:
-                K.axpy(self.gvec(conv, "bias"), dbias, 1.0, self.st)
+                K.axpy(self.gvec(conv, "bias"), dbias, 1.0, wst)
             else:
-                K.channel_sum(dy, self.gvec(conv, "bias"), True, self.st)
+                K.channel_sum(dy, self.gvec(conv, "bias"), True, wst)
         if dx is not None:
             K.conv2d_dgrad(d, dy, self.packed_wt(conv), dx, dx_acc, self.st)
 
@@ -376,6 +402,12 @@ class Plan:
         conv, bn, d, x, y, z, ms, act, slope = rec
         dy = self.bn_bwd(bn, y, z, ms, dz, act, slope, dres, dres_acc)
         self.conv_bwd(conv, d, x, dy, dx, dx_acc)
+
+
+    def join_side_stream(self):
+        """Order the main stream after every side-stream weight gradient issued so far."""
+        if self.side_stream is not None:
+            self.main_stream.wait_stream(self.side_stream)
 
 
 class GradSlots:
