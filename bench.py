@@ -22,6 +22,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # see uda_aerial_semantic_segmentation_research_amd/__init__.py
 
 import torch
 import torch.distributed as dist
@@ -36,6 +37,20 @@ def synthetic(n, h, w, classes, seed, device):
     g = torch.Generator().manual_seed(seed + 1)
     y = torch.randint(0, classes, (n, h, w), generator=g, dtype=torch.int64)
     return x.to(device), y.to(device)
+
+
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed PMC reduction (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    separate passes, corrected as MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py).  None when there is no such file."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        k = json.load(open(files[-1]))["kernels"].get(kernel)
+        return k["hbm_bytes_per_launch"] if k else None
+    except Exception:
+        return None
 
 
 def cpu_baseline(encoder, classes, hw, budget_s=25.0):
@@ -89,7 +104,7 @@ def main():
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    rehearse = os.environ.get("UDASEG_DDP_REHEARSE") == "1"   # run the N>1 code path (NCCL, side stream) at world 1
+    rehearse = os.environ.get("UDASEG_DDP_REHEARSE", "0") in ("1", "2", "3")   # run the N>1 code path (NCCL, side stream) at world 1
     if world > 1 or rehearse:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -113,12 +128,13 @@ def main():
     model.ensure_arena()
     if world > 1 or rehearse:
         from uda_aerial_semantic_segmentation_research_amd import ddp as _ddp
-        _ddp.FORCE = rehearse
+        _ddp.FORCE = os.environ.get("UDASEG_DDP_REHEARSE") == "1"       # "2": hooks and streams only, no collectives
         if world > 1:
             broadcast_parameters(model)
         else:
             dist.broadcast(model._arena, 0)
-        trainer.grad_reducer = GradAllReducer(model)
+        if os.environ.get("UDASEG_DDP_REHEARSE") != "3":               # "3": process group only
+            trainer.grad_reducer = GradAllReducer(model, bucket_bytes=int(os.environ.get("UDASEG_DDP_BUCKET_MB", "32")) << 20)
     opt = FusedAdam(model.parameters(), lr=1e-4)
     x, y = synthetic(args.batch, args.size, args.size, args.classes, seed=100 * rank, device=dev)
     if args.workload == "inference":
@@ -203,7 +219,7 @@ def main():
         achieved = dom[2] / (dom[1] * 1e-3) / 1e12
         conv_ms = sum(k[1] for k in kern) / psteps
         roofline = {"bound": "mfma", "kernel": dom[0], "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(dom[0]),
                     "launches_per_step": dom[3] // psteps, "avg_launch_us": round(1e3 * dom[1] / dom[3], 2),
                     "gflop_per_launch": round(dom[2] / dom[3] / 1e9, 3),
                     "ms_per_step": round(dom[1] / psteps, 3),

@@ -26,16 +26,18 @@ FORCE = False   # tests / 1-GPU rehearsal: issue the collectives even when world
 
 
 def average_(flat, world, group=None):
-    """In-place mean over ranks (AVG where the backend has it, else SUM + scale: gloo)."""
+    """In-place mean over ranks (AVG where the backend has it, else SUM + scale: gloo).
+
+    Enqueued with ``async_op=False``: with NCCL/RCCL that does NOT block the host -- it makes the CURRENT stream wait for
+    the collective (which runs on the backend's own stream), so ordering a consumer after the current stream is enough.
+    (With ``async_op=True`` and no ``work.wait()`` the calling stream would not be ordered after the collective.)"""
     if world == 1 and not (FORCE and dist.is_initialized()):
-        return None
-    backend = dist.get_backend(group)
-    if backend == "nccl":
-        return dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=group, async_op=True)
-    work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
-    work.wait()
-    flat.div_(world)
-    return None
+        return
+    if dist.get_backend(group) == "nccl":
+        dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=group)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat.div_(world)
 
 
 class GradAllReducer:
@@ -68,10 +70,16 @@ class GradAllReducer:
         if self.world == 1 and not FORCE:
             return
         if g.is_cuda:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
+            # gradients come from the backward's main stream AND its weight-gradient side stream: wait on both, without
+            # stalling either of them
+            if hasattr(self._plan, "ready_events"):
+                evs = self._plan.ready_events()
+            else:
+                evs = [torch.cuda.Event()]
+                evs[0].record(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
-                self.comm_stream.wait_event(ev)
+                for ev in evs:
+                    self.comm_stream.wait_event(ev)
                 average_(g, self.world, self.group)
         else:
             average_(g, self.world, self.group)
@@ -95,10 +103,8 @@ class GradAllReducer:
         """Average a network's whole gradient arena on the current stream (small networks: the discriminator)."""
         world = dist.get_world_size(group) if dist.is_initialized() else 1
         ga = getattr(net, "_grad_arena", None)
-        if world > 1 and ga is not None:
-            w = average_(ga, world, group)
-            if w is not None:
-                w.wait()
+        if (world > 1 or FORCE) and ga is not None:
+            average_(ga, world, group)
 
 
 def broadcast_parameters(net, src=0, group=None):

@@ -404,6 +404,16 @@ class Plan:
         self.conv_bwd(conv, d, x, dy, dx, dx_acc)
 
 
+    def ready_events(self):
+        """Events after which every gradient issued so far is final (one per stream in use); for the all-reduce stream."""
+        evs = [torch.cuda.Event()]
+        evs[0].record(self.main_stream)
+        if self.side_stream is not None:
+            e = torch.cuda.Event()
+            e.record(self.side_stream)
+            evs.append(e)
+        return evs
+
     def join_side_stream(self):
         """Order the main stream after every side-stream weight gradient issued so far."""
         if self.side_stream is not None:

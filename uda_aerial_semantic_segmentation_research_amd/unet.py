@@ -290,22 +290,20 @@ class Unet(ArenaModule):
         P.conv_bwd(head, d_head, h_last, dl, dx=dh, dx_acc=False, dbias=dbias)
         hook = self.grad_ready_hook
         if hook is not None:
-            P.join_side_stream()
             hook(P, P.offset_of(head))
         for blk, rec, out in reversed(tape):
             blk.bwd(P, G, rec, out)
             if hook is not None:
                 first = next(m for m in blk.modules() if isinstance(m, ConvP))
-                P.join_side_stream()
                 hook(P, P.offset_of(first))
         # stem: maxpool backward accumulates onto the skip gradient of f1, then BN+ReLU and the 7x7 wgrad
         d_pooled = G.pop(pooled)
         d_f1, acc = G.slot(f1)
         K.maxpool_bwd(d_pooled, pidx, d_f1, acc, P.st)
         P.conv_bn_act_bwd(r_stem, d_f1, dx=None)
-        P.join_side_stream()
         if hook is not None:
-            hook(P, 0)
+            hook(P, 0)            # the reducer's stream waits on events of both streams (Plan.ready_events)
+        P.join_side_stream()
         self.deliver_grads(P.garena)
 
 
