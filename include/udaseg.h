@@ -63,6 +63,13 @@ int udaseg_conv2d_fwd_bnstats(const udaseg_conv_desc* d, const float* x, const f
  * is the whole conv+BN(+add)+ReLU block of an eval-mode forward (reference validate(): src/models/train.py:391-438). */
 int udaseg_conv2d_fwd_fused(const udaseg_conv_desc* d, const float* x, const float* w, const float* bias,
                             const float* residual, float* y, int act, float slope, void* stream);
+/* bf16 storage variants (BASELINE configs 3 and 5): x, w, residual, y are bf16 (channel counts multiples of 8), accumulation,
+ * bias and BatchNorm statistics fp32/f64; v_mfma_f32_32x32x16_bf16.  out_f32 != 0 writes y as fp32 (segmentation logits).
+ * stats may be NULL. */
+int udaseg_conv2d_fwd_bf16(const udaseg_conv_desc* d, const void* x, const void* w, const float* bias, const void* residual,
+                           void* y, int out_f32, int act, float slope, double* stats, void* stream);
+int udaseg_conv2d_dgrad_bf16(const udaseg_conv_desc* d, const void* dy, const void* w_t, void* dx, int accumulate,
+                             void* stream);
 /* dx[n,hi,wi,ci] (+)= conv_transpose(dy, w).  w_t is the dgrad packing [ci][kh][kw][co] made by
  * udaseg_pack_dgrad_weights.  Autograd of the convs above: loss.backward() at train.py:343. */
 int udaseg_conv2d_dgrad(const udaseg_conv_desc* d, const float* dy, const float* w_t, float* dx, int accumulate,

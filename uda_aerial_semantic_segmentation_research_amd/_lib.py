@@ -32,6 +32,8 @@ SIGNATURES = {
     "udaseg_conv2d_fwd": (_I, [_D, _P, _P, _P, _P, _I, _F, _I, _P]),
     "udaseg_conv2d_fwd_bnstats": (_I, [_D, _P, _P, _P, _P, _P, _P]),
     "udaseg_conv2d_fwd_fused": (_I, [_D, _P, _P, _P, _P, _P, _I, _F, _P]),
+    "udaseg_conv2d_fwd_bf16": (_I, [_D, _P, _P, _P, _P, _P, _I, _I, _F, _P, _P]),
+    "udaseg_conv2d_dgrad_bf16": (_I, [_D, _P, _P, _P, _I, _P]),
     "udaseg_conv2d_dgrad": (_I, [_D, _P, _P, _P, _I, _P]),
     "udaseg_conv2d_wgrad": (_I, [_D, _P, _P, _P, _I, _P]),
     "udaseg_pack_dgrad_weights": (_I, [_D, _P, _P, _P]),

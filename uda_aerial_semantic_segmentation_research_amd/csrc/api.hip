@@ -36,7 +36,9 @@ static const char* const g_knames[PROF_NKERNELS] = {
     "conv_igemm_kernel<128, 128, 2, 2>", "conv_igemm_kernel<128, 64, 2, 2>", "conv_igemm_kernel<64, 64, 2, 2>",
     "conv_igemm_kernel<128, 32, 4, 1>",  "conv3x3_small_kernel<1, 1>",       "conv3x3_small_kernel<2, 1>",
     "conv3x3_small_kernel<1, 2>",        "conv_wgrad_kernel<64, 64, 2, 2>",  "conv_wgrad_kernel<32, 128, 1, 4>",
-    "conv3x3_small_wgrad_kernel<1, 1>",  "conv3x3_small_wgrad_kernel<2, 1>", "conv3x3_small_wgrad_kernel<1, 2>"};
+    "conv3x3_small_wgrad_kernel<1, 1>",  "conv3x3_small_wgrad_kernel<2, 1>", "conv3x3_small_wgrad_kernel<1, 2>",
+    "conv_igemm_kernel<*, bf16>",        "conv_wgrad_bf16_kernel",           "reserved14",
+    "reserved15"};
 static std::vector<KRec> g_krecs[PROF_NKERNELS];
 static std::vector<ProfRec> g_recs[2];
 static std::vector<hipEvent_t> g_pool;

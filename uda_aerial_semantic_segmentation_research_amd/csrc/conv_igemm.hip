@@ -28,10 +28,10 @@ namespace udaseg {
 constexpr int NCLS = 4;  // classes per launch: dgrad parity classes of a strided conv, or K-slices (tap ranges)
 
 struct IgemmArgs {
-  const float* x;
-  const float* w;
-  const float* bias;
-  float* y;
+  const void* x;      // fp32 or bf16 NHWC (template parameter BF of the kernel)
+  const void* w;
+  const float* bias;  // always fp32
+  void* y;
   int hi, wi, ci;
   int ho, wo, co;
   int sy_o, sx_o, sy_i, sx_i;
@@ -40,7 +40,9 @@ struct IgemmArgs {
   int accumulate, act;
   float slope;
   int dense_out;
-  const float* residual;  // same layout as y: added before the activation (eval-mode residual blocks), or null
+  const void* residual;  // same layout / type as y: added before the activation (eval-mode residual blocks), or null
+  int out_f32;            // bf16 kernels only: write fp32 outputs (segmentation logits)
+  int bf16;               // host-side selector of the kernel instantiation
   double* stats;    // BN statistics of the output: [R][2][co] f64 accumulators (sum, sum of squares), or null
   int atomic_out;   // K-slices of one output: epilogue adds with global_atomic_add_f32 (output pre-zeroed or accumulated)
   int nclass;
@@ -61,8 +63,17 @@ constexpr int LDS_LD = BK + 4;
 template <int BM, int BN>
 constexpr int igemm_lds_bytes() { return 2 * (BM + BN) * LDS_LD * 4 + 3 * 64 * 4; }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// BF = false: fp32 storage, v_mfma_f32_32x32x2_f32, 32 K-elements per tile.
+// BF = true : bf16 storage, v_mfma_f32_32x32x16_bf16, 64 K-elements per tile, fp32 accumulation / bias / statistics.
+// Both stage 128 bytes per row per tile with 16-byte loads, so gather, LDS layout and fragment reads are byte-identical;
+// a lane's 16-byte LDS read is 4 fp32 (-> 4 MFMAs) or 8 bf16 (-> exactly one bf16 MFMA's K slice: k = 16s + 8*lh + j).
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool BF>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
+  constexpr int ES = BF ? 2 : 4;        // element bytes
+  constexpr int EPV = 16 / ES;          // elements per 16-byte vector
+  constexpr int BKE = BK * 4 / ES;      // K elements per tile
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int A_PASS = BM / 32;
@@ -140,12 +151,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
       for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
 
   f32x4 ra[A_PASS], rb[B_PASS];
-  const int nkt = (cK + BK - 1) / BK;
+  const int nkt = (cK + BKE - 1) / BKE;
+  const char* xb = static_cast<const char*>(a.x);
+  const char* wb = static_cast<const char*>(a.w);
 
   __syncthreads();  // tap table visible
 
   auto load_tile = [&](int kt) {
-    const int kk = kt * BK + kq * 4;
+    const int kk = kt * BKE + kq * EPV;
     const bool kvalid = kk < cK;
     int t = (int)(((float)kk + 0.5f) * a.inv_ci);
     const int c = kk - t * a.ci;
@@ -159,7 +172,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (ok) {
         const size_t off = (size_t)(a_base[p] + iy * a.wi + ix) * (size_t)a.ci + (size_t)c;
-        v = *reinterpret_cast<const f32x4*>(a.x + off);
+        v = *reinterpret_cast<const f32x4*>(xb + off * ES);
       }
       ra[p] = v;
     }
@@ -168,7 +181,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (kvalid && b_off[p] >= 0) {
         const size_t off = (size_t)b_off[p] + (size_t)(wtt * a.ci + c);
-        v = *reinterpret_cast<const f32x4*>(a.w + off);
+        v = *reinterpret_cast<const f32x4*>(wb + off * ES);
       }
       rb[p] = v;
     }
@@ -203,13 +216,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
       for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ac + i * 32 * LDS_LD + s * 8);
 #pragma unroll
       for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bc + j * 32 * LDS_LD + s * 8);
-#pragma unroll
-      for (int k2 = 0; k2 < 4; ++k2)
+      if constexpr (BF) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][k2], bf[j][k2], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i]),
+                                                                __builtin_bit_cast(bf16x8, bf[j]), acc[i][j], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][k2], bf[j][k2], acc[i][j], 0, 0, 0);
+      }
     }
     if (more) store_tile(cur ^ 1);
     __syncthreads();
@@ -241,18 +263,37 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
       for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn + j * 32 + lr;
         if (n < a.co) {
-          float* dst = a.y + pix * (size_t)a.co + n;
-          if (a.atomic_out) {
-            atomicAdd(dst, acc[i][j][v]);
+          const size_t o = pix * (size_t)a.co + n;
+          if constexpr (!BF) {
+            float* dst = static_cast<float*>(a.y) + o;
+            if (a.atomic_out) {
+              atomicAdd(dst, acc[i][j][v]);
+            } else {
+              float val = acc[i][j][v];
+              if (a.bias) val += a.bias[n];
+              ssum[j] += val;          // BN statistics see the conv output (bias included), before any activation
+              ssq[j] += val * val;
+              if (a.residual) val += static_cast<const float*>(a.residual)[o];
+              val = act_apply(val, a.act, a.slope);
+              if (a.accumulate) val += *dst;
+              *dst = val;
+            }
           } else {
             float val = acc[i][j][v];
             if (a.bias) val += a.bias[n];
-            ssum[j] += val;            // BN statistics see the conv output (bias included), before any activation
+            ssum[j] += val;            // statistics from the fp32 accumulator, before rounding to bf16
             ssq[j] += val * val;
-            if (a.residual) val += a.residual[pix * (size_t)a.co + n];
+            if (a.residual) val += (float)static_cast<const __bf16*>(a.residual)[o];
             val = act_apply(val, a.act, a.slope);
-            if (a.accumulate) val += *dst;
-            *dst = val;
+            if (a.out_f32) {
+              float* dst = static_cast<float*>(a.y) + o;
+              if (a.accumulate) val += *dst;
+              *dst = val;
+            } else {
+              __bf16* dst = static_cast<__bf16*>(a.y) + o;
+              if (a.accumulate) val += (float)*dst;
+              *dst = (__bf16)val;
+            }
           }
         }
       }
@@ -290,11 +331,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
 
 // ------------------------------------------------------------------------------------------------- host side
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
-static int launch_cfg(const IgemmArgs& a, hipStream_t s) {
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool BF>
+static int launch_cfg_t(const IgemmArgs& a, hipStream_t s) {
   static bool attr_done = false;
   constexpr int lds = igemm_lds_bytes<BM, BN>();
-  auto kern = conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N>;
+  auto kern = conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, BF>;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv_igemm)");
@@ -311,12 +352,18 @@ static int launch_cfg(const IgemmArgs& a, hipStream_t s) {
   for (int c = a.nclass; c < NCLS; ++c) b.tile_begin[c + 1] = b.tile_begin[a.nclass];
   if (b.tile_begin[a.nclass] == 0) return UDASEG_OK;
   dim3 grid((unsigned)b.tile_begin[a.nclass]), block(256);
-  constexpr int kid = (BM == 128 && BN == 128) ? 0 : (BM == 128 && BN == 64) ? 1 : (BM == 64) ? 2 : 3;
+  constexpr int kid = BF ? 12 : (BM == 128 && BN == 128) ? 0 : (BM == 128 && BN == 64) ? 1 : (BM == 64) ? 2 : 3;
   hipEvent_t ev = kprof_begin(s);
   hipLaunchKernelGGL(kern, grid, block, lds, s, b);
   kprof_end(kid, ev, s, flops);
   UDASEG_LAUNCH_CHECK("conv_igemm launch");
   return UDASEG_OK;
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+static int launch_cfg(const IgemmArgs& a, hipStream_t s) {
+  if (a.bf16) return launch_cfg_t<BM, BN, WAVES_M, WAVES_N, true>(a, s);
+  return launch_cfg_t<BM, BN, WAVES_M, WAVES_N, false>(a, s);
 }
 
 static int tile_override() {
@@ -355,7 +402,7 @@ static int launch_igemm(const IgemmArgs& a, hipStream_t s) {
 }
 
 // Common part of the launch description.
-static void base_args(IgemmArgs& a, const float* x, const float* w, const float* bias, float* y, int hi, int wi, int ci,
+static void base_args(IgemmArgs& a, const void* x, const void* w, const float* bias, void* y, int hi, int wi, int ci,
                       int ho, int wo, int co, int tfull, int accumulate, int act, float slope) {
   a.x = x; a.w = w; a.bias = bias; a.y = y;
   a.hi = hi; a.wi = wi; a.ci = ci; a.ho = ho; a.wo = wo; a.co = co;
@@ -401,15 +448,19 @@ extern "C" double udaseg_conv_flops(const udaseg_conv_desc* d) {
   return 2.0 * (double)d->n * d->ho * d->wo * (double)d->co * (double)d->ci * d->kh * d->kw;
 }
 
-static int conv2d_fwd_impl(const udaseg_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
-                           int act, float slope, int accumulate, double* stats, const float* residual, void* stream) {
+static int conv2d_fwd_impl(const udaseg_conv_desc* d, const void* x, const void* w, const float* bias, void* y,
+                           int act, float slope, int accumulate, double* stats, const void* residual, void* stream,
+                           int bf16 = 0, int out_f32 = 0) {
   int rc = check_desc(d);
   if (rc) return rc;
   UDASEG_CHECK_ARG(x && w && y, "conv2d_fwd: NULL pointer");
+  UDASEG_CHECK_ARG(!bf16 || (d->ci % 8 == 0 && d->co % 8 == 0), "conv2d_fwd(bf16): channels must be multiples of 8 (ci=%d co=%d)",
+                   d->ci, d->co);
   hipStream_t st = as_stream(stream);
-  if (d->kh == d->kw && small_conv_applicable(d->kh, d->stride, d->pad, d->ci, d->co)) {
+  if (!bf16 && d->kh == d->kw && small_conv_applicable(d->kh, d->stride, d->pad, d->ci, d->co)) {
     prof_begin(0, st);
-    rc = launch_small_conv(x, w, bias, y, d->n, d->hi, d->wi, d->ci, d->co, 0, accumulate, act, slope, stats, residual, st);
+    rc = launch_small_conv(static_cast<const float*>(x), static_cast<const float*>(w), bias, static_cast<float*>(y), d->n,
+                           d->hi, d->wi, d->ci, d->co, 0, accumulate, act, slope, stats, static_cast<const float*>(residual), st);
     prof_end(0, st, udaseg_conv_flops(d), 0, d);
     return rc;
   }
@@ -426,7 +477,9 @@ static int conv2d_fwd_impl(const udaseg_conv_desc* d, const float* x, const floa
     }
   const int M = d->n * d->ho * d->wo;
   a.residual = residual;
-  const int ns = k_slices(M, d->co, ntaps, bias == nullptr && act == UDASEG_ACT_NONE && residual == nullptr);
+  a.bf16 = bf16;
+  a.out_f32 = out_f32;
+  const int ns = k_slices(M, d->co, ntaps, !bf16 && bias == nullptr && act == UDASEG_ACT_NONE && residual == nullptr);
   a.stats = (ns == 1) ? stats : nullptr;  // squares of partial sums do not add up: sliced launches take the separate pass
   a.nclass = ns;
   for (int c = 0; c < ns; ++c) {
@@ -445,8 +498,15 @@ static int conv2d_fwd_impl(const udaseg_conv_desc* d, const float* x, const floa
   }
   rc = launch_igemm(a, st);
   prof_end(0, st, udaseg_conv_flops(d), 0, d);
-  if (rc == UDASEG_OK && stats && ns > 1) rc = udaseg_bn_stats(y, (int64_t)M, d->co, stats, stream);
+  if (rc == UDASEG_OK && stats && ns > 1) rc = udaseg_bn_stats(static_cast<const float*>(y), (int64_t)M, d->co, stats, stream);
   return rc;
+}
+
+extern "C" int udaseg_conv2d_fwd_bf16(const udaseg_conv_desc* d, const void* x, const void* w, const float* bias,
+                                      const void* residual, void* y, int out_f32, int act, float slope, double* stats,
+                                      void* stream) {
+  UDASEG_CHECK_ARG(!(out_f32 && residual), "conv2d_fwd_bf16: residual with fp32 output is not supported");
+  return conv2d_fwd_impl(d, x, w, bias, y, act, slope, 0, stats, residual, stream, 1, out_f32);
 }
 
 extern "C" int udaseg_conv2d_fwd(const udaseg_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
@@ -465,18 +525,19 @@ extern "C" int udaseg_conv2d_fwd_bnstats(const udaseg_conv_desc* d, const float*
   return conv2d_fwd_impl(d, x, w, bias, y, UDASEG_ACT_NONE, 0.f, 0, stats, nullptr, stream);
 }
 
-extern "C" int udaseg_conv2d_dgrad(const udaseg_conv_desc* d, const float* dy, const float* w_t, float* dx,
-                                   int accumulate, void* stream) {
+static int conv2d_dgrad_impl(const udaseg_conv_desc* d, const void* dy, const void* w_t, void* dx, int accumulate,
+                             void* stream, int bf16) {
   int rc = check_desc(d);
   if (rc) return rc;
   UDASEG_CHECK_ARG(dy && w_t && dx, "conv2d_dgrad: NULL pointer");
+  UDASEG_CHECK_ARG(!bf16 || (d->ci % 8 == 0 && d->co % 8 == 0), "conv2d_dgrad(bf16): channels must be multiples of 8");
   hipStream_t st = as_stream(stream);
   const int s = d->stride;
   prof_begin(0, st);
-  if (d->kh == d->kw && small_conv_applicable(d->kh, d->stride, d->pad, d->co, d->ci)) {
+  if (!bf16 && d->kh == d->kw && small_conv_applicable(d->kh, d->stride, d->pad, d->co, d->ci)) {
     // dx = correlation of dy with the flipped taps; w_t is already [ci][9][co]
-    rc = launch_small_conv(dy, w_t, nullptr, dx, d->n, d->hi, d->wi, d->co, d->ci, 1, accumulate, UDASEG_ACT_NONE, 0.f, nullptr,
-                           nullptr, st);
+    rc = launch_small_conv(static_cast<const float*>(dy), static_cast<const float*>(w_t), nullptr, static_cast<float*>(dx), d->n,
+                           d->hi, d->wi, d->co, d->ci, 1, accumulate, UDASEG_ACT_NONE, 0.f, nullptr, nullptr, st);
     prof_end(0, st, udaseg_conv_flops(d), 1, d);
     return rc;
   }
@@ -509,7 +570,8 @@ extern "C" int udaseg_conv2d_dgrad(const udaseg_conv_desc* d, const float* dy, c
       ++nc;
     }
   a.nclass = nc;
-  if (s == 1 && nc == 1) {
+  a.bf16 = bf16;
+  if (s == 1 && nc == 1 && !bf16) {
     // single class: K-slices for the deep layers, as in the forward
     const int ntaps = a.ntaps[0];
     const int ns = k_slices(a.M[0], d->ci, ntaps, true);
@@ -523,7 +585,7 @@ extern "C" int udaseg_conv2d_dgrad(const udaseg_conv_desc* d, const float* dy, c
       a.nclass = ns;
       a.atomic_out = 1;
       if (!accumulate) {
-        hipError_t e = hipMemsetAsync(dx, 0, (size_t)d->n * d->hi * d->wi * d->ci * sizeof(float), st);
+        hipError_t e = hipMemsetAsync(dx, 0, (size_t)d->n * d->hi * d->wi * d->ci * sizeof(float), st);  // fp32 only
         if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(dgrad out)");
       }
     }
@@ -532,4 +594,14 @@ extern "C" int udaseg_conv2d_dgrad(const udaseg_conv_desc* d, const float* dy, c
   // dgrad FLOPs equal the forward's (every (pixel, tap, ci, co) product appears once)
   prof_end(0, st, udaseg_conv_flops(d), 1, d);
   return rc;
+}
+
+extern "C" int udaseg_conv2d_dgrad(const udaseg_conv_desc* d, const float* dy, const float* w_t, float* dx,
+                                   int accumulate, void* stream) {
+  return conv2d_dgrad_impl(d, dy, w_t, dx, accumulate, stream, 0);
+}
+
+extern "C" int udaseg_conv2d_dgrad_bf16(const udaseg_conv_desc* d, const void* dy, const void* w_t, void* dx, int accumulate,
+                                        void* stream) {
+  return conv2d_dgrad_impl(d, dy, w_t, dx, accumulate, stream, 1);
 }

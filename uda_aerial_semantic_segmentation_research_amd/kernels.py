@@ -67,6 +67,18 @@ def argmax_confusion(logits_base, target, pixels, classes, ldc, confusion, pred=
           "argmax_confusion")
 
 
+def conv2d_fwd_bf16(d, x, w, bias, residual, y, act=ACT_NONE, slope=0.0, stats=None, st=None):
+    """bf16 x / w / residual; y bf16, or fp32 when its dtype says so (logits)."""
+    check(_lib.load().udaseg_conv2d_fwd_bf16(_byref(d), x.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), y.data_ptr(),
+                                              int(y.dtype == torch.float32), act, slope, _ptr(stats),
+                                              st if st is not None else stream()), "conv2d_fwd_bf16")
+
+
+def conv2d_dgrad_bf16(d, dy, w_t, dx, accumulate=False, st=None):
+    check(_lib.load().udaseg_conv2d_dgrad_bf16(_byref(d), dy.data_ptr(), w_t.data_ptr(), dx.data_ptr(), int(accumulate),
+                                                st if st is not None else stream()), "conv2d_dgrad_bf16")
+
+
 def conv2d_dgrad(d, dy, w_t, dx, accumulate=False, st=None):
     check(_lib.load().udaseg_conv2d_dgrad(_byref(d), dy.data_ptr(), w_t.data_ptr(), dx.data_ptr(), int(accumulate),
                                            st if st is not None else stream()), "conv2d_dgrad")
