@@ -91,6 +91,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--layer-table", action="store_true", help="print TFLOP/s per conv shape (stderr)")
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="fp32 = BASELINE configs[1] (headline); bf16 = bf16 storage / MFMA with fp32 master (configs 3, 5), "
+                         "informational")
     ap.add_argument("--workload", default="segmentation", choices=["segmentation", "adversarial", "inference"],
                     help="segmentation = BASELINE configs[1] (headline); adversarial = configs[2]'s iteration "
                          "(adversarial_trainer.py:85-114) in fp32, reported for information")
@@ -117,7 +120,8 @@ def main():
     from uda_aerial_semantic_segmentation_research_amd.unet import Unet
 
     torch.manual_seed(1234)
-    model = Unet(encoder_name=args.encoder, encoder_weights=None, in_channels=3, classes=args.classes)
+    model = Unet(encoder_name=args.encoder, encoder_weights=None, in_channels=3, classes=args.classes,
+                 compute_dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32)
     if args.workload == "adversarial":
         from uda_aerial_semantic_segmentation_research_amd.adversarial_trainer import AdversarialTrainer
         trainer = AdversarialTrainer(model, dev, lambda_adv=0.001)
@@ -236,10 +240,10 @@ def main():
         value = imgs / dt
         conv_tflops = value * R18_CONV_GFLOP_PER_IMAGE / 1e3 / world if args.encoder == "resnet18" and args.size == 512 else None
         out = {
-            "metric": "training images/sec at 512x512" if args.workload == "segmentation"
-            else f"{args.workload} images/sec at 512x512 (informational, fp32)", "value": round(value, 2), "unit": "images/s", "n_gpus": world,
+            "metric": "training images/sec at 512x512" if args.workload == "segmentation" and args.dtype == "fp32"
+            else f"{args.workload} images/sec at 512x512 (informational, {args.dtype})", "value": round(value, 2), "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.encoder}-Unet source-only CE train step (zero_grad,fwd,CE,bwd,allreduce,Adam), "
                                    f"batch {args.batch}x3x{args.size}x{args.size} per GPU, {args.classes} classes, random init",
                        "global_batch": args.batch * world, "image": f"{args.size}x{args.size}", "parallelism": f"dp{world}",

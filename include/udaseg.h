@@ -70,6 +70,8 @@ int udaseg_conv2d_fwd_bf16(const udaseg_conv_desc* d, const void* x, const void*
                            void* y, int out_f32, int act, float slope, double* stats, void* stream);
 int udaseg_conv2d_dgrad_bf16(const udaseg_conv_desc* d, const void* dy, const void* w_t, void* dx, int accumulate,
                              void* stream);
+/* dw (fp32 master gradient) from bf16 x and dy */
+int udaseg_conv2d_wgrad_bf16(const udaseg_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate, void* stream);
 /* dx[n,hi,wi,ci] (+)= conv_transpose(dy, w).  w_t is the dgrad packing [ci][kh][kw][co] made by
  * udaseg_pack_dgrad_weights.  Autograd of the convs above: loss.backward() at train.py:343. */
 int udaseg_conv2d_dgrad(const udaseg_conv_desc* d, const float* dy, const float* w_t, float* dx, int accumulate,
@@ -176,6 +178,35 @@ int udaseg_adam_flat(float* p, const float* g, float* m, float* v, int64_t count
 /* ---- scratch: one caller-owned device buffer the library may use for split partial results (currently the
  *      small-channel weight gradient, <= 10 MiB).  Without it those calls take the generic atomics path. ---- */
 int udaseg_set_workspace(void* ptr, size_t bytes);
+
+/* ---- bf16 storage path (BASELINE configs 3 / 5): the HBM-bound kernels above on bf16 NHWC tensors (channels % 8 == 0),
+ *      arithmetic and statistics in fp32 / f64; same meaning as their fp32 namesakes.  Parameters, their gradients and the
+ *      optimizer state stay fp32 (master copies); udaseg_cast_f32_to_bf16 makes the per-step bf16 weight copy. ---- */
+int udaseg_bn_apply_bf16(const void* y, const double* sums, const float* gamma, const float* beta, const void* residual,
+                         void* z, int64_t pixels, int c, float eps, float momentum, float* running_mean, float* running_var,
+                         float* save_mean, float* save_rstd, int act, float slope, void* stream);
+int udaseg_bn_bwd_reduce_bf16(const void* dz, const void* z, const void* y, const float* save_mean, const float* save_rstd,
+                              int64_t pixels, int c, double* bsums, int act, float slope, void* stream);
+int udaseg_bn_bwd_apply_bf16(const void* dz, const void* z, const void* y, const float* save_mean, const float* save_rstd,
+                             const float* gamma, const double* bsums, void* dy, void* dres, float* dgamma, float* dbeta,
+                             int64_t pixels, int c, int act, float slope, int accumulate_dy, int accumulate_dres,
+                             int accumulate_param, void* stream);
+int udaseg_act_bwd_bf16(const void* dz, const void* z, void* dy, int64_t count, int act, float slope, void* stream);
+int udaseg_channel_sum_bf16(const void* x, int64_t pixels, int c, float* out, int accumulate, void* stream);
+int udaseg_nchw_to_nhwc_bf16(const float* x, void* y, int n, int c, int h, int w, int cpad, void* stream);
+int udaseg_cast_f32_to_bf16(const float* x, void* y, int64_t count, void* stream);
+int udaseg_maxpool3x3s2_fwd_bf16(const void* x, void* y, uint8_t* idx, int n, int h, int w, int c, void* stream);
+int udaseg_maxpool3x3s2_bwd_bf16(const void* dy, const uint8_t* idx, void* dx, int n, int h, int w, int c, int accumulate,
+                                 void* stream);
+int udaseg_upsample2x_concat_bwd_bf16(const void* dout, void* da, void* dskip, int n, int h, int w, int ca, int cb,
+                                      int accumulate_da, int accumulate_dskip, void* stream);
+int udaseg_gap_partial_bf16(const void* z, float* partial, int n, int hw, int c, void* stream);
+int udaseg_gap_finish(const float* partial, const float* w, const float* b, float* pooled, float* p, int n, int hw, int c,
+                      void* stream);
+int udaseg_gap_bwd_broadcast_bf16(const float* dp, const float* p, const float* w, void* dz, int n, int hw, int c, void* stream);
+int udaseg_gap_bwd_param(const float* dp, const float* p, const float* pooled, float* dw, float* db, int n, int c,
+                         int accumulate_param, void* stream);
+int udaseg_pack_dgrad_batched_bf16(const float* arena, void* packed, const int* table, int entries, void* stream);
 
 /* ---- small utilities ---- */
 int udaseg_fill_f32(float* p, int64_t count, float value, void* stream);

@@ -86,6 +86,205 @@ def test_conv_bf16_fwd_dgrad(K, case):
     dx = torch.empty((n, h, w, ci), device="cuda", dtype=torch.bfloat16)
     K.conv2d_dgrad_bf16(d, nhwc_bf(dy), wtp, dx)
     close(nchw32(dx), xr.grad, "bf16 dgrad")
+    # wgrad: fp32 master gradient from bf16 operands (ds_read_b64_tr_b16 fragments)
+    wr = wt.clone().requires_grad_(True)
+    F.conv2d(x, wr, None, stride=s, padding=p).backward(dy)
+    dw = torch.full((co, k, k, ci), float("nan"), device="cuda")
+    K.conv2d_wgrad_bf16(d, xd, nhwc_bf(dy), dw)
+    close(dw.cpu().permute(0, 3, 1, 2), wr.grad, "bf16 wgrad", 1e-4)
+    dw2 = torch.full((co, k, k, ci), 0.25, device="cuda")
+    K.conv2d_wgrad_bf16(d, xd, nhwc_bf(dy), dw2, accumulate=True)
+    close(dw2.cpu().permute(0, 3, 1, 2), wr.grad + 0.25, "bf16 wgrad + acc", 1e-4)
     dx2 = torch.full((n, h, w, ci), 0.5, device="cuda", dtype=torch.bfloat16)
     K.conv2d_dgrad_bf16(d, nhwc_bf(dy), wtp, dx2, accumulate=True)
     close(nchw32(dx2), xr.grad + 0.5, "bf16 dgrad + acc")
+
+
+def bf(t):  # NCHW cpu fp32 -> NHWC cuda bf16
+    return t.permute(0, 2, 3, 1).contiguous().to("cuda", torch.bfloat16)
+
+
+@pytest.mark.parametrize("c", [16, 64, 512])
+@pytest.mark.parametrize("act,slope,with_res", [(0, 0.0, False), (1, 0.0, True), (1, 0.2, False)])
+def test_bn_bf16_fwd_bwd(K, c, act, slope, with_res):
+    n, h, w = (2, 6, 10) if c > 64 else (4, 24, 20)
+    g = torch.Generator().manual_seed(c + act)
+    x = rb(torch.randn(n, c, h, w, generator=g) * 2 + 0.5).requires_grad_(True)
+    res = rb(torch.randn(n, c, h, w, generator=g)).requires_grad_(True) if with_res else None
+    bn = torch.nn.BatchNorm2d(c).train()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(c, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(c, generator=g))
+    rm0, rv0 = bn.running_mean.clone(), bn.running_var.clone()
+    u = bn(x)
+    if with_res:
+        u = u + res
+    z_ref = F.leaky_relu(u, slope) if act else u
+    dz = rb(torch.randn(z_ref.shape, generator=g))
+    z_ref.backward(dz)
+    yd = bf(x.detach())
+    R = K.bn_replicas()
+    sums = torch.zeros(2 * c * R, dtype=torch.float64, device="cuda")
+    xs = x.detach().double().permute(0, 2, 3, 1).reshape(-1, c)
+    sums[:c] = xs.sum(0).cuda()                     # statistics normally come from the conv epilogue (fp32 accumulators)
+    sums[c:2 * c] = (xs * xs).sum(0).cuda()
+    z = torch.empty_like(yd)
+    rm, rv = rm0.cuda(), rv0.cuda()
+    sm, sr = torch.empty(c, device="cuda"), torch.empty(c, device="cuda")
+    gam, bet = bn.weight.detach().cuda(), bn.bias.detach().cuda()
+    resd = bf(res.detach()) if with_res else None
+    K.bn_apply(yd, sums, gam, bet, resd, z, bn.eps, bn.momentum, rm, rv, sm, sr, act, slope)
+    close(nchw32(z), z_ref.detach(), "bn bf16 fwd")
+    close(rm.cpu(), bn.running_mean, "running_mean", 1e-5)
+    close(rv.cpu(), bn.running_var, "running_var", 1e-5)
+    bs = torch.zeros(2 * c * R, dtype=torch.float64, device="cuda")
+    K.bn_bwd_reduce(bf(dz), z, yd, sm, sr, bs, act, slope)
+    dy = torch.empty_like(yd)
+    dres = torch.empty_like(yd) if with_res else None
+    dg, db = torch.empty(c, device="cuda"), torch.empty(c, device="cuda")
+    K.bn_bwd_apply(bf(dz), z, yd, sm, sr, gam, bs, dy, dres, dg, db, act, slope)
+    # masks come from the bf16-rounded z: a handful of near-zero pre-activations can flip -> compare norm-wise, loosely
+    close(nchw32(dy), x.grad, "bn bf16 dx", 4 * BF_TOL)
+    close(dg.cpu(), bn.weight.grad, "bn bf16 dgamma", 4 * BF_TOL)
+    close(db.cpu(), bn.bias.grad, "bn bf16 dbeta", 4 * BF_TOL)
+    if with_res:
+        close(nchw32(dres), res.grad, "bn bf16 dres", 4 * BF_TOL)
+
+
+def test_pool_resize_layout_bf16(K):
+    g = torch.Generator().manual_seed(1)
+    x = rb(torch.relu(torch.randn(2, 64, 16, 12, generator=g))).requires_grad_(True)
+    y_ref = F.max_pool2d(x, 3, 2, 1)
+    dy = rb(torch.randn(y_ref.shape, generator=g))
+    y_ref.backward(dy)
+    y, idx = K.maxpool_fwd(bf(x.detach()))
+    assert y.dtype == torch.bfloat16 and torch.equal(nchw32(y), y_ref.detach())
+    dx = torch.empty((2, 16, 12, 64), device="cuda", dtype=torch.bfloat16)
+    K.maxpool_bwd(bf(dy), idx, dx)
+    close(nchw32(dx), x.grad, "maxpool bf16 bwd")
+    a = rb(torch.randn(2, 32, 5, 6, generator=g)).requires_grad_(True)
+    s = rb(torch.randn(2, 16, 10, 12, generator=g)).requires_grad_(True)
+    ref = torch.cat([F.interpolate(a, scale_factor=2.0, mode="nearest"), s], dim=1)
+    dout = rb(torch.randn(ref.shape, generator=g))
+    ref.backward(dout)
+    out = K.upsample2x_concat_fwd(bf(a.detach()), bf(s.detach()))
+    assert torch.equal(nchw32(out), ref.detach())
+    da = torch.empty((2, 5, 6, 32), device="cuda", dtype=torch.bfloat16)
+    ds = torch.empty((2, 10, 12, 16), device="cuda", dtype=torch.bfloat16)
+    K.upsample2x_concat_bwd(bf(dout), da, ds, 32, 16)
+    close(nchw32(da), a.grad, "upcat bf16 da")
+    assert torch.equal(nchw32(ds), s.grad)
+    img = torch.randn(3, 3, 10, 14, generator=g)
+    yb = K.nchw_to_nhwc(img.cuda(), dtype=torch.bfloat16)
+    assert yb.shape == (3, 10, 14, 8) and torch.equal(yb[..., :3].float().cpu(), rb(img).permute(0, 2, 3, 1))
+    assert float(yb[..., 3:].float().abs().max()) == 0.0
+    v = torch.randn(4096, generator=g)
+    assert torch.equal(K.cast_to_bf16(v.cuda()).cpu(), v.to(torch.bfloat16))
+
+
+def _net_pair_bf16(name):
+    from oracle.unet_ref import UnetRef
+    from uda_aerial_semantic_segmentation_research_amd.unet import Unet
+    torch.manual_seed(1234)
+    ref = UnetRef(name, classes=23).train()
+    net = Unet(encoder_name=name, encoder_weights=None, in_channels=3, classes=23, compute_dtype=torch.bfloat16)
+    net.load_state_dict(ref.state_dict())
+    return ref, net.to("cuda").train()
+
+
+@pytest.mark.parametrize("name,size", [("resnet18", 128), ("resnet50", 128)])
+def test_unet_bf16_vs_fp32_oracle(K, name, size):
+    """bf16 storage / bf16 MFMA against the fp32 CPU oracle.  Stated tolerance ('bf16 configs compared to the
+    fp32 CPU result with a stated, looser tolerance'): the logits may be no farther from the fp32 oracle than 1.5x what
+    PyTorch's OWN bf16 execution of the same oracle is (measured in the test: 9e-2 for r18, 0.22 for r50 at random init,
+    norm-wise -- a 30-60-layer train-mode-BN net amplifies bf16 rounding that much); loss 1e-2; gradients of the shallow
+    tensors: head 0.05 norm-wise / cosine >= 0.995, last decoder conv 0.25 / 0.97; deeper gradients go through thousands of
+    flipped ReLU mask bits at bf16 resolution (see test_gpu_model.py): finite, and as aligned with the fp32 gradients (median
+    cosine over the tensors) as PyTorch's own bf16 backward is."""
+    import copy
+    from oracle.adversarial_ref import synthetic_batch
+    from uda_aerial_semantic_segmentation_research_amd.losses import CrossEntropyLoss
+    from uda_aerial_semantic_segmentation_research_amd.optim import FusedAdam
+    ref, net = _net_pair_bf16(name)
+    x, y, _ = synthetic_batch(2, size, size, seed=0)
+    t16 = copy.deepcopy(ref).bfloat16()
+    torch_bf16 = t16(x.bfloat16()).float()
+    F.cross_entropy(torch_bf16, y).backward()              # PyTorch's own bf16 forward/backward of the oracle, for scale
+    torch_bf16 = torch_bf16.detach()
+    logits_ref = ref(x)
+    loss_ref = F.cross_entropy(logits_ref, y)
+    loss_ref.backward()
+    e_torch = ((torch_bf16 - logits_ref.detach()).abs().max() / logits_ref.abs().max()).item()
+    opt = FusedAdam(net.parameters(), lr=1e-4)
+    logits = net(x.cuda())
+    assert logits.dtype == torch.float32 and logits.shape == logits_ref.shape
+    loss = CrossEntropyLoss()(logits, y.cuda())
+    loss.backward()
+    e = ((logits.detach().cpu() - logits_ref.detach()).abs().max() / logits_ref.abs().max()).item()
+    assert e <= 1.5 * e_torch + 1e-2, f"bf16 logits rel err {e:.3e} vs torch-bf16 {e_torch:.3e}"
+    assert abs(loss.item() - loss_ref.item()) <= 1e-2 * loss_ref.item()
+    gref = dict(ref.named_parameters())
+
+    def cosine(u, v):
+        u, v = u.double().flatten(), v.double().flatten()
+        return (u @ v / (u.norm() * v.norm()).clamp_min(1e-300)).item()
+    torch_cos = sorted(cosine(p16.grad, gref[k].grad) for k, p16 in t16.named_parameters())
+    cosines = []
+    for k, p in net.named_parameters():
+        assert p.grad is not None and p.grad.dtype == torch.float32 and torch.isfinite(p.grad).all(), k
+        a, b = p.grad.detach().double().cpu().flatten(), gref[k].grad.double().flatten()
+        cos = (a @ b / (a.norm() * b.norm()).clamp_min(1e-300)).item()
+        cosines.append(cos)
+        rel = ((a - b).abs().max() / b.abs().max()).item()
+        if k.startswith("segmentation_head"):                 # nothing but the loss behind it
+            assert rel <= 0.05 and cos >= 0.995, f"{k}: rel {rel:.3e} cos {cos:.4f}"
+        elif k.startswith("decoder.blocks.4.conv2"):          # one BN+ReLU behind it: ~1e3 mask bits flip at bf16 resolution
+            assert rel <= 0.25 and cos >= 0.97, f"{k}: rel {rel:.3e} cos {cos:.4f}"
+    cosines.sort()
+    med, tmed = cosines[len(cosines) // 2], torch_cos[len(torch_cos) // 2]
+    print(f"{name} bf16: logits rel err {e:.2e} (torch bf16 on CPU: {e_torch:.2e}); gradient cosine vs fp32 oracle: "
+          f"min {cosines[0]:.3f} median {med:.3f} (torch bf16: min {torch_cos[0]:.3f} median {tmed:.3f})")
+    # at random init bf16 rounding scrambles deep gradients for ANY implementation (torch's own bf16 backward: median cosine
+    # 0.81 for r18, 0.12 for r50): be at least as aligned with the fp32 gradients as PyTorch's bf16 run, minus a margin
+    assert med >= tmed - 0.15, (med, tmed)
+    opt.step()
+    losses = []
+    for _ in range(8):
+        opt.zero_grad()
+        l = CrossEntropyLoss()(net(x.cuda()), y.cuda())
+        l.backward()
+        opt.step()
+        losses.append(l.item())
+    assert losses[-1] < losses[0], losses
+    # eval mode (BatchNorm folded, bf16)
+    net.eval()
+    ref.eval()
+    with torch.no_grad():
+        ref.load_state_dict({k: v.cpu() for k, v in net.state_dict().items()})
+        oe, oref = net(x.cuda()).cpu(), ref(x)
+        oref16 = copy.deepcopy(ref).bfloat16()(x.bfloat16()).float()
+    e_eval, e_eval_torch = (((t - oref).abs().max() / oref.abs().max()).item() for t in (oe, oref16))
+    assert e_eval <= 1.5 * e_eval_torch + 1e-2, (e_eval, e_eval_torch)
+
+
+def test_adversarial_iteration_bf16(K):
+    from uda_aerial_semantic_segmentation_research_amd.adversarial_trainer import AdversarialTrainer
+    from uda_aerial_semantic_segmentation_research_amd.optim import FusedAdam
+    from uda_aerial_semantic_segmentation_research_amd.unet import Unet
+    from oracle.adversarial_ref import (AdversarialLossRef, DomainDiscriminatorRef, adversarial_step, synthetic_batch)
+    from oracle.unet_ref import UnetRef
+    torch.manual_seed(1234)
+    ref = UnetRef("resnet18", classes=23).train()
+    Dr = DomainDiscriminatorRef(3).train()
+    net = Unet("resnet18", encoder_weights=None, in_channels=3, classes=23, compute_dtype=torch.bfloat16)
+    net.load_state_dict(ref.state_dict())
+    tr = AdversarialTrainer(net, torch.device("cuda"), lambda_adv=0.001)
+    assert tr.discriminator.compute_dtype == torch.bfloat16
+    tr.discriminator.load_state_dict(Dr.state_dict())
+    src, masks, tgt = synthetic_batch(2, 128, 128, seed=0)
+    opt = FusedAdam(net.parameters(), lr=1e-4)
+    avg, dm = tr.train_epoch([(src, masks)], [tgt], opt, epoch=1)
+    r = adversarial_step(ref, Dr, AdversarialLossRef(0.001), torch.optim.Adam(ref.parameters(), lr=1e-4),
+                         torch.optim.Adam(Dr.parameters(), lr=1e-4), src, masks, tgt)
+    for k in ("seg_loss", "d_loss", "adv_loss"):
+        assert abs(tr.last_losses[k] - r[k].item()) <= 2e-2 * abs(r[k].item()) + 1e-6, (k, tr.last_losses[k], r[k].item())

@@ -34,6 +34,7 @@ SIGNATURES = {
     "udaseg_conv2d_fwd_fused": (_I, [_D, _P, _P, _P, _P, _P, _I, _F, _P]),
     "udaseg_conv2d_fwd_bf16": (_I, [_D, _P, _P, _P, _P, _P, _I, _I, _F, _P, _P]),
     "udaseg_conv2d_dgrad_bf16": (_I, [_D, _P, _P, _P, _I, _P]),
+    "udaseg_conv2d_wgrad_bf16": (_I, [_D, _P, _P, _P, _I, _P]),
     "udaseg_conv2d_dgrad": (_I, [_D, _P, _P, _P, _I, _P]),
     "udaseg_conv2d_wgrad": (_I, [_D, _P, _P, _P, _I, _P]),
     "udaseg_pack_dgrad_weights": (_I, [_D, _P, _P, _P]),
@@ -63,6 +64,21 @@ SIGNATURES = {
     "udaseg_bce_logits_fwd": (_I, [_P, _I, _F, _F, _P, _I, _P]),
     "udaseg_bce_logits_bwd": (_I, [_P, _I, _F, _F, _P, _P, _I, _P]),
     "udaseg_adam_flat": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _P]),
+    "udaseg_bn_apply_bf16": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _F, _F, _P, _P, _P, _P, _I, _F, _P]),
+    "udaseg_bn_bwd_reduce_bf16": (_I, [_P, _P, _P, _P, _P, _L, _I, _P, _I, _F, _P]),
+    "udaseg_bn_bwd_apply_bf16": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _I, _I, _I, _P]),
+    "udaseg_act_bwd_bf16": (_I, [_P, _P, _P, _L, _I, _F, _P]),
+    "udaseg_channel_sum_bf16": (_I, [_P, _L, _I, _P, _I, _P]),
+    "udaseg_nchw_to_nhwc_bf16": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "udaseg_cast_f32_to_bf16": (_I, [_P, _P, _L, _P]),
+    "udaseg_maxpool3x3s2_fwd_bf16": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "udaseg_maxpool3x3s2_bwd_bf16": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "udaseg_upsample2x_concat_bwd_bf16": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "udaseg_gap_partial_bf16": (_I, [_P, _P, _I, _I, _I, _P]),
+    "udaseg_gap_finish": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "udaseg_gap_bwd_broadcast_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "udaseg_gap_bwd_param": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "udaseg_pack_dgrad_batched_bf16": (_I, [_P, _P, _P, _I, _P]),
     "udaseg_set_workspace": (_I, [_P, C.c_size_t]),
     "udaseg_fill_f32": (_I, [_P, _L, _F, _P]),
     "udaseg_axpy_f32": (_I, [_P, _P, _L, _F, _P]),

@@ -39,7 +39,7 @@ def _drop_channel_axis(masks):
 class AdversarialTrainer(SegmentationTrainer):
     def __init__(self, model, device, lambda_adv=0.001):
         super().__init__(model, device)
-        self.discriminator = DomainDiscriminator().to(device)
+        self.discriminator = DomainDiscriminator(compute_dtype=getattr(model, "compute_dtype", torch.float32)).to(device)
         self.adversarial_loss = AdversarialLoss(lambda_adv)
         self.domain_metrics = DomainAdaptationMetrics()
         self.discriminator_optimizer = None      # created on first use, see train_epoch

@@ -62,6 +62,41 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
+// Per-channel f64 accumulators are replicated BN_REPLICAS times ([R][2][C]); block b adds into replica b % R and the
+// consumer sums the replicas.  Same-address memory-side atomics serialise (~100 ns each): 2048 blocks on one address
+// cost ~130 us per launch (measured, profiles/r01_kernel_stats_first.csv); 512 blocks over 16 replicas = 32 per address.
+constexpr int BN_REPLICAS = 16;
+constexpr int REDUCE_MAX_BLOCKS = 512;
+
+struct StreamShape {
+  int bs;      // threads per block (multiple of 64... or of C4 when C4 is not a power of two)
+  int grid;
+  int c4;
+};
+
+// Choose block/grid so grid*bs is a multiple of c4 (see header comment).
+static inline StreamShape stream_shape(int64_t n4, int c4, int max_blocks = 2048) {
+  StreamShape s;
+  s.c4 = c4;
+  int unit;  // grid must be a multiple of `unit`
+  if (c4 <= 256) {
+    s.bs = (256 / c4) * c4;
+    unit = 1;
+  } else {
+    s.bs = 256;
+    unit = (c4 + 255) / 256;
+    while ((unit * 256) % c4 != 0) ++unit;  // c4 = 512 -> 2
+  }
+  int64_t want = (n4 + (int64_t)s.bs * 4 - 1) / ((int64_t)s.bs * 4);  // ~4 float4 per thread
+  if (want > max_blocks) want = max_blocks;
+  if (want < 1) want = 1;
+  s.grid = (int)(((want + unit - 1) / unit) * unit);
+  // every channel quad needs an owning thread among the first c4 global threads
+  while ((int64_t)s.grid * s.bs < c4) s.grid += unit;
+  return s;
+}
+
+
 // small-channel direct 3x3 kernels (conv_small.hip)
 bool small_conv_applicable(int k, int stride, int pad, int ci_gather, int co_out);
 int launch_small_conv(const float* x, const float* w, const float* bias, float* y, int n, int h, int wd, int ci, int co,

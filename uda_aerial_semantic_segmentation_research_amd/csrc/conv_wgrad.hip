@@ -21,8 +21,8 @@
 namespace udaseg {
 
 struct WgradArgs {
-  const float* x;
-  const float* dy;
+  const void* x;    // fp32, or bf16 for conv_wgrad_bf16_kernel
+  const void* dy;
   float* dw;
   int hi, wi, ci, ho, wo, co;
   int kw, stride, pad;
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     for (int p = 0; p < A_PASS; ++p) {
       const int m = mb + arow + A_ROWS * p;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (a_ok && m < kend) v = *reinterpret_cast<const f32x4*>(a.dy + (size_t)m * a.co + a_co);
+      if (a_ok && m < kend) v = *reinterpret_cast<const f32x4*>(static_cast<const float*>(a.dy) + (size_t)m * a.co + a_co);
       ra[p] = v;
     }
 #pragma unroll
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
         const int oy = t1 - ni * a.ho;
         const int iy = oy * a.stride + b_dy, ix = ox * a.stride + b_dx;
         if ((unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi)
-          v = *reinterpret_cast<const f32x4*>(a.x + ((size_t)(ni * a.hi + iy) * a.wi + ix) * (size_t)a.ci + b_c);
+          v = *reinterpret_cast<const f32x4*>(static_cast<const float*>(a.x) + ((size_t)(ni * a.hi + iy) * a.wi + ix) * (size_t)a.ci + b_c);
       }
       rb[p] = v;
     }
@@ -163,8 +163,158 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------- bf16 storage
+// Same GEMM with bf16 x / dy and fp32 dW (master gradients).  GEMM-K is the pixel axis = the STRIDED axis of both operands
+// ([pixel][channel] in memory and in LDS), while v_mfma_f32_32x32x16_bf16 wants 8 consecutive K values per lane: fragments
+// are read with ds_read_b64_tr_b16 (per 16 lanes: a 4-pixel x 16-channel block delivered channel-major), two reads per
+// fragment.  LDS rows carry a 16-byte pad so the 4 rows of a block fall on distinct banks.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
+constexpr int WBKB = 32;  // pixels per K-tile (two 16-deep MFMA steps)
+
+__device__ __forceinline__ bf16x8w tr_fragment(const unsigned short* row0, int ld) {
+  // row0: this lane's address in the first 4-row block; the second block is 4 rows further down
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(row0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(row0 + 4 * ld));
+  const s16x8 f = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8w, f);
+}
+
 template <int BMW, int BNW, int WAVES_M, int WAVES_N>
-static int launch_wgrad(WgradArgs a, int accumulate, hipStream_t s) {
+__global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradArgs a) {
+  constexpr int WM = BMW / WAVES_M, WN = BNW / WAVES_N;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int LDA = BMW + 8, LDB = BNW + 8;         // elements per LDS row (16-byte pad)
+  constexpr int AQ = BMW / 8, BQ = BNW / 8;            // 16-byte vectors per row
+  constexpr int A_ROWS = 256 / AQ, B_ROWS = 256 / BQ;
+  constexpr int A_PASS = (WBKB + A_ROWS - 1) / A_ROWS, B_PASS = (WBKB + B_ROWS - 1) / B_ROWS;
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+
+  __shared__ __attribute__((aligned(16))) unsigned short As[2][WBKB][LDA];
+  __shared__ __attribute__((aligned(16))) unsigned short Bs[2][WBKB][LDB];
+  const unsigned short* xg = reinterpret_cast<const unsigned short*>(a.x);
+  const unsigned short* dyg = reinterpret_cast<const unsigned short*>(a.dy);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int wm = (wave / WAVES_N) * WM, wn = (wave % WAVES_N) * WN;
+  // transposed-read roles inside the 16-lane group
+  const int grp = lane >> 4, cb = 16 * (grp & 1), hk = grp >> 1, tq = (lane & 15) >> 2, tp = lane & 3;
+
+  const int ntj = (a.J + BNW - 1) / BNW;
+  const int co0 = (blockIdx.x / ntj) * BMW;
+  const int j0 = (blockIdx.x % ntj) * BNW;
+  const int kbeg = blockIdx.y * a.kchunk;
+  const int kend = min(a.M, kbeg + a.kchunk);
+
+  const int aq = tid % AQ, arow = tid / AQ;
+  const int a_co = co0 + aq * 8;
+  const bool a_ok = a_co < a.co;
+  const int bq = tid % BQ, brow = tid / BQ;
+  const int j = j0 + bq * 8;
+  const bool b_ok = j < a.J;
+  int b_dy = 0, b_dx = 0, b_c = 0;
+  if (b_ok) {
+    const int tap = fast_div(j, a.ci, a.inv_ci);
+    b_c = j - tap * a.ci;
+    const int r = fast_div(tap, a.kw, a.inv_kw);
+    b_dy = r - a.pad;
+    b_dx = (tap - r * a.kw) - a.pad;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[i][jn][v] = 0.f;
+
+  f32x4 ra[A_PASS], rb[B_PASS];
+  const int nkt = (kend - kbeg + WBKB - 1) / WBKB;
+
+  auto load_tile = [&](int kt) {
+    const int mb = kbeg + kt * WBKB;
+#pragma unroll
+    for (int p = 0; p < A_PASS; ++p) {
+      const int row = arow + A_ROWS * p, m = mb + row;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (a_ok && row < WBKB && m < kend) v = *reinterpret_cast<const f32x4*>(dyg + (size_t)m * a.co + a_co);
+      ra[p] = v;
+    }
+#pragma unroll
+    for (int p = 0; p < B_PASS; ++p) {
+      const int row = brow + B_ROWS * p, m = mb + row;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (b_ok && row < WBKB && m < kend) {
+        const int t1 = fast_div(m, a.wo, a.inv_wo);
+        const int ox = m - t1 * a.wo;
+        const int ni = fast_div(t1, a.ho, a.inv_ho);
+        const int oy = t1 - ni * a.ho;
+        const int iy = oy * a.stride + b_dy, ix = ox * a.stride + b_dx;
+        if ((unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi)
+          v = *reinterpret_cast<const f32x4*>(xg + ((size_t)(ni * a.hi + iy) * a.wi + ix) * (size_t)a.ci + b_c);
+      }
+      rb[p] = v;
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < A_PASS; ++p)
+      if (arow + A_ROWS * p < WBKB) *reinterpret_cast<f32x4*>(&As[buf][arow + A_ROWS * p][aq * 8]) = ra[p];
+#pragma unroll
+    for (int p = 0; p < B_PASS; ++p)
+      if (brow + B_ROWS * p < WBKB) *reinterpret_cast<f32x4*>(&Bs[buf][brow + B_ROWS * p][bq * 8]) = rb[p];
+  };
+
+  if (nkt > 0) {
+    load_tile(0);
+    store_tile(0);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const bool more = (kt + 1) < nkt;
+    if (more) load_tile(kt + 1);
+#pragma unroll
+    for (int ks = 0; ks < WBKB / 16; ++ks) {
+      bf16x8w af[TM], bfr[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = tr_fragment(&As[cur][16 * ks + 8 * hk + tq][wm + 32 * i + cb + 4 * tp], LDA);
+#pragma unroll
+      for (int jn = 0; jn < TN; ++jn) bfr[jn] = tr_fragment(&Bs[cur][16 * ks + 8 * hk + tq][wn + 32 * jn + cb + 4 * tp], LDB);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn)
+          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[jn], acc[i][jn], 0, 0, 0);
+    }
+    if (more) store_tile(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int co = co0 + wm + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
+      if (co >= a.co) continue;
+#pragma unroll
+      for (int jn = 0; jn < TN; ++jn) {
+        const int jj = j0 + wn + jn * 32 + lr;
+        if (jj < a.J) {
+          float* dst = a.dw + (size_t)co * a.J + jj;
+          if (a.use_atomic) atomicAdd(dst, acc[i][jn][v]);
+          else *dst = acc[i][jn][v];
+        }
+      }
+    }
+}
+
+template <int BMW, int BNW, int WAVES_M, int WAVES_N>
+static int launch_wgrad(WgradArgs a, int accumulate, hipStream_t s, bool bf16 = false) {
   const int tiles = cdiv(a.co, BMW) * cdiv(a.J, BNW);
   // enough blocks for ~4 per CU, at least 256 pixels per split (UDASEG_WGRAD_BLOCKS: tuning aid)
   static int target = -1;
@@ -187,8 +337,13 @@ static int launch_wgrad(WgradArgs a, int accumulate, hipStream_t s) {
   }
   dim3 grid((unsigned)tiles, (unsigned)splits), block(256);
   hipEvent_t ev = kprof_begin(s);
-  hipLaunchKernelGGL((conv_wgrad_kernel<BMW, BNW, WAVES_M, WAVES_N>), grid, block, 0, s, a);
-  kprof_end(BMW == 64 ? 7 : 8, ev, s, 2.0 * (double)a.M * a.co * a.J);
+  if (bf16) {
+    hipLaunchKernelGGL((conv_wgrad_bf16_kernel<BMW, BNW, WAVES_M, WAVES_N>), grid, block, 0, s, a);
+    kprof_end(13, ev, s, 2.0 * (double)a.M * a.co * a.J);
+  } else {
+    hipLaunchKernelGGL((conv_wgrad_kernel<BMW, BNW, WAVES_M, WAVES_N>), grid, block, 0, s, a);
+    kprof_end(BMW == 64 ? 7 : 8, ev, s, 2.0 * (double)a.M * a.co * a.J);
+  }
   UDASEG_LAUNCH_CHECK("conv_wgrad launch");
   return UDASEG_OK;
 }
@@ -219,6 +374,27 @@ extern "C" int udaseg_conv2d_wgrad(const udaseg_conv_desc* d, const float* x, co
     rc = launch_small_wgrad(x, dy, dw, d->n, d->hi, d->wi, d->ci, d->co, accumulate, st);
   else if (d->co > 32) rc = launch_wgrad<64, 64, 2, 2>(a, accumulate, st);
   else rc = launch_wgrad<32, 128, 1, 4>(a, accumulate, st);
+  prof_end(1, st, udaseg_conv_flops(d), 2, d);
+  return rc;
+}
+
+extern "C" int udaseg_conv2d_wgrad_bf16(const udaseg_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate,
+                                        void* stream) {
+  UDASEG_CHECK_ARG(d && x && dy && dw, "conv2d_wgrad_bf16: NULL pointer");
+  UDASEG_CHECK_ARG(d->ci % 8 == 0 && d->co % 8 == 0 && d->ci > 0 && d->co > 0, "conv2d_wgrad_bf16: channels must be multiples of 8");
+  UDASEG_CHECK_ARG(d->kh > 0 && d->kw > 0 && d->stride >= 1, "conv2d_wgrad_bf16: bad kernel/stride");
+  UDASEG_CHECK_ARG((long long)d->n * d->hi * d->wi * d->ci < (1LL << 31) && (long long)d->n * d->ho * d->wo * d->co < (1LL << 31),
+                   "conv2d_wgrad_bf16: tensor exceeds 2^31 elements");
+  WgradArgs a = {};
+  a.x = x; a.dy = dy; a.dw = dw;
+  a.hi = d->hi; a.wi = d->wi; a.ci = d->ci; a.ho = d->ho; a.wo = d->wo; a.co = d->co;
+  a.kw = d->kw; a.stride = d->stride; a.pad = d->pad;
+  a.M = d->n * d->ho * d->wo;
+  a.J = d->kh * d->kw * d->ci;
+  a.inv_ci = 1.0f / d->ci; a.inv_kw = 1.0f / d->kw; a.inv_wo = 1.0f / d->wo; a.inv_ho = 1.0f / d->ho;
+  hipStream_t st = as_stream(stream);
+  prof_begin(1, st);
+  const int rc = launch_wgrad<64, 64, 2, 2>(a, accumulate, st, true);
   prof_end(1, st, udaseg_conv_flops(d), 2, d);
   return rc;
 }

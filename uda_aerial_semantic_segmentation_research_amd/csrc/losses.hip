@@ -434,6 +434,25 @@ extern "C" int udaseg_gap_linear_sigmoid_bwd(const float* dp, const float* p, co
   return UDASEG_OK;
 }
 
+// dtype-independent stages of the tail, for the bf16 path (its pooling partials / broadcast live in elem_bf16.hip)
+extern "C" int udaseg_gap_finish(const float* partial, const float* w, const float* b, float* pooled, float* p, int n, int hw,
+                                 int c, void* stream) {
+  UDASEG_CHECK_ARG(partial && w && b && pooled && p && n > 0 && hw > 0 && c > 0, "gap_finish: bad arguments");
+  hipLaunchKernelGGL(gap_linear_sigmoid_kernel, dim3(n), dim3(256), 0, as_stream(stream), partial, w, b, pooled, p, hw, c,
+                     udaseg_gap_splits(hw));
+  UDASEG_LAUNCH_CHECK("gap_finish launch");
+  return UDASEG_OK;
+}
+
+extern "C" int udaseg_gap_bwd_param(const float* dp, const float* p, const float* pooled, float* dw, float* db, int n, int c,
+                                    int accumulate_param, void* stream) {
+  UDASEG_CHECK_ARG(dp && p && pooled && dw && db && n > 0 && c > 0, "gap_bwd_param: bad arguments");
+  hipLaunchKernelGGL(gap_bwd_param_kernel, dim3((c + 255) / 256), dim3(256), 0, as_stream(stream), dp, p, pooled, dw, db, n, c,
+                     accumulate_param);
+  UDASEG_LAUNCH_CHECK("gap_bwd_param launch");
+  return UDASEG_OK;
+}
+
 extern "C" int udaseg_bce_logits_fwd(const float* x, int n, float label, float weight, float* loss, int accumulate,
                                      void* stream) {
   UDASEG_CHECK_ARG(x && loss && n > 0, "bce_logits_fwd: bad arguments");

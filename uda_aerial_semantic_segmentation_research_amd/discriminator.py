@@ -48,7 +48,7 @@ class _DiscFunction(torch.autograd.Function):
 
 
 class DomainDiscriminator(ArenaModule):
-    def __init__(self, input_channels=3):
+    def __init__(self, input_channels=3, compute_dtype=torch.float32):
         super().__init__()
         widths = (64, 128, 256, 512)
         layers, cin = [], input_channels
@@ -65,6 +65,8 @@ class DomainDiscriminator(ArenaModule):
         self.classifier = nn.Sequential(nn.Identity(), nn.Identity(), LinearP(cin, 1), nn.Identity())
         self.input_channels = input_channels
         self.build_arena()
+        if compute_dtype != torch.float32:
+            self.set_compute_dtype(compute_dtype)
 
     def _layers(self):
         f = self.features
@@ -85,7 +87,7 @@ class DomainDiscriminator(ArenaModule):
     def _forward_plan(self, x, save):
         P = Plan(self, self.training, save)
         conv0, blocks, lin = self._layers()
-        x4 = K.nchw_to_nhwc(x, ceil4(self.input_channels), P.st)
+        x4 = K.nchw_to_nhwc(x, conv0.cin_p, P.st, dtype=P.adt)
         a0, d0 = P.conv(conv0, x4, ACT_LEAKY, SLOPE)     # bias + LeakyReLU fused into the conv epilogue
         h, recs = a0, []
         for conv, bn in blocks:

@@ -27,6 +27,10 @@ def ceil4(c):
     return (c + 3) // 4 * 4
 
 
+def ceil_to(c, a):
+    return (c + a - 1) // a * a
+
+
 class ConvP(nn.Module):
     """Parameter holder for one convolution (logical OIHW ``weight``, optional ``bias``); no forward of its own."""
 
@@ -36,14 +40,15 @@ class ConvP(nn.Module):
         self.weight = nn.Parameter(torch.empty(cout, cin, k, k))
         self.bias = nn.Parameter(torch.empty(cout)) if bias else None
         self.needs_dgrad = True
+        self.align = 4          # physical channel granule: 4 (fp32 storage) or 8 (bf16 storage), set by the owning network
 
     @property
     def cin_p(self):
-        return ceil4(self.cin)
+        return ceil_to(self.cin, self.align)
 
     @property
     def cout_p(self):
-        return ceil4(self.cout)
+        return ceil_to(self.cout, self.align)
 
     def extra_repr(self):
         return f"{self.cin}, {self.cout}, kernel_size={self.k}, stride={self.stride}, padding={self.pad}, bias={self.bias is not None}"
@@ -79,6 +84,20 @@ class ArenaModule(nn.Module):
         self._nbt = None            # int64 arena of the BN num_batches_tracked counters
         self._idx = {}
         self._nbn = 0
+        self.compute_dtype = torch.float32
+
+    def set_compute_dtype(self, dtype):
+        """torch.float32 (default; BASELINE configs 1-2, 4) or torch.bfloat16 (configs 3, 5): bf16 activations / weight
+        copies / MFMA with fp32 accumulation, statistics, master weights, gradients and optimizer state."""
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("compute_dtype must be torch.float32 or torch.bfloat16")
+        self.compute_dtype = dtype
+        for m in self.modules():
+            if isinstance(m, ConvP):
+                m.align = 8 if dtype == torch.bfloat16 else 4
+        if self._arena is not None:
+            self.build_arena()          # physical channel padding changed: re-lay the arena (values are preserved)
+        return self
 
     # ---- arena construction ------------------------------------------------------------------------------------
     def _phys_shape(self, owner, name, p):
@@ -148,7 +167,7 @@ class ArenaModule(nn.Module):
             if isinstance(m, ConvP) and m.needs_dgrad:
                 self._wt_off[id(m)] = woff
                 woff += m.cout_p * m.k * m.k * m.cin_p
-        self._wt_arena = torch.empty(max(woff, 4), device=device, dtype=torch.float32)
+        self._wt_arena = torch.empty(max(woff, 8), device=device, dtype=self.compute_dtype)
         rows = []
         for m in self.modules():
             if isinstance(m, ConvP) and m.needs_dgrad:
@@ -244,6 +263,10 @@ class Plan:
         dev = net._arena.device
         self.R = K.bn_replicas()
         K.ensure_workspace(dev)
+        self.adt = net.compute_dtype                      # activation storage type
+        self.bf16 = self.adt == torch.bfloat16
+        # bf16 storage: one cast of the whole fp32 master arena per forward (same offsets / physical shapes)
+        self.w16 = K.cast_to_bf16(net._arena, st=self.st) if self.bf16 else None
         nbn = net._nbn
         self.dev = dev
         if training:
@@ -263,7 +286,7 @@ class Plan:
     # -- parameter access
     def w(self, conv):
         o, n, shp = self.idx[(id(conv), "weight")]
-        return self.net._arena[o:o + n].view(shp)
+        return (self.w16 if self.bf16 else self.net._arena)[o:o + n].view(shp)
 
     def b(self, conv):
         o, n, shp = self.idx[(id(conv), "bias")]
@@ -285,11 +308,11 @@ class Plan:
         return self.idx[(id(mod), name)][0]
 
     # -- forward pieces
-    def conv(self, conv, x, act=ACT_NONE, slope=0.0):
+    def conv(self, conv, x, act=ACT_NONE, slope=0.0, out_dtype=None):
         n, h, w, ci = x.shape
         assert ci == conv.cin_p, (ci, conv.cin_p)
         d = K.conv_desc(n, h, w, ci, conv.cout_p, conv.k, conv.stride, conv.pad)
-        y = torch.empty((n, d.ho, d.wo, conv.cout_p), device=x.device, dtype=torch.float32)
+        y = torch.empty((n, d.ho, d.wo, conv.cout_p), device=x.device, dtype=out_dtype or self.adt)
         K.conv2d_fwd(d, x, self.w(conv), self.b(conv) if conv.bias is not None else None, y, act, slope, False, self.st)
         return y, d
 
@@ -322,7 +345,7 @@ class Plan:
         if self.training:
             n, h, w, ci = x.shape
             d = K.conv_desc(n, h, w, ci, conv.cout_p, conv.k, conv.stride, conv.pad)
-            y = torch.empty((n, d.ho, d.wo, conv.cout_p), device=x.device, dtype=torch.float32)
+            y = torch.empty((n, d.ho, d.wo, conv.cout_p), device=x.device, dtype=self.adt)
             sums = self._next_stats(ceil4(bn.c))
             K.conv2d_fwd_bnstats(d, x, self.w(conv), self.b(conv) if conv.bias is not None else None, y, sums[0], self.st)
             z, ms = self.bn(bn, y, act, slope, residual, sums)
@@ -335,9 +358,12 @@ class Plan:
             c = ceil4(bn.c)
             bf = self.fold_b[self._fold_off:self._fold_off + c]
             self._fold_off += c
-            K.bn_fold(self.w(conv), self.b(conv) if conv.bias is not None else None, self.pvec(bn, "weight"),
+            w32 = self.net._arena[o:o + nel].view(shp)
+            K.bn_fold(w32, self.b(conv) if conv.bias is not None else None, self.pvec(bn, "weight"),
                       self.pvec(bn, "bias"), bn.running_mean, bn.running_var, bn.eps, wf, bf, self.st)
-            z = torch.empty((n, d.ho, d.wo, conv.cout_p), device=x.device, dtype=torch.float32)
+            if self.bf16:
+                wf = K.cast_to_bf16(wf, st=self.st)
+            z = torch.empty((n, d.ho, d.wo, conv.cout_p), device=x.device, dtype=self.adt)
             K.conv2d_fwd_fused(d, x, wf, bf, residual, z, act, slope, self.st)
             return z, None
         rec = (conv, bn, d, x, y, z, ms, act, slope) if self.save else None

@@ -40,16 +40,23 @@ def conv_desc(n, hi, wi, ci, co, k, stride, pad):
 
 
 def conv2d_fwd(d, x, w, bias, y, act=ACT_NONE, slope=0.0, accumulate=False, st=None):
+    if x.dtype == torch.bfloat16:
+        assert not accumulate
+        return conv2d_fwd_bf16(d, x, w, bias, None, y, act, slope, None, st)
     check(_lib.load().udaseg_conv2d_fwd(_byref(d), x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), act, slope,
                                          int(accumulate), st if st is not None else stream()), "conv2d_fwd")
 
 
 def conv2d_fwd_bnstats(d, x, w, bias, y, stats, st=None):
+    if x.dtype == torch.bfloat16:
+        return conv2d_fwd_bf16(d, x, w, bias, None, y, ACT_NONE, 0.0, stats, st)
     check(_lib.load().udaseg_conv2d_fwd_bnstats(_byref(d), x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(),
                                                  stats.data_ptr(), st if st is not None else stream()), "conv2d_fwd_bnstats")
 
 
 def conv2d_fwd_fused(d, x, w, bias, residual, y, act=ACT_NONE, slope=0.0, st=None):
+    if x.dtype == torch.bfloat16:
+        return conv2d_fwd_bf16(d, x, w, bias, residual, y, act, slope, None, st)
     check(_lib.load().udaseg_conv2d_fwd_fused(_byref(d), x.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), y.data_ptr(),
                                                act, slope, st if st is not None else stream()), "conv2d_fwd_fused")
 
@@ -79,12 +86,21 @@ def conv2d_dgrad_bf16(d, dy, w_t, dx, accumulate=False, st=None):
                                                 st if st is not None else stream()), "conv2d_dgrad_bf16")
 
 
+def conv2d_wgrad_bf16(d, x, dy, dw, accumulate=False, st=None):
+    check(_lib.load().udaseg_conv2d_wgrad_bf16(_byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), int(accumulate),
+                                                st if st is not None else stream()), "conv2d_wgrad_bf16")
+
+
 def conv2d_dgrad(d, dy, w_t, dx, accumulate=False, st=None):
+    if dy.dtype == torch.bfloat16:
+        return conv2d_dgrad_bf16(d, dy, w_t, dx, accumulate, st)
     check(_lib.load().udaseg_conv2d_dgrad(_byref(d), dy.data_ptr(), w_t.data_ptr(), dx.data_ptr(), int(accumulate),
                                            st if st is not None else stream()), "conv2d_dgrad")
 
 
 def conv2d_wgrad(d, x, dy, dw, accumulate=False, st=None):
+    if x.dtype == torch.bfloat16:
+        return conv2d_wgrad_bf16(d, x, dy, dw, accumulate, st)
     check(_lib.load().udaseg_conv2d_wgrad(_byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), int(accumulate),
                                            st if st is not None else stream()), "conv2d_wgrad")
 
@@ -94,7 +110,20 @@ def pack_dgrad_weights(d, w, w_t, st=None):
                                                  st if st is not None else stream()), "pack_dgrad_weights")
 
 
+def cast_to_bf16(x, out=None, st=None):
+    """fp32 -> bf16 (round to nearest even), flat; numel must be a multiple of 8."""
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
+    check(_lib.load().udaseg_cast_f32_to_bf16(x.data_ptr(), out.data_ptr(), x.numel(), st if st is not None else stream()),
+          "cast_f32_to_bf16")
+    return out
+
+
 def pack_dgrad_batched(arena, packed, table, st=None):
+    if packed.dtype == torch.bfloat16:
+        check(_lib.load().udaseg_pack_dgrad_batched_bf16(arena.data_ptr(), packed.data_ptr(), table.data_ptr(), table.shape[0],
+                                                          st if st is not None else stream()), "pack_dgrad_batched_bf16")
+        return
     check(_lib.load().udaseg_pack_dgrad_batched(arena.data_ptr(), packed.data_ptr(), table.data_ptr(), table.shape[0],
                                                  st if st is not None else stream()), "pack_dgrad_batched")
 
@@ -103,12 +132,18 @@ def conv_flops(d):
     return _lib.load().udaseg_conv_flops(_byref(d))
 
 
-def nchw_to_nhwc(x, cpad=None, st=None):
-    """[N,C,H,W] contiguous -> [N,H,W,cpad] (zero-padded channels)."""
+def nchw_to_nhwc(x, cpad=None, st=None, dtype=torch.float32):
+    """[N,C,H,W] contiguous fp32 -> [N,H,W,cpad] (zero-padded channels), fp32 or bf16."""
     n, c, h, w = x.shape
-    cpad = cpad or ((c + 3) // 4) * 4
     if not x.is_contiguous():
         x = x.contiguous()
+    if dtype == torch.bfloat16:
+        cpad = cpad or ((c + 7) // 8) * 8
+        y = torch.empty((n, h, w, cpad), device=x.device, dtype=torch.bfloat16)
+        check(_lib.load().udaseg_nchw_to_nhwc_bf16(x.data_ptr(), y.data_ptr(), n, c, h, w, cpad,
+                                                    st if st is not None else stream()), "nchw_to_nhwc_bf16")
+        return y
+    cpad = cpad or ((c + 3) // 4) * 4
     y = torch.empty((n, h, w, cpad), device=x.device, dtype=torch.float32)
     check(_lib.load().udaseg_nchw_to_nhwc(x.data_ptr(), y.data_ptr(), n, c, h, w, cpad,
                                            st if st is not None else stream()), "nchw_to_nhwc")
@@ -134,6 +169,12 @@ def bn_stats(y, sums, st=None):
 def bn_apply(y, sums, gamma, beta, residual, z, eps, momentum, running_mean, running_var, save_mean, save_rstd, act, slope,
              st=None):
     c = y.shape[-1]
+    if y.dtype == torch.bfloat16:
+        check(_lib.load().udaseg_bn_apply_bf16(y.data_ptr(), sums.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(residual),
+                                                z.data_ptr(), y.numel() // c, c, eps, momentum, _ptr(running_mean),
+                                                _ptr(running_var), _ptr(save_mean), _ptr(save_rstd), act, slope,
+                                                st if st is not None else stream()), "bn_apply_bf16")
+        return
     check(_lib.load().udaseg_bn_apply(y.data_ptr(), sums.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(residual),
                                        z.data_ptr(), y.numel() // c, c, eps, momentum, _ptr(running_mean), _ptr(running_var),
                                        _ptr(save_mean), _ptr(save_rstd), act, slope,
@@ -149,6 +190,11 @@ def bn_apply_eval(y, gamma, beta, running_mean, running_var, residual, z, eps, a
 
 def bn_bwd_reduce(dz, z, y, save_mean, save_rstd, bsums, act, slope, st=None):
     c = y.shape[-1]
+    if y.dtype == torch.bfloat16:
+        check(_lib.load().udaseg_bn_bwd_reduce_bf16(dz.data_ptr(), _ptr(z), y.data_ptr(), save_mean.data_ptr(),
+                                                     save_rstd.data_ptr(), y.numel() // c, c, bsums.data_ptr(), act, slope,
+                                                     st if st is not None else stream()), "bn_bwd_reduce_bf16")
+        return
     check(_lib.load().udaseg_bn_bwd_reduce(dz.data_ptr(), _ptr(z), y.data_ptr(), save_mean.data_ptr(), save_rstd.data_ptr(),
                                             y.numel() // c, c, bsums.data_ptr(), act, slope,
                                             st if st is not None else stream()), "bn_bwd_reduce")
@@ -157,6 +203,13 @@ def bn_bwd_reduce(dz, z, y, save_mean, save_rstd, bsums, act, slope, st=None):
 def bn_bwd_apply(dz, z, y, save_mean, save_rstd, gamma, bsums, dy, dres, dgamma, dbeta, act, slope, accumulate_dy=False,
                  accumulate_dres=False, accumulate_param=False, st=None):
     c = y.shape[-1]
+    if y.dtype == torch.bfloat16:
+        check(_lib.load().udaseg_bn_bwd_apply_bf16(dz.data_ptr(), _ptr(z), y.data_ptr(), save_mean.data_ptr(),
+                                                    save_rstd.data_ptr(), gamma.data_ptr(), bsums.data_ptr(), dy.data_ptr(),
+                                                    _ptr(dres), _ptr(dgamma), _ptr(dbeta), y.numel() // c, c, act, slope,
+                                                    int(accumulate_dy), int(accumulate_dres), int(accumulate_param),
+                                                    st if st is not None else stream()), "bn_bwd_apply_bf16")
+        return
     check(_lib.load().udaseg_bn_bwd_apply(dz.data_ptr(), _ptr(z), y.data_ptr(), save_mean.data_ptr(), save_rstd.data_ptr(),
                                            gamma.data_ptr(), bsums.data_ptr(), dy.data_ptr(), _ptr(dres), _ptr(dgamma),
                                            _ptr(dbeta), y.numel() // c, c, act, slope, int(accumulate_dy),
@@ -165,12 +218,20 @@ def bn_bwd_apply(dz, z, y, save_mean, save_rstd, gamma, bsums, dy, dres, dgamma,
 
 
 def act_bwd(dz, z, dy, act, slope, st=None):
+    if dz.dtype == torch.bfloat16:
+        check(_lib.load().udaseg_act_bwd_bf16(dz.data_ptr(), z.data_ptr(), dy.data_ptr(), dz.numel(), act, slope,
+                                               st if st is not None else stream()), "act_bwd_bf16")
+        return
     check(_lib.load().udaseg_act_bwd(dz.data_ptr(), z.data_ptr(), dy.data_ptr(), dz.numel(), act, slope,
                                       st if st is not None else stream()), "act_bwd")
 
 
 def channel_sum(x, out, accumulate=False, st=None):
     c = x.shape[-1]
+    if x.dtype == torch.bfloat16:
+        check(_lib.load().udaseg_channel_sum_bf16(x.data_ptr(), x.numel() // c, c, out.data_ptr(), int(accumulate),
+                                                   st if st is not None else stream()), "channel_sum_bf16")
+        return
     check(_lib.load().udaseg_channel_sum(x.data_ptr(), x.numel() // c, c, out.data_ptr(), int(accumulate),
                                           st if st is not None else stream()), "channel_sum")
 
@@ -178,8 +239,12 @@ def channel_sum(x, out, accumulate=False, st=None):
 def maxpool_fwd(x, st=None):
     n, h, w, c = x.shape
     ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
-    y = torch.empty((n, ho, wo, c), device=x.device, dtype=torch.float32)
+    y = torch.empty((n, ho, wo, c), device=x.device, dtype=x.dtype)
     idx = torch.empty((n, ho, wo, c), device=x.device, dtype=torch.uint8)
+    if x.dtype == torch.bfloat16:
+        check(_lib.load().udaseg_maxpool3x3s2_fwd_bf16(x.data_ptr(), y.data_ptr(), idx.data_ptr(), n, h, w, c,
+                                                        st if st is not None else stream()), "maxpool_fwd_bf16")
+        return y, idx
     check(_lib.load().udaseg_maxpool3x3s2_fwd(x.data_ptr(), y.data_ptr(), idx.data_ptr(), n, h, w, c,
                                                st if st is not None else stream()), "maxpool_fwd")
     return y, idx
@@ -187,6 +252,10 @@ def maxpool_fwd(x, st=None):
 
 def maxpool_bwd(dy, idx, dx, accumulate=False, st=None):
     n, h, w, c = dx.shape
+    if dx.dtype == torch.bfloat16:
+        check(_lib.load().udaseg_maxpool3x3s2_bwd_bf16(dy.data_ptr(), idx.data_ptr(), dx.data_ptr(), n, h, w, c, int(accumulate),
+                                                        st if st is not None else stream()), "maxpool_bwd_bf16")
+        return
     check(_lib.load().udaseg_maxpool3x3s2_bwd(dy.data_ptr(), idx.data_ptr(), dx.data_ptr(), n, h, w, c, int(accumulate),
                                                st if st is not None else stream()), "maxpool_bwd")
 
@@ -194,7 +263,9 @@ def maxpool_bwd(dy, idx, dx, accumulate=False, st=None):
 def upsample2x_concat_fwd(a, skip, st=None):
     n, h, w, ca = a.shape
     cb = 0 if skip is None else skip.shape[-1]
-    out = torch.empty((n, 2 * h, 2 * w, ca + cb), device=a.device, dtype=torch.float32)
+    out = torch.empty((n, 2 * h, 2 * w, ca + cb), device=a.device, dtype=a.dtype)
+    if a.dtype == torch.bfloat16:      # pure data movement in 16-byte vectors: 8 bf16 channels == 4 fp32 "channels"
+        ca, cb = ca // 2, cb // 2
     check(_lib.load().udaseg_upsample2x_concat_fwd(a.data_ptr(), _ptr(skip), out.data_ptr(), n, h, w, ca, cb,
                                                     st if st is not None else stream()), "upsample2x_concat_fwd")
     return out
@@ -202,6 +273,11 @@ def upsample2x_concat_fwd(a, skip, st=None):
 
 def upsample2x_concat_bwd(dout, da, dskip, ca, cb, accumulate_da=False, accumulate_dskip=False, st=None):
     n, h2, w2, _ = dout.shape
+    if dout.dtype == torch.bfloat16:
+        check(_lib.load().udaseg_upsample2x_concat_bwd_bf16(dout.data_ptr(), _ptr(da), _ptr(dskip), n, h2 // 2, w2 // 2, ca, cb,
+                                                             int(accumulate_da), int(accumulate_dskip),
+                                                             st if st is not None else stream()), "upsample2x_concat_bwd_bf16")
+        return
     check(_lib.load().udaseg_upsample2x_concat_bwd(dout.data_ptr(), _ptr(da), _ptr(dskip), n, h2 // 2, w2 // 2, ca, cb,
                                                     int(accumulate_da), int(accumulate_dskip),
                                                     st if st is not None else stream()), "upsample2x_concat_bwd")
@@ -225,6 +301,12 @@ def gap_linear_sigmoid_fwd(z, w, b, st=None):
     partial = torch.empty((n, splits, c), device=z.device, dtype=torch.float32)
     pooled = torch.empty((n, c), device=z.device, dtype=torch.float32)
     p = torch.empty((n, 1), device=z.device, dtype=torch.float32)
+    if z.dtype == torch.bfloat16:
+        sv = st if st is not None else stream()
+        check(_lib.load().udaseg_gap_partial_bf16(z.data_ptr(), partial.data_ptr(), n, hw, c, sv), "gap_partial_bf16")
+        check(_lib.load().udaseg_gap_finish(partial.data_ptr(), w.data_ptr(), b.data_ptr(), pooled.data_ptr(), p.data_ptr(), n, hw,
+                                             c, sv), "gap_finish")
+        return p, pooled
     check(_lib.load().udaseg_gap_linear_sigmoid_fwd(z.data_ptr(), w.data_ptr(), b.data_ptr(), partial.data_ptr(),
                                                      pooled.data_ptr(), p.data_ptr(), n, hw, c,
                                                      st if st is not None else stream()), "gap_linear_sigmoid_fwd")
@@ -233,6 +315,13 @@ def gap_linear_sigmoid_fwd(z, w, b, st=None):
 
 def gap_linear_sigmoid_bwd(dp, p, pooled, w, dz, dw, db, accumulate_param=False, st=None):
     n, h, wd, c = dz.shape
+    if dz.dtype == torch.bfloat16:
+        sv = st if st is not None else stream()
+        check(_lib.load().udaseg_gap_bwd_broadcast_bf16(dp.data_ptr(), p.data_ptr(), w.data_ptr(), dz.data_ptr(), n, h * wd, c, sv),
+              "gap_bwd_broadcast_bf16")
+        check(_lib.load().udaseg_gap_bwd_param(dp.data_ptr(), p.data_ptr(), pooled.data_ptr(), dw.data_ptr(), db.data_ptr(), n, c,
+                                                int(accumulate_param), sv), "gap_bwd_param")
+        return
     check(_lib.load().udaseg_gap_linear_sigmoid_bwd(dp.data_ptr(), p.data_ptr(), pooled.data_ptr(), w.data_ptr(), dz.data_ptr(),
                                                      dw.data_ptr(), db.data_ptr(), n, h * wd, c, int(accumulate_param),
                                                      st if st is not None else stream()), "gap_linear_sigmoid_bwd")

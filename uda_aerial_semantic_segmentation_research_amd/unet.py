@@ -195,7 +195,8 @@ class Unet(ArenaModule):
     """smp.Unet-shaped factory (same keyword arguments as the reference's call sites)."""
 
     def __init__(self, encoder_name="resnet34", encoder_depth=5, encoder_weights=None, decoder_use_batchnorm=True,
-                 decoder_channels=DECODER_CHANNELS, in_channels=3, classes=1, activation=None, **unused):
+                 decoder_channels=DECODER_CHANNELS, in_channels=3, classes=1, activation=None,
+                 compute_dtype=torch.float32, **unused):
         super().__init__()
         if encoder_name not in ENCODERS:
             raise ValueError(f"unsupported encoder {encoder_name!r}; available: {sorted(ENCODERS)}")
@@ -220,6 +221,8 @@ class Unet(ArenaModule):
             warnings.warn("encoder_weights='imagenet' needs a download; offline build keeps the seeded random init "
                           "(pass a state_dict path to load pretrained weights)")
         self.build_arena()
+        if compute_dtype != torch.float32:
+            self.set_compute_dtype(compute_dtype)
 
     # ------------------------------------------------------------------------------------------------ forward
     def forward(self, x):
@@ -243,7 +246,7 @@ class Unet(ArenaModule):
         P = Plan(self, self.training, save)
         enc = self.encoder
         tape = []
-        x4 = K.nchw_to_nhwc(x, ceil4(self.in_channels), P.st)
+        x4 = K.nchw_to_nhwc(x, enc.conv1.cin_p, P.st, dtype=P.adt)
         f1, r_stem = P.conv_bn_act(enc.conv1, enc.bn1, x4, *RELU)
         pooled, pidx = K.maxpool_fwd(f1, P.st)
         feats = [f1]
@@ -259,7 +262,7 @@ class Unet(ArenaModule):
             h, rec = blk.fwd(P, h, skip)
             tape.append((blk, rec, h))
         head = self.segmentation_head[0]
-        logits, d_head = P.conv(head, h)
+        logits, d_head = P.conv(head, h, out_dtype=torch.float32)     # logits stay fp32 (loss accuracy) in every mode
         if self.training:
             self.tick_batchnorm_counters()
         if not save:
@@ -287,6 +290,8 @@ class Unet(ArenaModule):
         dh, _ = G.slot(h_last)
         from .losses import COLSUM_SIDE_TABLE
         dbias = COLSUM_SIDE_TABLE.pop(dl.data_ptr(), None)     # made by ce_bwd in the same pass as dl, when it was
+        if P.bf16:
+            dl = K.cast_to_bf16(dl, st=P.st)                   # the head's dgrad / wgrad take bf16 operands
         P.conv_bwd(head, d_head, h_last, dl, dx=dh, dx_acc=False, dbias=dbias)
         hook = self.grad_ready_hook
         if hook is not None:
