@@ -150,6 +150,35 @@ int udaseg_ce_fwd(const float* logits, const int64_t* target, int64_t pixels, in
 int udaseg_ce_bwd(const float* logits, const int64_t* target, const float* lse, const float* grad_out, int64_t pixels,
                   int classes, int ldc, float* dlogits, float* colsum_partials, float* colsum, void* stream);
 
+/* ---- the reference's other segmentation losses (src/models/losses.py), same logits layout as udaseg_ce_* (ldc <= 32) ----
+ * udaseg_seg_partials(): doubles of scratch the *_fwd calls below need in `partials`. */
+int udaseg_seg_partials(void);
+/* DiceLoss (losses.py:110-152): softmax over classes, per image b and class c
+ *   I = sum_pix p_c*[t==c], U = sum_pix p_c + sum_pix [t==c]; loss = 1 - mean_{b,c} (2I+smooth)/(U+smooth).
+ * sums: batch*3*classes doubles, caller-zeroed; coef: batch*2*classes floats kept for udaseg_dice_bwd. */
+int udaseg_dice_fwd(const float* logits, const int64_t* target, int batch, int64_t pix_per_image, int classes, int ldc,
+                    float smooth, double* sums, float* coef, float* loss, void* stream);
+/* dlogits (+)= (*grad_out) * weight * dLoss/dlogits (grad_out may be NULL = 1); pad channels written as 0 */
+int udaseg_dice_bwd(const float* logits, const int64_t* target, const float* coef, const float* grad_out, float weight,
+                    int batch, int64_t pix_per_image, int classes, int ldc, float* dlogits, int accumulate, void* stream);
+/* focal term of WeightedSegmentationLoss (losses.py:181-197): ce = w[t]*(-log softmax_t) (class_weights may be NULL),
+ * pt = exp(-ce), f = alpha*(1-pt)^gamma*ce; loss (+)= mean (mean=1) or sum (mean=0) of f over pixels */
+int udaseg_focal_fwd(const float* logits, const int64_t* target, const float* class_weights, float alpha, float gamma,
+                     int64_t pixels, int classes, int ldc, int mean, double* partials, float* loss, int accumulate,
+                     void* stream);
+/* dlogits (+)= (*grad_out) * weight * df/dlogits per pixel (the caller folds 1/pixels into weight for 'mean') */
+int udaseg_focal_bwd(const float* logits, const int64_t* target, const float* class_weights, float alpha, float gamma,
+                     const float* grad_out, float weight, int64_t pixels, int classes, int ldc, float* dlogits,
+                     int accumulate, void* stream);
+/* ConsistencyLoss (losses.py:53-108): p_i = softmax(z_i / T);
+ * loss = (KL(p2||p1) + KL(p1||p2)) / (2 * batch)  (F.kl_div(..., reduction='batchmean') both ways, averaged) */
+int udaseg_consistency_fwd(const float* z1, const float* z2, float temperature, int batch, int64_t pixels, int classes,
+                           int ldc, double* partials, float* loss, void* stream);
+/* gradients with respect to BOTH predictions (the reference detaches neither); d1 or d2 may be NULL */
+int udaseg_consistency_bwd(const float* z1, const float* z2, float temperature, const float* grad_out, float weight,
+                           int batch, int64_t pixels, int classes, int ldc, float* d1, float* d2, int accumulate,
+                           void* stream);
+
 /* ---- validation metrics (SegmentationTrainer.calculate_metrics, train.py:225-243; src/analysis/metrics.py:17-29):
  * confusion[t*classes + argmax(logits[p])] += 1 over all pixels (int64, caller-zeroed); pred[p] = argmax (optional).
  * classes <= 32, ldc <= 32. */

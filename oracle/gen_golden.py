@@ -10,6 +10,8 @@ runs them on seeded inputs and stores inputs' seeds + expected outputs (data onl
 no reference source text) in:
 
 * ``tests/golden/adversarial_ref.npz``  -- produced by the REFERENCE's own classes;
+* ``tests/golden/losses_ref.npz``       -- produced by the REFERENCE's ``ConsistencyLoss`` / ``DiceLoss`` /
+  ``WeightedSegmentationLoss`` / ``FineTuningLoss`` / ``calculate_class_weights`` (values and autograd gradients, fp64 and fp32);
 * ``tests/golden/unet_oracle.npz``      -- produced by ``oracle.unet_ref.UnetRef`` (the
   encoder-decoder is third-party upstream): a regression anchor for the
   oracle and a travelling fixture for the GPU tests.  Its structure is pinned
@@ -186,7 +188,90 @@ def gen_unet():
     print("unet_oracle.npz:", len(out), "arrays")
 
 
+def gen_losses():
+    """Reference loss family on seeded inputs: values + input gradients, float64 (the parity anchor) and float32."""
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    from src.models import losses as R                        # reference
+    from oracle import losses_ref as O
+
+    out = {}
+    torch.set_num_threads(1)
+
+    def close(a, b, what):
+        a, b = a.detach().double(), b.detach().double()
+        err = (a - b).abs().max().item() / max(b.abs().max().item(), 1e-300)
+        assert err < 1e-12, (what, err)
+
+    cases = {"c23": dict(seed=11, batch=2, classes=23, h=12, w=10), "c5": dict(seed=12, batch=3, classes=5, h=7, w=9),
+             "c2": dict(seed=13, batch=1, classes=2, h=4, w=4)}
+    for name, kw in cases.items():
+        out[f"{name}/shape"] = np.array([kw["seed"], kw["batch"], kw["classes"], kw["h"], kw["w"]])
+        for dt, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+            z1, z2, target, weights, domain = O.loss_inputs(dtype=dt, **kw)
+            c = kw["classes"]
+
+            def run(fn, *inputs):
+                leaves = [t.clone().requires_grad_(True) for t in inputs]
+                val = fn(*leaves)
+                val.backward()
+                return val.detach(), [t.grad for t in leaves]
+
+            pairs = {
+                "dice": (lambda z: R.DiceLoss()(z, target), lambda z: O.DiceLossRef()(z, target), (z1,)),
+                "dice_smooth": (lambda z: R.DiceLoss(smooth=0.1)(z, target), lambda z: O.DiceLossRef(0.1)(z, target), (z1,)),
+                "focal": (lambda z: R.WeightedSegmentationLoss(c, weights).focal_loss(z, target),
+                          lambda z: O.WeightedSegmentationLossRef(c, weights).focal_loss(z, target), (z1,)),
+                "wseg": (lambda z: R.WeightedSegmentationLoss(c, weights)(z, target, 0.7),
+                         lambda z: O.WeightedSegmentationLossRef(c, weights)(z, target, 0.7), (z1,)),
+                "wseg_sum": (lambda z: R.WeightedSegmentationLoss(c, torch.ones(c, dtype=dt), alpha=0.5, gamma=1.5, reduction='sum')(z, target),
+                             lambda z: O.WeightedSegmentationLossRef(c, None, 0.5, 1.5, 'sum')(z, target), (z1,)),
+                "cons": (lambda a, b: R.ConsistencyLoss()(a, b), lambda a, b: O.ConsistencyLossRef()(a, b), (z1, z2)),
+                "cons_t2": (lambda a, b: R.ConsistencyLoss(2.0)(a, b), lambda a, b: O.ConsistencyLossRef(2.0)(a, b), (z1, z2)),
+                "fine": (lambda a, b, d, s: R.FineTuningLoss()(a, b, d, 10, s, target)['total'],
+                         lambda a, b, d, s: O.FineTuningLossRef()(a, b, d, 10, s, target)['total'], (z1, z2, domain, z2)),
+            }
+            for key, (ref_fn, ora_fn, inputs) in pairs.items():
+                v, grads = run(ref_fn, *inputs)
+                if dt == torch.float64:
+                    v2, grads2 = run(ora_fn, *inputs)
+                    close(v2, v, (name, key))
+                    for g2, g in zip(grads2, grads):
+                        close(g2, g, (name, key, "grad"))
+                out[f"{name}/{tag}/{key}/value"] = v.numpy()
+                if dt == torch.float64:                     # gradients: the float64 run is the anchor
+                    for i, g in enumerate(grads):
+                        out[f"{name}/{tag}/{key}/grad{i}"] = g.numpy()
+            if dt == torch.float64:
+                ft_r = R.FineTuningLoss(0.8, 0.2, 0.3, rampup_length=8)
+                ft_o = O.FineTuningLossRef(0.8, 0.2, 0.3, rampup_length=8)
+                for epoch in (0, 3, 8, 50):
+                    d_r = ft_r(z1, z2, domain, epoch, z2, target.float())
+                    d_o = ft_o(z1, z2, domain, epoch, z2, target.float())
+                    assert sorted(d_r) == sorted(d_o)
+                    for k in d_r:
+                        close(d_o[k], d_r[k], (name, "fine_dict", epoch, k))
+                    out[f"{name}/fine_dict/{epoch}"] = np.array([d_r[k].item() for k in sorted(d_r)])
+                d_r = ft_r(z1, z2, domain, 3)              # no labelled samples
+                out[f"{name}/fine_dict/unsup"] = np.array([d_r[k].item() for k in sorted(d_r)])
+                out[f"{name}/fine_dict/keys"] = np.array(sorted(d_r))
+    # class weights from a toy dataset, both methods
+    g = torch.Generator().manual_seed(5)
+    ds = [(None, torch.randint(0, 6, (9, 11), generator=g)) for _ in range(4)]
+    for method in ("effective_samples", "inverse_freq"):
+        w_r = R.calculate_class_weights(ds, 7, method)
+        assert torch.equal(w_r, O.calculate_class_weights_ref(ds, 7, method))
+        out[f"class_weights/{method}"] = w_r.numpy()
+    out["restatement_agrees_1e-12"] = np.bool_(True)
+    np.savez_compressed(os.path.join(GOLD, "losses_ref.npz"), **out)
+    print("losses_ref.npz:", len(out), "arrays")
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "losses":
+        gen_losses()
+        sys.exit(0)
     gen_adversarial()
+    gen_losses()
     gen_unet()

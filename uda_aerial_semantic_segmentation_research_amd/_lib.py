@@ -57,6 +57,13 @@ SIGNATURES = {
     "udaseg_ce_partials": (_I, []),
     "udaseg_ce_fwd": (_I, [_P, _P, _L, _I, _I, _P, _P, _P, _P]),
     "udaseg_ce_bwd": (_I, [_P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _P]),
+    "udaseg_seg_partials": (_I, []),
+    "udaseg_dice_fwd": (_I, [_P, _P, _I, _L, _I, _I, _F, _P, _P, _P, _P]),
+    "udaseg_dice_bwd": (_I, [_P, _P, _P, _P, _F, _I, _L, _I, _I, _P, _I, _P]),
+    "udaseg_focal_fwd": (_I, [_P, _P, _P, _F, _F, _L, _I, _I, _I, _P, _P, _I, _P]),
+    "udaseg_focal_bwd": (_I, [_P, _P, _P, _F, _F, _P, _F, _L, _I, _I, _P, _I, _P]),
+    "udaseg_consistency_fwd": (_I, [_P, _P, _F, _I, _L, _I, _I, _P, _P, _P]),
+    "udaseg_consistency_bwd": (_I, [_P, _P, _F, _P, _F, _I, _L, _I, _I, _P, _P, _I, _P]),
     "udaseg_argmax_confusion": (_I, [_P, _P, _L, _I, _I, _P, _P, _P]),
     "udaseg_gap_splits": (_I, [_I]),
     "udaseg_gap_linear_sigmoid_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),

@@ -294,6 +294,49 @@ def ce_bwd(logits_base, target, lse, grad_out, pixels, classes, ldc, dlogits, co
                                      st if st is not None else stream()), "ce_bwd")
 
 
+def seg_partials():
+    return _lib.load().udaseg_seg_partials()
+
+
+def dice_fwd(logits_base, target, batch, pix_per_image, classes, ldc, smooth, sums, coef, loss, st=None):
+    check(_lib.load().udaseg_dice_fwd(logits_base.data_ptr(), target.data_ptr(), batch, pix_per_image, classes, ldc,
+                                       float(smooth), sums.data_ptr(), coef.data_ptr(), loss.data_ptr(),
+                                       st if st is not None else stream()), "dice_fwd")
+
+
+def dice_bwd(logits_base, target, coef, grad_out, weight, batch, pix_per_image, classes, ldc, dlogits, accumulate=False,
+             st=None):
+    check(_lib.load().udaseg_dice_bwd(logits_base.data_ptr(), target.data_ptr(), coef.data_ptr(), _ptr(grad_out),
+                                       float(weight), batch, pix_per_image, classes, ldc, dlogits.data_ptr(),
+                                       int(accumulate), st if st is not None else stream()), "dice_bwd")
+
+
+def focal_fwd(logits_base, target, class_weights, alpha, gamma, pixels, classes, ldc, mean, partials, loss, accumulate=False,
+              st=None):
+    check(_lib.load().udaseg_focal_fwd(logits_base.data_ptr(), target.data_ptr(), _ptr(class_weights), float(alpha),
+                                        float(gamma), pixels, classes, ldc, int(mean), partials.data_ptr(), loss.data_ptr(),
+                                        int(accumulate), st if st is not None else stream()), "focal_fwd")
+
+
+def focal_bwd(logits_base, target, class_weights, alpha, gamma, grad_out, weight, pixels, classes, ldc, dlogits,
+              accumulate=False, st=None):
+    check(_lib.load().udaseg_focal_bwd(logits_base.data_ptr(), target.data_ptr(), _ptr(class_weights), float(alpha),
+                                        float(gamma), _ptr(grad_out), float(weight), pixels, classes, ldc,
+                                        dlogits.data_ptr(), int(accumulate), st if st is not None else stream()), "focal_bwd")
+
+
+def consistency_fwd(z1, z2, temperature, batch, pixels, classes, ldc, partials, loss, st=None):
+    check(_lib.load().udaseg_consistency_fwd(z1.data_ptr(), z2.data_ptr(), float(temperature), batch, pixels, classes, ldc,
+                                              partials.data_ptr(), loss.data_ptr(), st if st is not None else stream()),
+          "consistency_fwd")
+
+
+def consistency_bwd(z1, z2, temperature, grad_out, weight, batch, pixels, classes, ldc, d1, d2, accumulate=False, st=None):
+    check(_lib.load().udaseg_consistency_bwd(z1.data_ptr(), z2.data_ptr(), float(temperature), _ptr(grad_out), float(weight),
+                                              batch, pixels, classes, ldc, _ptr(d1), _ptr(d2), int(accumulate),
+                                              st if st is not None else stream()), "consistency_bwd")
+
+
 def gap_linear_sigmoid_fwd(z, w, b, st=None):
     n, h, wd, c = z.shape
     hw = h * wd

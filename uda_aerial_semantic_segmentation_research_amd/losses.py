@@ -4,7 +4,11 @@
   reduction, no class weights, no ignore_index, no label smoothing; reference ``src/models/train.py:208``).
 * ``AdversarialLoss``   -- mirror of reference ``src/models/losses.py:7-51`` (same constructor, same two methods).
   As upstream, BCE-*with-logits* is applied to whatever the discriminator returns (its sigmoid output).
+* ``DiceLoss``, ``WeightedSegmentationLoss``, ``ConsistencyLoss``, ``FineTuningLoss``, ``calculate_class_weights`` --
+  the rest of the reference's loss family (``src/models/losses.py:53-342``), kernels in
+  csrc/losses_seg.hip: one pass over the logits per direction, softmax rows in registers.
 """
+from typing import Dict, Optional
 import torch
 import torch.nn as nn
 
@@ -127,3 +131,201 @@ class AdversarialLoss:
         """lambda_adv * BCEWithLogits(target_pred, 1)"""
         _need_gpu(target_pred, "AdversarialLoss.generator_loss")
         return _BCEPairFunction.apply(target_pred, 1.0, float(self.lambda_adv), None, 0.0, 0.0)
+
+
+# ------------------------------------------------------------------------------------------ Dice / focal / consistency
+def _check_seg_pair(who, logits, target):
+    _need_gpu(logits, who)
+    if logits.dim() != 4:
+        raise ValueError(f"{who}: expected predictions [B,C,H,W], got {tuple(logits.shape)}")
+    if logits.shape[1] > 32:
+        raise ValueError(f"{who}: at most 32 classes are supported by the HIP kernels, got {logits.shape[1]}")
+    if target.dim() == 4:
+        # the reference also takes one-hot [B,C,H,W] targets; the kernels work from class indices
+        target = target.argmax(dim=1)
+    if target.dim() != 3 or target.shape[0] != logits.shape[0] or target.shape[1:] != logits.shape[2:]:
+        raise ValueError(f"{who}: targets {tuple(target.shape)} do not match predictions {tuple(logits.shape)}")
+    return target.long().contiguous()
+
+
+class _SegLossFunction(torch.autograd.Function):
+    """loss = focal_w * focal(logits, target) + dice_w * dice(logits, target); either weight may be 0 (term skipped)."""
+
+    @staticmethod
+    def forward(ctx, logits, target, class_weights, alpha, gamma, mean, smooth, focal_w, dice_w):
+        n, c, h, w = logits.shape
+        buf, ldc = _padded_nhwc(logits.detach())
+        dev = logits.device
+        loss = torch.zeros((), device=dev, dtype=torch.float32)
+        coef = None
+        if focal_w != 0.0:
+            parts = torch.empty(K.seg_partials(), device=dev, dtype=torch.float64)
+            K.focal_fwd(buf, target, class_weights, alpha, gamma, n * h * w, c, ldc, mean, parts, loss)
+            if focal_w != 1.0:
+                loss.mul_(focal_w)
+        if dice_w != 0.0:
+            sums = torch.zeros(n * 3 * c, device=dev, dtype=torch.float64)
+            coef = torch.empty(n * 2 * c, device=dev, dtype=torch.float32)
+            dloss = torch.empty((), device=dev, dtype=torch.float32)
+            K.dice_fwd(buf, target, n, h * w, c, ldc, smooth, sums, coef, dloss)
+            loss.add_(dloss, alpha=dice_w)
+        ctx.save_for_backward(buf, target, class_weights, coef)
+        ctx.cfg = (n, c, h, w, ldc, alpha, gamma, mean, focal_w, dice_w)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        buf, target, class_weights, coef = ctx.saved_tensors
+        n, c, h, w, ldc, alpha, gamma, mean, focal_w, dice_w = ctx.cfg
+        g = grad_out.detach().float().contiguous()
+        dl = torch.empty((n, h, w, ldc), device=buf.device, dtype=torch.float32)
+        wrote = False
+        if focal_w != 0.0:
+            K.focal_bwd(buf, target, class_weights, alpha, gamma, g, focal_w / (n * h * w) if mean else focal_w, n * h * w, c,
+                        ldc, dl, False)
+            wrote = True
+        if dice_w != 0.0:
+            K.dice_bwd(buf, target, coef, g, dice_w, n, h * w, c, ldc, dl, wrote)
+        return (dl.permute(0, 3, 1, 2)[:, :c],) + (None,) * 8
+
+
+class DiceLoss(nn.Module):
+    """1 - mean over (image, class) of the soft Dice coefficient of softmax(predictions) against the labels."""
+
+    def __init__(self, smooth=1.0):
+        super().__init__()
+        self.smooth = smooth
+
+    def forward(self, predictions, targets):
+        targets = _check_seg_pair("DiceLoss", predictions, targets)
+        return _SegLossFunction.apply(predictions, targets, None, 0.0, 0.0, True, float(self.smooth), 0.0, 1.0)
+
+
+class WeightedSegmentationLoss(nn.Module):
+    """domain_weight * (focal-modulated class-weighted cross entropy + Dice)."""
+
+    def __init__(self, num_classes: int, class_weights: Optional[torch.Tensor] = None, alpha: float = 0.25,
+                 gamma: float = 2.0, reduction: str = 'mean'):
+        super().__init__()
+        self.num_classes = num_classes
+        self.register_buffer('class_weights', torch.ones(num_classes) if class_weights is None else class_weights)
+        self.alpha = alpha
+        self.gamma = gamma
+        self.reduction = reduction
+        self.dice_loss = DiceLoss()
+
+    def _weights_on(self, device):
+        return self.class_weights.to(device=device, dtype=torch.float32).contiguous()
+
+    def focal_loss(self, inputs, targets):
+        targets = _check_seg_pair("WeightedSegmentationLoss.focal_loss", inputs, targets)
+        return _SegLossFunction.apply(inputs, targets, self._weights_on(inputs.device), float(self.alpha), float(self.gamma),
+                                      self.reduction == 'mean', 1.0, 1.0, 0.0)
+
+    def forward(self, inputs, targets, domain_weight: float = 1.0):
+        if inputs.dim() == 4 and inputs.shape[1] != self.num_classes:
+            raise ValueError(f"WeightedSegmentationLoss: {inputs.shape[1]} channels for {self.num_classes} classes")
+        targets = _check_seg_pair("WeightedSegmentationLoss", inputs, targets)
+        both = _SegLossFunction.apply(inputs, targets, self._weights_on(inputs.device), float(self.alpha), float(self.gamma),
+                                      self.reduction == 'mean', float(self.dice_loss.smooth), 1.0, 1.0)
+        return domain_weight * both
+
+
+def calculate_class_weights(dataset, num_classes: int, method: str = 'effective_samples') -> torch.Tensor:
+    """Class weights from pixel counts over ``dataset`` (items ``(image, mask)``): 'effective_samples' uses
+    (1-beta)/(1-beta^n) with beta=0.9999, anything else 1/n; normalised to sum to num_classes."""
+    counts = torch.zeros(num_classes)
+    for _, mask in dataset:
+        m = torch.as_tensor(mask).reshape(-1).long()
+        m = m[(m >= 0) & (m < num_classes)]
+        counts += torch.bincount(m, minlength=num_classes).to(counts.dtype)
+    counts = counts.clamp(min=1.0)
+    if method == 'effective_samples':
+        beta = 0.9999
+        weights = (1.0 - beta) / (1.0 - torch.pow(beta, counts))
+    else:
+        weights = 1.0 / counts
+    return weights / weights.sum() * num_classes
+
+
+class _ConsistencyFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred1, pred2, temperature):
+        n, c, h, w = pred1.shape
+        z1, ldc = _padded_nhwc(pred1.detach())
+        z2, _ = _padded_nhwc(pred2.detach())
+        dev = pred1.device
+        parts = torch.empty(K.seg_partials(), device=dev, dtype=torch.float64)
+        loss = torch.empty((), device=dev, dtype=torch.float32)
+        K.consistency_fwd(z1, z2, temperature, n, n * h * w, c, ldc, parts, loss)
+        ctx.save_for_backward(z1, z2)
+        ctx.cfg = (n, c, h, w, ldc, temperature)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        z1, z2 = ctx.saved_tensors
+        n, c, h, w, ldc, temperature = ctx.cfg
+        g = grad_out.detach().float().contiguous()
+        need1, need2 = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        d1 = torch.empty((n, h, w, ldc), device=z1.device, dtype=torch.float32) if need1 else None
+        d2 = torch.empty((n, h, w, ldc), device=z1.device, dtype=torch.float32) if need2 else None
+        if need1 or need2:
+            K.consistency_bwd(z1, z2, temperature, g, 1.0, n, n * h * w, c, ldc, d1, d2)
+        return (d1.permute(0, 3, 1, 2)[:, :c] if need1 else None, d2.permute(0, 3, 1, 2)[:, :c] if need2 else None, None)
+
+
+class ConsistencyLoss(nn.Module):
+    """Symmetric KL between the temperature-softened class distributions of two predictions of the same image."""
+
+    def __init__(self, temperature=0.5):
+        super().__init__()
+        self.temperature = temperature
+
+    def forward(self, pred1, pred2):
+        _need_gpu(pred1, "ConsistencyLoss")
+        if pred1.dim() != 4 or pred1.shape != pred2.shape:
+            raise ValueError(f"ConsistencyLoss: expected two [B,C,H,W] predictions, got {tuple(pred1.shape)} and {tuple(pred2.shape)}")
+        if pred1.shape[1] > 32:
+            raise ValueError("ConsistencyLoss: at most 32 classes are supported by the HIP kernels")
+        return _ConsistencyFunction.apply(pred1, pred2, float(self.temperature))
+
+    def get_similarity_matrix(self, pred1, pred2):
+        """Per-pixel cosine similarity of the two softmax distributions, [B,H,W] (visualisation helper, not on the hot
+        path: plain torch ops)."""
+        return torch.nn.functional.cosine_similarity(torch.softmax(pred1, dim=1), torch.softmax(pred2, dim=1), dim=1)
+
+
+class FineTuningLoss(nn.Module):
+    """Phase-3 objective: ramped consistency + ramped domain confusion (+ Dice on labelled samples when given).
+
+    As upstream, ``domain_weight`` enters twice: as ``AdversarialLoss(lambda_adv=domain_weight)`` and again as the
+    multiplier of that term."""
+
+    def __init__(self, consistency_weight: float = 1.0, domain_weight: float = 0.1, supervised_weight: float = 0.1,
+                 rampup_length: int = 40, temperature: float = 0.5):
+        super().__init__()
+        self.consistency_loss = ConsistencyLoss(temperature=temperature)
+        self.domain_loss = AdversarialLoss(lambda_adv=domain_weight)
+        self.supervised_loss = DiceLoss()
+        self.consistency_weight = consistency_weight
+        self.domain_weight = domain_weight
+        self.supervised_weight = supervised_weight
+        self.rampup_length = rampup_length
+
+    def rampup(self, epoch: int) -> float:
+        """Linear 0 -> 1 over the first ``rampup_length`` epochs, 1 afterwards."""
+        return 1.0 if epoch >= self.rampup_length else float(epoch) / self.rampup_length
+
+    def forward(self, pred1, pred2, domain_pred, epoch: int, supervised_pred=None,
+                supervised_target=None) -> Dict[str, torch.Tensor]:
+        ramp = self.rampup(epoch)
+        consistency = self.consistency_loss(pred1, pred2)
+        domain_confusion = self.domain_loss.generator_loss(domain_pred)
+        total = consistency * (self.consistency_weight * ramp) + domain_confusion * (self.domain_weight * ramp)
+        supervised = torch.tensor(0.0, device=pred1.device)
+        if supervised_pred is not None and supervised_target is not None:
+            supervised = self.supervised_loss(supervised_pred, supervised_target)
+            total = total + supervised * self.supervised_weight
+        return {'total': total, 'consistency': consistency.detach(), 'domain_confusion': domain_confusion.detach(),
+                'supervised': supervised.detach(), 'rampup_weight': torch.tensor(ramp)}
