@@ -155,9 +155,12 @@ int udaseg_ce_bwd(const float* logits, const int64_t* target, const float* lse, 
 int udaseg_seg_partials(void);
 /* DiceLoss (losses.py:110-152): softmax over classes, per image b and class c
  *   I = sum_pix p_c*[t==c], U = sum_pix p_c + sum_pix [t==c]; loss = 1 - mean_{b,c} (2I+smooth)/(U+smooth).
+ * pooled != 0: the segmentation_models_pytorch DiceLoss(mode='multiclass') form used by the reference's UDALoss
+ *   (src/models/uda.py:84): I, U summed over the batch too, score_c = (2I+smooth)/max(U+smooth, eps),
+ *   loss = mean_c (1-score_c)*[class c occurs in target]   (smp defaults: smooth 0, eps 1e-7).
  * sums: batch*3*classes doubles, caller-zeroed; coef: batch*2*classes floats kept for udaseg_dice_bwd. */
 int udaseg_dice_fwd(const float* logits, const int64_t* target, int batch, int64_t pix_per_image, int classes, int ldc,
-                    float smooth, double* sums, float* coef, float* loss, void* stream);
+                    float smooth, float eps, int pooled, double* sums, float* coef, float* loss, void* stream);
 /* dlogits (+)= (*grad_out) * weight * dLoss/dlogits (grad_out may be NULL = 1); pad channels written as 0 */
 int udaseg_dice_bwd(const float* logits, const int64_t* target, const float* coef, const float* grad_out, float weight,
                     int batch, int64_t pix_per_image, int classes, int ldc, float* dlogits, int accumulate, void* stream);
@@ -193,11 +196,22 @@ int udaseg_gap_linear_sigmoid_fwd(const float* z, const float* w, const float* b
 /* given dp[n]: dw (+)=, db (+)=, dz[n][hw][c] = dp*p*(1-p)*w[c]/hw broadcast */
 int udaseg_gap_linear_sigmoid_bwd(const float* dp, const float* p, const float* pooled, const float* w, float* dz,
                                   float* dw, float* db, int n, int hw, int c, int accumulate_param, void* stream);
+/* feature-level discriminator tail Conv2d(c,1,1) -> AdaptiveAvgPool2d(1) (src/models/uda.py:22-23):
+ * logit[n] = dot(mean_hw z[n], w) + b  (no sigmoid; that design applies BCE-with-logits to real logits) */
+int udaseg_gap_linear_fwd(const float* z, const float* w, const float* b, float* partial, float* pooled, float* logit, int n,
+                          int hw, int c, void* stream);
+int udaseg_gap_linear_bwd(const float* dlogit, const float* pooled, const float* w, float* dz, float* dw, float* db, int n,
+                          int hw, int c, int accumulate_param, void* stream);
 /* loss (+)= weight * mean(softplus(x) - x*label)   (BCEWithLogits on whatever x is: reference feeds probabilities) */
 int udaseg_bce_logits_fwd(const float* x, int n, float label, float weight, float* loss, int accumulate, void* stream);
 /* dx = (*grad_out) * weight * (sigmoid(x) - label) / n */
 int udaseg_bce_logits_bwd(const float* x, int n, float label, float weight, const float* grad_out, float* dx,
                           int accumulate, void* stream);
+/* the same with a per-sample target vector (nn.BCEWithLogitsLoss()(x, y): src/models/uda.py:85,96; trainer_phases.py:157) */
+int udaseg_bce_logits_target_fwd(const float* x, const float* target, int n, float weight, float* loss, int accumulate,
+                                 void* stream);
+int udaseg_bce_logits_target_bwd(const float* x, const float* target, int n, float weight, const float* grad_out, float* dx,
+                                 int accumulate, void* stream);
 
 /* ---- Adam: torch.optim.Adam(...).step() at train.py:344,461; adversarial_trainer.py:56-59,98,114 ----
  * flat fp32 arrays; bc1 = 1-beta1^t, bc2 = 1-beta2^t computed by the caller. */
@@ -240,6 +254,8 @@ int udaseg_pack_dgrad_batched_bf16(const float* arena, void* packed, const int* 
 /* ---- small utilities ---- */
 int udaseg_fill_f32(float* p, int64_t count, float value, void* stream);
 int udaseg_axpy_f32(float* y, const float* x, int64_t count, float alpha, void* stream); /* y += alpha*x */
+int udaseg_scale_f32(const float* x, float* y, int64_t count, float alpha, void* stream); /* y = alpha*x: gradient reversal,
+                                                                                         * src/models/uda.py:99-111 */
 
 /* ---- live kernel timing for bench.py's roofline leg: HIP events bracket every launch of the conv
  *      kernel families on the launch stream while enabled. ---- */

@@ -72,7 +72,7 @@ def _unit_of(name):
 def _gpu_relu_outputs(net):
     """(unit, NCHW cpu tensor) of every ReLU output of the last training forward, in execution order."""
     from uda_aerial_semantic_segmentation_research_amd import unet as U
-    P, tape, (r_stem, f1, pooled, pidx), _ = net._last_tape
+    P, tape, (r_stem, f1, pooled, pidx), _, _ = net._last_tape
     names = {id(m): n for n, m in net.named_modules()}
     outs = [((0, 0, 0), f1)]
     for blk, rec, out in tape:
@@ -87,7 +87,7 @@ def _gpu_relu_outputs(net):
     return [(u, z.detach().cpu().permute(0, 3, 1, 2)) for u, z in outs]
 
 
-def grads_vs_oracle(net, ref32, x, loss_fn, label):
+def grads_vs_oracle(net, ref32, x, loss_fn, label, forward_fn=None, skip_none=False):
     """Gradient parity at north_star's 1e-3 (norm-wise per tensor) on EVERY parameter tensor.
 
     The loss is piecewise smooth: each ReLU mask bit is a kink, and two correct fp32 evaluations that disagree on a
@@ -112,7 +112,7 @@ def grads_vs_oracle(net, ref32, x, loss_fn, label):
     R._relu = forced
     try:
         ref32.zero_grad()
-        out = ref32(x)
+        out = (forward_fn or ref32)(x)
         loss_fn(out).backward()
     finally:
         R._relu = orig
@@ -124,6 +124,9 @@ def grads_vs_oracle(net, ref32, x, loss_fn, label):
     g32 = dict(ref32.named_parameters())
     worst = ("", 0.0)
     for k, p in net.named_parameters():
+        if skip_none and g32[k].grad is None:
+            assert p.grad is None or p.grad.abs().max().item() == 0.0, k
+            continue
         assert p.grad is not None, k
         e = check(p.grad, g32[k].grad, f"{label} grad {k}")
         if e > worst[1]:

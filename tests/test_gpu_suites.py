@@ -151,7 +151,7 @@ def test_full_size_step_properties(pkg):
     # BN+ReLU output of the stem in training mode: pre-activation statistics are (beta, gamma^2) = (0, 1) at init
     net.debug_keep_tape = True
     net(xd)
-    _, _, (r_stem, f1, _, _), _ = net._last_tape
+    _, _, (r_stem, f1, _, _), _, _ = net._last_tape
     y_stem, (mean, rstd) = r_stem[4], r_stem[6]
     pre = (y_stem - mean) * rstd
     assert pre.mean(dim=(0, 1, 2)).abs().max().item() < 1e-4

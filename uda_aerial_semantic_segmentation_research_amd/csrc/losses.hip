@@ -215,7 +215,8 @@ __global__ void gap_partial_kernel(const f32x4* __restrict__ z, f32x4* __restric
 // one block per image: pooled = sum_s partial / hw ; p = sigmoid(dot(pooled, w) + b)
 __global__ __launch_bounds__(256) void gap_linear_sigmoid_kernel(const float* __restrict__ partial, const float* __restrict__ w,
                                                                  const float* __restrict__ b, float* __restrict__ pooled,
-                                                                 float* __restrict__ p, int hw, int c, int splits) {
+                                                                 float* __restrict__ p, int hw, int c, int splits,
+                                                                 int sigmoid) {
   __shared__ float red[4];
   const int ni = blockIdx.x;
   float dot = 0.f;
@@ -232,36 +233,36 @@ __global__ __launch_bounds__(256) void gap_linear_sigmoid_kernel(const float* __
   __syncthreads();
   if (threadIdx.x == 0) {
     const float t = red[0] + red[1] + red[2] + red[3] + b[0];
-    p[ni] = 1.f / (1.f + expf(-t));
+    p[ni] = sigmoid ? 1.f / (1.f + expf(-t)) : t;
   }
 }
 
 // dz[n][p][c] = dlogit[n] * w[c] / hw, broadcast over the hw pixels
 __global__ void gap_bwd_broadcast_kernel(const float* __restrict__ dp, const float* __restrict__ p, const f32x4* __restrict__ w,
-                                         f32x4* __restrict__ dz, int n, int hw, int c4) {
+                                         f32x4* __restrict__ dz, int n, int hw, int c4, int sigmoid) {
   const int64_t total = (int64_t)n * hw * c4;
   const int64_t T = (int64_t)gridDim.x * blockDim.x;
   const float inv = 1.f / (float)hw;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += T) {
     const int q = (int)(i % c4);
     const int ni = (int)(i / ((int64_t)hw * c4));
-    const float pv = p[ni];
-    const float dl = dp[ni] * pv * (1.f - pv) * inv;
+    const float pv = sigmoid ? p[ni] : 0.f;
+    const float dl = dp[ni] * (sigmoid ? pv * (1.f - pv) : 1.f) * inv;
     dz[i] = w[q] * dl;
   }
 }
 
 // dw[c] (+)= sum_n dlogit[n]*pooled[n][c] ; db (+)= sum_n dlogit[n]
 __global__ void gap_bwd_param_kernel(const float* __restrict__ dp, const float* __restrict__ p, const float* __restrict__ pooled,
-                                     float* __restrict__ dw, float* __restrict__ db, int n, int c, int accumulate) {
+                                     float* __restrict__ dw, float* __restrict__ db, int n, int c, int accumulate, int sigmoid) {
   for (int ch = blockIdx.x * blockDim.x + threadIdx.x; ch < c; ch += gridDim.x * blockDim.x) {
     float s = 0.f;
-    for (int ni = 0; ni < n; ++ni) s += dp[ni] * p[ni] * (1.f - p[ni]) * pooled[(int64_t)ni * c + ch];
+    for (int ni = 0; ni < n; ++ni) s += dp[ni] * (sigmoid ? p[ni] * (1.f - p[ni]) : 1.f) * pooled[(int64_t)ni * c + ch];
     dw[ch] = accumulate ? dw[ch] + s : s;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     float s = 0.f;
-    for (int ni = 0; ni < n; ++ni) s += dp[ni] * p[ni] * (1.f - p[ni]);
+    for (int ni = 0; ni < n; ++ni) s += dp[ni] * (sigmoid ? p[ni] * (1.f - p[ni]) : 1.f);
     db[0] = accumulate ? db[0] + s : s;
   }
 }
@@ -294,6 +295,27 @@ __global__ void bce_bwd_kernel(const float* __restrict__ x, int n, float label, 
     const float v = x[i];
     const float sg = 1.f / (1.f + expf(-v));
     const float d = (sg - label) * g;
+    dx[i] = accumulate ? dx[i] + d : d;
+  }
+}
+
+// per-sample targets (nn.BCEWithLogitsLoss()(x, y), reference src/models/uda.py:85,96)
+__global__ void bce_target_fwd_kernel(const float* __restrict__ x, const float* __restrict__ y, int n, float weight,
+                                      float* __restrict__ loss, int accumulate) {
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 64) s += (1.f - y[i]) * x[i] + softplus_f(-x[i]);
+  s = wave_sum(s);
+  if (threadIdx.x == 0) {
+    const float l = weight * (s / (float)n);
+    *loss = accumulate ? *loss + l : l;
+  }
+}
+
+__global__ void bce_target_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, int n, float weight,
+                                      const float* __restrict__ grad_out, float* __restrict__ dx, int accumulate) {
+  const float g = (grad_out ? *grad_out : 1.f) * weight / (float)n;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float d = (1.f / (1.f + expf(-x[i])) - y[i]) * g;
     dx[i] = accumulate ? dx[i] + d : d;
   }
 }
@@ -415,7 +437,7 @@ extern "C" int udaseg_gap_linear_sigmoid_fwd(const float* z, const float* w, con
   const int bs = (c / 4) < 256 ? (((c / 4) + 63) / 64) * 64 : 256;
   hipLaunchKernelGGL(gap_partial_kernel, dim3(splits, n), dim3(bs), 0, st, (const f32x4*)z, (f32x4*)partial, hw, c / 4, splits);
   UDASEG_LAUNCH_CHECK("gap_partial launch");
-  hipLaunchKernelGGL(gap_linear_sigmoid_kernel, dim3(n), dim3(256), 0, st, partial, w, b, pooled, p, hw, c, splits);
+  hipLaunchKernelGGL(gap_linear_sigmoid_kernel, dim3(n), dim3(256), 0, st, partial, w, b, pooled, p, hw, c, splits, 1);
   UDASEG_LAUNCH_CHECK("gap_linear_sigmoid launch");
   return UDASEG_OK;
 }
@@ -427,9 +449,9 @@ extern "C" int udaseg_gap_linear_sigmoid_bwd(const float* dp, const float* p, co
   hipStream_t st = as_stream(stream);
   const int64_t total = (int64_t)n * hw * (c / 4);
   int grid = (int)((total + 511) / 512 > 2048 ? 2048 : (total + 511) / 512);
-  hipLaunchKernelGGL(gap_bwd_broadcast_kernel, dim3(grid), dim3(256), 0, st, dp, p, (const f32x4*)w, (f32x4*)dz, n, hw, c / 4);
+  hipLaunchKernelGGL(gap_bwd_broadcast_kernel, dim3(grid), dim3(256), 0, st, dp, p, (const f32x4*)w, (f32x4*)dz, n, hw, c / 4, 1);
   UDASEG_LAUNCH_CHECK("gap_bwd_broadcast launch");
-  hipLaunchKernelGGL(gap_bwd_param_kernel, dim3((c + 255) / 256), dim3(256), 0, st, dp, p, pooled, dw, db, n, c, accumulate_param);
+  hipLaunchKernelGGL(gap_bwd_param_kernel, dim3((c + 255) / 256), dim3(256), 0, st, dp, p, pooled, dw, db, n, c, accumulate_param, 1);
   UDASEG_LAUNCH_CHECK("gap_bwd_param launch");
   return UDASEG_OK;
 }
@@ -439,7 +461,7 @@ extern "C" int udaseg_gap_finish(const float* partial, const float* w, const flo
                                  int c, void* stream) {
   UDASEG_CHECK_ARG(partial && w && b && pooled && p && n > 0 && hw > 0 && c > 0, "gap_finish: bad arguments");
   hipLaunchKernelGGL(gap_linear_sigmoid_kernel, dim3(n), dim3(256), 0, as_stream(stream), partial, w, b, pooled, p, hw, c,
-                     udaseg_gap_splits(hw));
+                     udaseg_gap_splits(hw), 1);
   UDASEG_LAUNCH_CHECK("gap_finish launch");
   return UDASEG_OK;
 }
@@ -448,7 +470,7 @@ extern "C" int udaseg_gap_bwd_param(const float* dp, const float* p, const float
                                     int accumulate_param, void* stream) {
   UDASEG_CHECK_ARG(dp && p && pooled && dw && db && n > 0 && c > 0, "gap_bwd_param: bad arguments");
   hipLaunchKernelGGL(gap_bwd_param_kernel, dim3((c + 255) / 256), dim3(256), 0, as_stream(stream), dp, p, pooled, dw, db, n, c,
-                     accumulate_param);
+                     accumulate_param, 1);
   UDASEG_LAUNCH_CHECK("gap_bwd_param launch");
   return UDASEG_OK;
 }
@@ -467,5 +489,54 @@ extern "C" int udaseg_bce_logits_bwd(const float* x, int n, float label, float w
   hipLaunchKernelGGL(bce_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), x, n, label, weight, grad_out, dx,
                      accumulate);
   UDASEG_LAUNCH_CHECK("bce_bwd launch");
+  return UDASEG_OK;
+}
+
+// ---- feature-level discriminator tail: Conv2d(c, 1, 1) -> AdaptiveAvgPool2d(1) (reference src/models/uda.py:22-23).
+// The two are linear, so mean_hw(w.x + b) = w.mean_hw(x) + b: same kernels as the image-level tail, no sigmoid.
+extern "C" int udaseg_gap_linear_fwd(const float* z, const float* w, const float* b, float* partial, float* pooled, float* logit,
+                                     int n, int hw, int c, void* stream) {
+  UDASEG_CHECK_ARG(z && w && b && partial && pooled && logit, "gap_linear_fwd: NULL pointer");
+  UDASEG_CHECK_ARG(n > 0 && hw > 0 && c > 0 && c % 4 == 0, "gap_linear_fwd: bad shape");
+  hipStream_t st = as_stream(stream);
+  const int splits = udaseg_gap_splits(hw);
+  const int bs = (c / 4) < 256 ? (((c / 4) + 63) / 64) * 64 : 256;
+  hipLaunchKernelGGL(gap_partial_kernel, dim3(splits, n), dim3(bs), 0, st, (const f32x4*)z, (f32x4*)partial, hw, c / 4, splits);
+  UDASEG_LAUNCH_CHECK("gap_partial launch");
+  hipLaunchKernelGGL(gap_linear_sigmoid_kernel, dim3(n), dim3(256), 0, st, partial, w, b, pooled, logit, hw, c, splits, 0);
+  UDASEG_LAUNCH_CHECK("gap_linear launch");
+  return UDASEG_OK;
+}
+
+extern "C" int udaseg_gap_linear_bwd(const float* dlogit, const float* pooled, const float* w, float* dz, float* dw, float* db,
+                                     int n, int hw, int c, int accumulate_param, void* stream) {
+  UDASEG_CHECK_ARG(dlogit && pooled && w && dz && dw && db, "gap_linear_bwd: NULL pointer");
+  UDASEG_CHECK_ARG(n > 0 && hw > 0 && c > 0 && c % 4 == 0, "gap_linear_bwd: bad shape");
+  hipStream_t st = as_stream(stream);
+  const int64_t total = (int64_t)n * hw * (c / 4);
+  int grid = (int)((total + 511) / 512 > 2048 ? 2048 : (total + 511) / 512);
+  hipLaunchKernelGGL(gap_bwd_broadcast_kernel, dim3(grid), dim3(256), 0, st, dlogit, (const float*)nullptr, (const f32x4*)w,
+                     (f32x4*)dz, n, hw, c / 4, 0);
+  UDASEG_LAUNCH_CHECK("gap_bwd_broadcast launch");
+  hipLaunchKernelGGL(gap_bwd_param_kernel, dim3((c + 255) / 256), dim3(256), 0, st, dlogit, (const float*)nullptr, pooled, dw, db,
+                     n, c, accumulate_param, 0);
+  UDASEG_LAUNCH_CHECK("gap_bwd_param launch");
+  return UDASEG_OK;
+}
+
+extern "C" int udaseg_bce_logits_target_fwd(const float* x, const float* target, int n, float weight, float* loss, int accumulate,
+                                            void* stream) {
+  UDASEG_CHECK_ARG(x && target && loss && n > 0, "bce_logits_target_fwd: bad arguments");
+  hipLaunchKernelGGL(bce_target_fwd_kernel, dim3(1), dim3(64), 0, as_stream(stream), x, target, n, weight, loss, accumulate);
+  UDASEG_LAUNCH_CHECK("bce_target_fwd launch");
+  return UDASEG_OK;
+}
+
+extern "C" int udaseg_bce_logits_target_bwd(const float* x, const float* target, int n, float weight, const float* grad_out,
+                                            float* dx, int accumulate, void* stream) {
+  UDASEG_CHECK_ARG(x && target && dx && n > 0, "bce_logits_target_bwd: bad arguments");
+  hipLaunchKernelGGL(bce_target_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), x, target, n, weight, grad_out,
+                     dx, accumulate);
+  UDASEG_LAUNCH_CHECK("bce_target_bwd launch");
   return UDASEG_OK;
 }

@@ -80,23 +80,49 @@ __global__ __launch_bounds__(256) void dice_stats_kernel(const f32x4* __restrict
   }
 }
 
-// loss = 1 - mean_{b,c} (2I + s)/(U + s);  coef[b][0][c] = dD/dp for onehot=1 minus onehot=0 part: a = 2/(U+s),
-// coef[b][1][c] = b = -(2I+s)/(U+s)^2, both pre-divided by -(B*C) so the backward is g_c = a*onehot + b
-__global__ void dice_finish_kernel(const double* __restrict__ sums, int batch, int classes, float smooth, float* __restrict__ loss,
-                                   float* __restrict__ coef) {
+// per-image mode (reference DiceLoss): loss = 1 - mean_{b,c} (2I + s)/(U + s).
+// pooled mode (segmentation_models_pytorch DiceLoss(mode='multiclass'), the reference's UDALoss at src/models/uda.py:84):
+//   sums pooled over the batch; score_c = (2I_c + s)/max(U_c + s, eps); loss = mean_c (1 - score_c) * [class c present].
+// coef[b][0][c] = a, coef[b][1][c] = b with dLoss/dp_c(pixel of image b) = a * onehot_c + b.
+__global__ void dice_finish_kernel(const double* __restrict__ sums, int batch, int classes, float smooth, float eps, int pooled,
+                                   float* __restrict__ loss, float* __restrict__ coef) {
   double acc = 0.0;
-  const int n = batch * classes;
-  for (int i = threadIdx.x; i < n; i += 64) {
-    const int b = i / classes, c = i % classes;
-    const double I = sums[((size_t)b * 3 + 0) * classes + c];
-    const double U = sums[((size_t)b * 3 + 1) * classes + c] + sums[((size_t)b * 3 + 2) * classes + c];
+  if (!pooled) {
+    const int n = batch * classes;
+    for (int i = threadIdx.x; i < n; i += 64) {
+      const int b = i / classes, c = i % classes;
+      const double I = sums[((size_t)b * 3 + 0) * classes + c];
+      const double U = sums[((size_t)b * 3 + 1) * classes + c] + sums[((size_t)b * 3 + 2) * classes + c];
+      const double den = U + (double)smooth;
+      acc += (2.0 * I + (double)smooth) / den;
+      coef[((size_t)b * 2 + 0) * classes + c] = (float)(-(2.0 / den) / n);
+      coef[((size_t)b * 2 + 1) * classes + c] = (float)(((2.0 * I + (double)smooth) / (den * den)) / n);
+    }
+    acc = wave_sum_d(acc);
+    if (threadIdx.x == 0) *loss = (float)(1.0 - acc / n);
+    return;
+  }
+  for (int c = threadIdx.x; c < classes; c += 64) {
+    double I = 0.0, U = 0.0, T = 0.0;
+    for (int b = 0; b < batch; ++b) {
+      I += sums[((size_t)b * 3 + 0) * classes + c];
+      U += sums[((size_t)b * 3 + 1) * classes + c] + sums[((size_t)b * 3 + 2) * classes + c];
+      T += sums[((size_t)b * 3 + 2) * classes + c];
+    }
     const double den = U + (double)smooth;
-    acc += (2.0 * I + (double)smooth) / den;
-    coef[((size_t)b * 2 + 0) * classes + c] = (float)(-(2.0 / den) / n);
-    coef[((size_t)b * 2 + 1) * classes + c] = (float)(((2.0 * I + (double)smooth) / (den * den)) / n);
+    const bool present = T > 0.0, clamped = den < (double)eps;
+    const double score = (2.0 * I + (double)smooth) / (clamped ? (double)eps : den);
+    if (present) acc += 1.0 - score;
+    // d(1 - score)/dp = -(2 t)/den + (2I + s)/den^2 (the second term vanishes where the denominator is clamped)
+    const float a = present ? (float)(-(2.0 / (clamped ? (double)eps : den)) / classes) : 0.f;
+    const float bq = present && !clamped ? (float)(((2.0 * I + (double)smooth) / (den * den)) / classes) : 0.f;
+    for (int b = 0; b < batch; ++b) {
+      coef[((size_t)b * 2 + 0) * classes + c] = a;
+      coef[((size_t)b * 2 + 1) * classes + c] = bq;
+    }
   }
   acc = wave_sum_d(acc);
-  if (threadIdx.x == 0) *loss = (float)(1.0 - acc / n);
+  if (threadIdx.x == 0) *loss = (float)(acc / classes);
 }
 
 // dlogits (+)= scale * p_k * (g_k - sum_c p_c g_c),  g_c = coef_a[b][c] * onehot_c + coef_b[b][c]
@@ -304,7 +330,7 @@ using namespace udaseg;
 extern "C" int udaseg_seg_partials(void) { return SL_BLOCKS; }
 
 extern "C" int udaseg_dice_fwd(const float* logits, const int64_t* target, int batch, int64_t pix_per_image, int classes, int ldc,
-                               float smooth, double* sums, float* coef, float* loss, void* stream) {
+                               float smooth, float eps, int pooled, double* sums, float* coef, float* loss, void* stream) {
   int rc = check_seg(logits, pix_per_image, classes, ldc, "dice_fwd");
   if (rc) return rc;
   UDASEG_CHECK_ARG(target && sums && coef && loss && batch > 0, "dice_fwd: NULL pointer");
@@ -312,7 +338,7 @@ extern "C" int udaseg_dice_fwd(const float* logits, const int64_t* target, int b
   const int gx = (int)((pix_per_image + 255) / 256 > 256 ? 256 : (pix_per_image + 255) / 256);
   SEG_DISPATCH(dice_stats_kernel, dim3(gx, batch), (const f32x4*)logits, target, pix_per_image, classes, sums)
   UDASEG_LAUNCH_CHECK("dice_stats launch");
-  hipLaunchKernelGGL(dice_finish_kernel, dim3(1), dim3(64), 0, st, sums, batch, classes, smooth, loss, coef);
+  hipLaunchKernelGGL(dice_finish_kernel, dim3(1), dim3(64), 0, st, sums, batch, classes, smooth, eps, pooled, loss, coef);
   UDASEG_LAUNCH_CHECK("dice_finish launch");
   return UDASEG_OK;
 }

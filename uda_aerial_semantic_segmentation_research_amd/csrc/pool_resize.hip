@@ -172,6 +172,11 @@ __global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, 
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += T) y[i] += alpha * x[i];
 }
 
+__global__ void scale_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, float alpha) {
+  const int64_t T = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += T) y[i] = alpha * x[i];
+}
+
 static inline int grid_for(int64_t items, int per_thread = 2) {
   int64_t g = (items + 256LL * per_thread - 1) / (256LL * per_thread);
   if (g > 4096) g = 4096;
@@ -258,5 +263,14 @@ extern "C" int udaseg_axpy_f32(float* y, const float* x, int64_t count, float al
   if (count == 0) return UDASEG_OK;
   hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(count, 4)), dim3(256), 0, as_stream(stream), y, x, count, alpha);
   UDASEG_LAUNCH_CHECK("axpy launch");
+  return UDASEG_OK;
+}
+
+/* y = alpha * x (gradient reversal: alpha = -lambda; reference src/models/uda.py:99-111) */
+extern "C" int udaseg_scale_f32(const float* x, float* y, int64_t count, float alpha, void* stream) {
+  UDASEG_CHECK_ARG(y && x && count >= 0, "scale_f32: bad arguments");
+  if (count == 0) return UDASEG_OK;
+  hipLaunchKernelGGL(scale_kernel, dim3(grid_for(count, 4)), dim3(256), 0, as_stream(stream), x, y, count, alpha);
+  UDASEG_LAUNCH_CHECK("scale launch");
   return UDASEG_OK;
 }

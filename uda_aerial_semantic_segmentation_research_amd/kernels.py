@@ -298,10 +298,10 @@ def seg_partials():
     return _lib.load().udaseg_seg_partials()
 
 
-def dice_fwd(logits_base, target, batch, pix_per_image, classes, ldc, smooth, sums, coef, loss, st=None):
+def dice_fwd(logits_base, target, batch, pix_per_image, classes, ldc, smooth, sums, coef, loss, eps=1e-7, pooled=False, st=None):
     check(_lib.load().udaseg_dice_fwd(logits_base.data_ptr(), target.data_ptr(), batch, pix_per_image, classes, ldc,
-                                       float(smooth), sums.data_ptr(), coef.data_ptr(), loss.data_ptr(),
-                                       st if st is not None else stream()), "dice_fwd")
+                                       float(smooth), float(eps), int(pooled), sums.data_ptr(), coef.data_ptr(),
+                                       loss.data_ptr(), st if st is not None else stream()), "dice_fwd")
 
 
 def dice_bwd(logits_base, target, coef, grad_out, weight, batch, pix_per_image, classes, ldc, dlogits, accumulate=False,
@@ -378,6 +378,45 @@ def bce_logits_fwd(x, label, weight, loss, accumulate=False, st=None):
 def bce_logits_bwd(x, label, weight, grad_out, dx, accumulate=False, st=None):
     check(_lib.load().udaseg_bce_logits_bwd(x.data_ptr(), x.numel(), label, weight, _ptr(grad_out), dx.data_ptr(),
                                              int(accumulate), st if st is not None else stream()), "bce_logits_bwd")
+
+
+def gap_linear_fwd(z, w, b, st=None):
+    """logit[n] = dot(mean over pixels of z[n], w) + b for NHWC z; returns (logit [n], pooled [n, c])."""
+    n, h, wd, c = z.shape
+    hw = h * wd
+    splits = _lib.load().udaseg_gap_splits(hw)
+    partial = torch.empty((n, splits, c), device=z.device, dtype=torch.float32)
+    pooled = torch.empty((n, c), device=z.device, dtype=torch.float32)
+    logit = torch.empty(n, device=z.device, dtype=torch.float32)
+    check(_lib.load().udaseg_gap_linear_fwd(z.data_ptr(), w.data_ptr(), b.data_ptr(), partial.data_ptr(), pooled.data_ptr(),
+                                             logit.data_ptr(), n, hw, c, st if st is not None else stream()), "gap_linear_fwd")
+    return logit, pooled
+
+
+def gap_linear_bwd(dlogit, pooled, w, dz, dw, db, accumulate_param=False, st=None):
+    n, h, wd, c = dz.shape
+    check(_lib.load().udaseg_gap_linear_bwd(dlogit.data_ptr(), pooled.data_ptr(), w.data_ptr(), dz.data_ptr(), dw.data_ptr(),
+                                             db.data_ptr(), n, h * wd, c, int(accumulate_param),
+                                             st if st is not None else stream()), "gap_linear_bwd")
+
+
+def bce_logits_target_fwd(x, target, weight, loss, accumulate=False, st=None):
+    check(_lib.load().udaseg_bce_logits_target_fwd(x.data_ptr(), target.data_ptr(), x.numel(), float(weight), loss.data_ptr(),
+                                                    int(accumulate), st if st is not None else stream()), "bce_logits_target_fwd")
+
+
+def bce_logits_target_bwd(x, target, weight, grad_out, dx, accumulate=False, st=None):
+    check(_lib.load().udaseg_bce_logits_target_bwd(x.data_ptr(), target.data_ptr(), x.numel(), float(weight), _ptr(grad_out),
+                                                    dx.data_ptr(), int(accumulate), st if st is not None else stream()),
+          "bce_logits_target_bwd")
+
+
+def scale(x, alpha, out=None, st=None):
+    """out = alpha * x (dense fp32)."""
+    out = torch.empty_like(x) if out is None else out
+    check(_lib.load().udaseg_scale_f32(x.data_ptr(), out.data_ptr(), x.numel(), float(alpha),
+                                        st if st is not None else stream()), "scale_f32")
+    return out
 
 
 def adam_flat(p, g, m, v, count, lr, beta1, beta2, eps, bc1, bc2, st=None):

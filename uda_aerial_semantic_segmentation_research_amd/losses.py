@@ -112,6 +112,51 @@ class _BCEPairFunction(torch.autograd.Function):
         return da, None, None, db, None, None
 
 
+class _BCETargetFunction(torch.autograd.Function):
+    """weight * mean(bce_with_logits(x, y)) with a per-sample target vector y."""
+
+    @staticmethod
+    def forward(ctx, x, y, weight):
+        x_c = x.detach().float().contiguous()
+        y_c = y.detach().float().contiguous()
+        loss = torch.empty((), device=x.device, dtype=torch.float32)
+        K.bce_logits_target_fwd(x_c, y_c, weight, loss, False)
+        ctx.save_for_backward(x_c, y_c)
+        ctx.weight, ctx.shape = weight, x.shape
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x_c, y_c = ctx.saved_tensors
+        dx = torch.empty_like(x_c)
+        K.bce_logits_target_bwd(x_c, y_c, ctx.weight, grad_out.detach().float().contiguous(), dx, False)
+        return dx.view(ctx.shape), None, None
+
+
+class BCEWithLogitsLoss(nn.Module):
+    """``nn.BCEWithLogitsLoss()`` as the reference constructs it (mean reduction, no weights; ``src/models/uda.py:85``)."""
+
+    def forward(self, input, target):
+        _need_gpu(input, "BCEWithLogitsLoss")
+        if input.shape != target.shape:
+            raise ValueError(f"Target size ({tuple(target.shape)}) must be the same as input size ({tuple(input.shape)})")
+        return _BCETargetFunction.apply(input, target.to(input.device), 1.0)
+
+
+class MulticlassDiceLoss(nn.Module):
+    """``smp.losses.DiceLoss(mode='multiclass')`` with its defaults (from_logits, smooth 0, eps 1e-7, no ignore_index), the
+    segmentation term of the reference's ``UDALoss`` (``src/models/uda.py:84``): Dice pooled over batch and pixels per
+    class, classes absent from the batch's labels contribute 0, mean over all classes."""
+
+    def __init__(self, smooth=0.0, eps=1e-7):
+        super().__init__()
+        self.smooth, self.eps = smooth, eps
+
+    def forward(self, y_pred, y_true):
+        y_true = _check_seg_pair("MulticlassDiceLoss", y_pred, y_true)
+        return _SegLossFunction.apply(y_pred, y_true, None, 0.0, 0.0, True, float(self.smooth), 0.0, 1.0, float(self.eps), True)
+
+
 def _need_gpu(t, who):
     if t.device.type != "cuda":
         raise RuntimeError(f"{who}: predictions must live on the GPU (no CPU path in this build)")
@@ -152,7 +197,8 @@ class _SegLossFunction(torch.autograd.Function):
     """loss = focal_w * focal(logits, target) + dice_w * dice(logits, target); either weight may be 0 (term skipped)."""
 
     @staticmethod
-    def forward(ctx, logits, target, class_weights, alpha, gamma, mean, smooth, focal_w, dice_w):
+    def forward(ctx, logits, target, class_weights, alpha, gamma, mean, smooth, focal_w, dice_w, dice_eps=1e-7,
+                dice_pooled=False):
         n, c, h, w = logits.shape
         buf, ldc = _padded_nhwc(logits.detach())
         dev = logits.device
@@ -167,7 +213,7 @@ class _SegLossFunction(torch.autograd.Function):
             sums = torch.zeros(n * 3 * c, device=dev, dtype=torch.float64)
             coef = torch.empty(n * 2 * c, device=dev, dtype=torch.float32)
             dloss = torch.empty((), device=dev, dtype=torch.float32)
-            K.dice_fwd(buf, target, n, h * w, c, ldc, smooth, sums, coef, dloss)
+            K.dice_fwd(buf, target, n, h * w, c, ldc, smooth, sums, coef, dloss, dice_eps, dice_pooled)
             loss.add_(dloss, alpha=dice_w)
         ctx.save_for_backward(buf, target, class_weights, coef)
         ctx.cfg = (n, c, h, w, ldc, alpha, gamma, mean, focal_w, dice_w)
@@ -186,7 +232,7 @@ class _SegLossFunction(torch.autograd.Function):
             wrote = True
         if dice_w != 0.0:
             K.dice_bwd(buf, target, coef, g, dice_w, n, h * w, c, ldc, dl, wrote)
-        return (dl.permute(0, 3, 1, 2)[:, :c],) + (None,) * 8
+        return (dl.permute(0, 3, 1, 2)[:, :c],) + (None,) * 10
 
 
 class DiceLoss(nn.Module):

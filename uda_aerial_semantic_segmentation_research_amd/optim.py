@@ -45,17 +45,25 @@ class FusedAdam(torch.optim.Optimizer):
             if not ps:
                 continue
             lr, (b1, b2), eps = group["lr"], group["betas"], group["eps"]
-            flat = self._flat_view(ps) if ps[0].is_cuda else None
-            if flat is not None:
+            # one launch per parameter arena: a group may span several networks (e.g. segmenter + feature discriminator)
+            parts = {}
+            for p in ps:
+                parts.setdefault(p.untyped_storage().data_ptr(), []).append(p)
+            rest = []
+            for k, part in enumerate(parts.values()):
+                flat = self._flat_view(part) if part[0].is_cuda else None
+                if flat is None:
+                    rest.extend(part)
+                    continue
                 fp, fg = flat
-                st = self.state.setdefault(("flat", gi), {})
+                st = self.state.setdefault(("flat", gi) if k == 0 else ("flat", gi, k), {})
                 if "m" not in st or st["m"].numel() != fp.numel() or st["ptr"] != fp.data_ptr():
                     st["m"], st["v"] = torch.zeros_like(fp), torch.zeros_like(fp)
                     st["step"], st["ptr"] = st.get("step", 0), fp.data_ptr()
                 st["step"] += 1
                 t = st["step"]
                 K.adam_flat(fp, fg, st["m"], st["v"], fp.numel(), lr, b1, b2, eps, 1 - b1 ** t, 1 - b2 ** t)
-                continue
+            ps = rest
             # parameters that do not share an arena: same arithmetic, per tensor (dense tensors -> the kernel)
             for p in ps:
                 st = self.state[p]

@@ -176,19 +176,20 @@ class _UnetFunction(torch.autograd.Function):
     """One autograd node for the whole network: forward = kernel plan, backward = the reverse plan."""
 
     @staticmethod
-    def forward(ctx, net, x, *params):
-        logits_buf, tape = net._forward_plan(x, True)
-        ctx.net, ctx.tape = net, tape
-        return logits_buf.permute(0, 3, 1, 2)[:, : net.classes]
+    def forward(ctx, net, x, want, *params):
+        outs, tape = net._forward_plan(x, True, want)
+        ctx.net, ctx.tape, ctx.want = net, tape, want
+        ctx.set_materialize_grads(False)          # an output the loss never touched arrives as None, not as zeros
+        return outs[0] if len(outs) == 1 else tuple(outs)
 
     @staticmethod
-    def backward(ctx, dlogits):
+    def backward(ctx, *grads):
         net, tape = ctx.net, ctx.tape
         if tape is None:
             raise RuntimeError("Unet: backward needs a training-mode forward with grad enabled")
         ctx.tape = None
-        net._backward_plan(tape, dlogits)         # delivers .grad itself (arena views), see deliver_grads
-        return (None, None) + (None,) * len(net._param_list)
+        net._backward_plan(tape, dict(zip(ctx.want, grads)))   # delivers .grad itself (arena views), see deliver_grads
+        return (None, None, None) + (None,) * len(net._param_list)
 
 
 class Unet(ArenaModule):
@@ -225,8 +226,21 @@ class Unet(ArenaModule):
             self.set_compute_dtype(compute_dtype)
 
     # ------------------------------------------------------------------------------------------------ forward
+    OUTPUTS = ("logits", "decoder", "features")
+
     def forward(self, x):
+        return self.forward_parts(x, ("logits",))
+
+    def forward_parts(self, x, want=("logits",)):
+        """One pass, several differentiable results (all ``[N,C,h,w]``-shaped views of NHWC buffers), in ``want`` order:
+        ``"logits"`` -- what ``forward`` returns; ``"decoder"`` -- the decoder's 16-channel output before the head
+        (``model.decoder(*features)`` upstream, reference ``src/models/uda.py:68``); ``"features"`` -- the deepest encoder
+        feature (``model.encoder(x)[-1]``, reference ``src/models/uda.py:64,74-76``).  A single name returns a tensor,
+        several a tuple.  The head is only computed when ``"logits"`` is asked for."""
         require_gpu()
+        want = tuple(want)
+        if not want or any(w not in self.OUTPUTS for w in want) or len(set(want)) != len(want):
+            raise ValueError(f"forward_parts: want must be distinct names out of {self.OUTPUTS}, got {want}")
         if x.device.type != "cuda":
             raise RuntimeError("Unet.forward: input must live on the GPU (no CPU path in this build)")
         self.ensure_arena()
@@ -237,12 +251,12 @@ class Unet(ArenaModule):
                                f"divisible by 32.")  # smp's check_input_shape
         x = x.float()
         if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self._param_list):
-            return _UnetFunction.apply(self, x, *self._param_list)
+            return _UnetFunction.apply(self, x, want, *self._param_list)
         with torch.no_grad():                     # inference / validation: no tape, no autograd node
-            logits_buf, _ = self._forward_plan(x, False)
-        return logits_buf.permute(0, 3, 1, 2)[:, : self.classes]
+            outs, _ = self._forward_plan(x, False, want)
+        return outs[0] if len(outs) == 1 else tuple(outs)
 
-    def _forward_plan(self, x, save):
+    def _forward_plan(self, x, save, want=("logits",)):
         P = Plan(self, self.training, save)
         enc = self.encoder
         tape = []
@@ -262,41 +276,73 @@ class Unet(ArenaModule):
             h, rec = blk.fwd(P, h, skip)
             tape.append((blk, rec, h))
         head = self.segmentation_head[0]
-        logits, d_head = P.conv(head, h, out_dtype=torch.float32)     # logits stay fp32 (loss accuracy) in every mode
+        logits, d_head = None, None
+        if "logits" in want:
+            logits, d_head = P.conv(head, h, out_dtype=torch.float32)  # logits stay fp32 (loss accuracy) in every mode
         if self.training:
             self.tick_batchnorm_counters()
+        top = feats[-1]
+        views = {"logits": None if logits is None else logits.permute(0, 3, 1, 2)[:, : self.classes],
+                 "decoder": h.permute(0, 3, 1, 2)[:, : DECODER_CHANNELS[-1]],
+                 "features": top.permute(0, 3, 1, 2)[:, : self.encoder.out_channels[-1]]}
+        outs = [views[w] for w in want]
         if not save:
-            return logits, None
-        tape_all = (P, tape, (r_stem, f1, pooled, pidx), (head, d_head, h))
+            return outs, None
+        tape_all = (P, tape, (r_stem, f1, pooled, pidx), (head, d_head, h), top)
         if self.debug_keep_tape:
             self._last_tape = tape_all
-        return logits, tape_all
+        return outs, tape_all
 
     # ----------------------------------------------------------------------------------------------- backward
-    def _backward_plan(self, tape_all, dlogits):
-        P, tape, (r_stem, f1, pooled, pidx), (head, d_head, h_last) = tape_all
+    @staticmethod
+    def _seed(G, act, grad):
+        """Put an incoming NCHW-shaped gradient of activation ``act`` (NHWC, padded channels) into its gradient slot."""
+        buf, acc = G.slot(act)
+        c = grad.shape[1]
+        if not acc:
+            if buf.shape[-1] != c:
+                buf.zero_()
+            buf.permute(0, 3, 1, 2)[:, :c].copy_(grad)
+        else:
+            buf.permute(0, 3, 1, 2)[:, :c].add_(grad.to(buf.dtype))
+
+    def _backward_plan(self, tape_all, grads):
+        """grads: {"logits" | "decoder" | "features": NCHW-shaped gradient or None}, or the logits gradient itself."""
+        if torch.is_tensor(grads):
+            grads = {"logits": grads}
+        P, tape, (r_stem, f1, pooled, pidx), (head, d_head, h_last), top = tape_all
+        dlogits, d_dec, d_top = grads.get("logits"), grads.get("decoder"), grads.get("features")
+        if dlogits is None and d_dec is None and d_top is None:
+            return
         P.begin_backward()
         G = GradSlots()
-        n, _, hh, ww = dlogits.shape
-        cp = head.cout_p
-        # dlogits arrives NCHW-shaped; the CE kernel hands over the padded NHWC buffer as a strided view -- use it as is
-        if (dlogits.dtype == torch.float32 and dlogits.stride(1) == 1 and dlogits.stride(3) == cp
-                and dlogits.stride(2) == cp * ww and dlogits.stride(0) == cp * ww * hh and dlogits.storage_offset() == 0
-                and dlogits.untyped_storage().nbytes() >= 4 * n * hh * ww * cp):
-            dl = dlogits.as_strided((n, hh, ww, cp), (hh * ww * cp, ww * cp, cp, 1), 0)
-        else:
-            dl = torch.zeros((n, hh, ww, cp), device=dlogits.device, dtype=torch.float32)
-            dl.permute(0, 3, 1, 2)[:, : self.classes].copy_(dlogits)
-        dh, _ = G.slot(h_last)
-        from .losses import COLSUM_SIDE_TABLE
-        dbias = COLSUM_SIDE_TABLE.pop(dl.data_ptr(), None)     # made by ce_bwd in the same pass as dl, when it was
-        if P.bf16:
-            dl = K.cast_to_bf16(dl, st=P.st)                   # the head's dgrad / wgrad take bf16 operands
-        P.conv_bwd(head, d_head, h_last, dl, dx=dh, dx_acc=False, dbias=dbias)
         hook = self.grad_ready_hook
-        if hook is not None:
-            hook(P, P.offset_of(head))
+        if dlogits is not None:
+            n, _, hh, ww = dlogits.shape
+            cp = head.cout_p
+            # dlogits arrives NCHW-shaped; the CE kernel hands over the padded NHWC buffer as a strided view -- use it as is
+            if (dlogits.dtype == torch.float32 and dlogits.stride(1) == 1 and dlogits.stride(3) == cp
+                    and dlogits.stride(2) == cp * ww and dlogits.stride(0) == cp * ww * hh and dlogits.storage_offset() == 0
+                    and dlogits.untyped_storage().nbytes() >= 4 * n * hh * ww * cp):
+                dl = dlogits.as_strided((n, hh, ww, cp), (hh * ww * cp, ww * cp, cp, 1), 0)
+            else:
+                dl = torch.zeros((n, hh, ww, cp), device=dlogits.device, dtype=torch.float32)
+                dl.permute(0, 3, 1, 2)[:, : self.classes].copy_(dlogits)
+            dh, _ = G.slot(h_last)
+            from .losses import COLSUM_SIDE_TABLE
+            dbias = COLSUM_SIDE_TABLE.pop(dl.data_ptr(), None)     # made by ce_bwd in the same pass as dl, when it was
+            if P.bf16:
+                dl = K.cast_to_bf16(dl, st=P.st)                   # the head's dgrad / wgrad take bf16 operands
+            P.conv_bwd(head, d_head, h_last, dl, dx=dh, dx_acc=False, dbias=dbias)
+            if hook is not None:
+                hook(P, P.offset_of(head))
+        if d_dec is not None:
+            self._seed(G, h_last, d_dec)
+        if d_top is not None:
+            self._seed(G, top, d_top)
         for blk, rec, out in reversed(tape):
+            if not G.has(out):
+                continue                                           # e.g. the whole decoder when only "features" was used
             blk.bwd(P, G, rec, out)
             if hook is not None:
                 first = next(m for m in blk.modules() if isinstance(m, ConvP))
