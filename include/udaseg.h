@@ -218,6 +218,17 @@ int udaseg_bce_logits_target_bwd(const float* x, const float* target, int n, flo
 int udaseg_adam_flat(float* p, const float* g, float* m, float* v, int64_t count, float lr, float beta1, float beta2,
                      float eps, float bc1, float bc2, void* stream);
 
+/* ---- device-side input pipeline: uint8 RGB HWC images [n][h][w][3] (+ uint8 masks [n][h][w], may be NULL) ->
+ *      normalised, D4-augmented, channel-padded NHWC model input (fp32, or bf16 when out_bf16) and int64 masks.
+ *      Replaces the per-sample host work of src/data/dataset.py:116-138 with the geometric part of
+ *      src/models/augmentation.py:11-13 (RandomRotate90 / Flip / Transpose = one D4 element per sample) and
+ *      A.Normalize() (augmentation.py:36): out = (x - mean255[c]) * inv_std255[c] in fp32.
+ *      d4[n] (may be NULL = identity): bit0 transpose, bit1 flip rows, bit2 flip columns, applied in that order.
+ *      mean255 / inv_std255 are HOST arrays of 3 floats.  Transposing codes need h == w. ---- */
+int udaseg_prepare_batch_u8(const uint8_t* images, const uint8_t* masks, const int32_t* d4, int n, int h, int w,
+                            const float* mean255, const float* inv_std255, void* out_images, int cpad, int out_bf16,
+                            int64_t* out_masks, int square_checked, void* stream);
+
 /* ---- scratch: one caller-owned device buffer the library may use for split partial results (currently the
  *      small-channel weight gradient, <= 10 MiB).  Without it those calls take the generic atomics path. ---- */
 int udaseg_set_workspace(void* ptr, size_t bytes);

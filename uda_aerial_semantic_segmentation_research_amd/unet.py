@@ -249,18 +249,33 @@ class Unet(ArenaModule):
         if x.shape[2] % 32 or x.shape[3] % 32:
             raise RuntimeError(f"Wrong input shape height={x.shape[2]}, width={x.shape[3]}. Expected image height and width "
                                f"divisible by 32.")  # smp's check_input_shape
-        x = x.float()
+        if self._padded_input_view(x) is None:
+            x = x.float()
         if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self._param_list):
             return _UnetFunction.apply(self, x, want, *self._param_list)
         with torch.no_grad():                     # inference / validation: no tape, no autograd node
             outs, _ = self._forward_plan(x, False, want)
         return outs[0] if len(outs) == 1 else tuple(outs)
 
+    def _padded_input_view(self, x):
+        """``data.prepare_batch`` hands the images over as an [N,3,H,W]-shaped view of the channel-padded NHWC buffer the
+        stem convolution reads: recognise it (layout + dtype) and return that buffer, else None."""
+        cp = self.encoder.conv1.cin_p
+        n, c, h, w = x.shape
+        es = x.element_size()
+        if (x.dtype == self.compute_dtype and x.stride() == (h * w * cp, 1, w * cp, cp)
+                and x.untyped_storage().nbytes() - es * x.storage_offset() >= es * n * h * w * cp
+                and (x.data_ptr() % 16) == 0):
+            return x.as_strided((n, h, w, cp), (h * w * cp, w * cp, cp, 1), x.storage_offset())
+        return None
+
     def _forward_plan(self, x, save, want=("logits",)):
         P = Plan(self, self.training, save)
         enc = self.encoder
         tape = []
-        x4 = K.nchw_to_nhwc(x, enc.conv1.cin_p, P.st, dtype=P.adt)
+        x4 = self._padded_input_view(x.detach())
+        if x4 is None:
+            x4 = K.nchw_to_nhwc(x, enc.conv1.cin_p, P.st, dtype=P.adt)
         f1, r_stem = P.conv_bn_act(enc.conv1, enc.bn1, x4, *RELU)
         pooled, pidx = K.maxpool_fwd(f1, P.st)
         feats = [f1]
