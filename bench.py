@@ -28,6 +28,12 @@ import torch
 import torch.distributed as dist
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+WORKLOAD_TEXT = {
+    "segmentation": "source-only CE train step (zero_grad,fwd,CE,bwd,allreduce,Adam)",
+    "adversarial": "adversarial iteration (D step on 8 source + 8 target images, then segmenter step: CE + lambda*BCE)",
+    "inference": "validation step (eval forward with folded BN, CE, device-side confusion matrix)",
+}
+BF16_MFMA_PEAK_TFLOPS = 2500.0     # same guide: ~2.5 PF dense bf16 (never the 2:1-sparsity figure)
 R18_CONV_GFLOP_PER_IMAGE = 133.30  # fwd + dgrad + wgrad conv FLOPs per source image, r18-Unet @512^2
 
 
@@ -105,13 +111,21 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    # UDASEG_BENCH_SHARE_GPU=1 + UDASEG_BENCH_BACKEND=gloo: rehearsal of the N>1 control flow on a one-GPU box (all ranks on
+    # device 0, collectives through gloo); the real run is one rank per GPU over RCCL
+    share = os.environ.get("UDASEG_BENCH_SHARE_GPU", "0") == "1"
+    backend = os.environ.get("UDASEG_BENCH_BACKEND", "nccl")
+    local = 0 if share else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     rehearse = os.environ.get("UDASEG_DDP_REHEARSE", "0") in ("1", "2", "3")   # run the N>1 code path (NCCL, side stream) at world 1
     if world > 1 or rehearse:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from uda_aerial_semantic_segmentation_research_amd import kernels as K
     from uda_aerial_semantic_segmentation_research_amd.ddp import GradAllReducer, broadcast_parameters
@@ -139,6 +153,9 @@ def main():
             dist.broadcast(model._arena, 0)
         if os.environ.get("UDASEG_DDP_REHEARSE") != "3":               # "3": process group only
             trainer.grad_reducer = GradAllReducer(model, bucket_bytes=int(os.environ.get("UDASEG_DDP_BUCKET_MB", "32")) << 20)
+            if args.workload == "adversarial":
+                broadcast_parameters(trainer.discriminator)
+                trainer.d_grad_reducer = GradAllReducer          # its allreduce_now(): one collective over D's gradient arena
     opt = FusedAdam(model.parameters(), lr=1e-4)
     x, y = synthetic(args.batch, args.size, args.size, args.classes, seed=100 * rank, device=dev)
     if args.workload == "inference":
@@ -191,6 +208,11 @@ def main():
         from uda_aerial_semantic_segmentation_research_amd import engine as _engine
         was_side = _engine.SIDE_STREAM_WGRAD
         _engine.SIDE_STREAM_WGRAD = False
+        # only rank 0 runs this leg: no collective may be issued in it (the other ranks are already at the barrier below)
+        trainer.grad_reducer = None
+        model.grad_ready_hook = None
+        if hasattr(trainer, "d_grad_reducer"):
+            trainer.d_grad_reducer = None
         for _ in range(2):
             step()
         torch.cuda.synchronize()
@@ -222,8 +244,9 @@ def main():
         dom = kern[0]                                   # the kernel symbol with the most device time
         achieved = dom[2] / (dom[1] * 1e-3) / 1e12
         conv_ms = sum(k[1] for k in kern) / psteps
-        roofline = {"bound": "mfma", "kernel": dom[0], "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(dom[0]),
+        peak = BF16_MFMA_PEAK_TFLOPS if args.dtype == "bf16" else FP32_MFMA_PEAK_TFLOPS
+        roofline = {"bound": "mfma", "kernel": dom[0], "achieved": round(achieved, 2), "peak": peak,
+                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": pmc_traffic(dom[0]),
                     "launches_per_step": dom[3] // psteps, "avg_launch_us": round(1e3 * dom[1] / dom[3], 2),
                     "gflop_per_launch": round(dom[2] / dom[3] / 1e9, 3),
                     "ms_per_step": round(dom[1] / psteps, 3),
@@ -244,11 +267,12 @@ def main():
             else f"{args.workload} images/sec at 512x512 (informational, {args.dtype})", "value": round(value, 2), "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{args.encoder}-Unet source-only CE train step (zero_grad,fwd,CE,bwd,allreduce,Adam), "
+            "config": {"workload": f"{args.encoder}-Unet " + WORKLOAD_TEXT[args.workload] + ", "
                                    f"batch {args.batch}x3x{args.size}x{args.size} per GPU, {args.classes} classes, random init",
                        "global_batch": args.batch * world, "image": f"{args.size}x{args.size}", "parallelism": f"dp{world}",
                        "final_loss": round(final_loss, 5),
-                       "conv_mfma_util_per_gpu": round(conv_tflops / FP32_MFMA_PEAK_TFLOPS, 4) if conv_tflops else None},
+                       "conv_mfma_util_per_gpu": round(conv_tflops / (BF16_MFMA_PEAK_TFLOPS if args.dtype == "bf16"
+                                                                      else FP32_MFMA_PEAK_TFLOPS), 4) if conv_tflops else None},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
