@@ -54,7 +54,14 @@ struct IgemmArgs {
   signed char dy[64];
   signed char dx[64];
   unsigned char wt[64];
+  // uniform-tap fast path (ci a multiple of the K-tile: every thread of a block is in the same tap during a K-step)
+  int uniform;                 // host-side selector
+  unsigned x_bytes, w_bytes;   // operand sizes for the buffer descriptors (range-checked loads: out of range reads 0)
+  int tap_xoff[32];            // ((dy*wi + dx) * ci) * element_size
+  int tap_woff[32];            // wt * ci * element_size
 };
+
+__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};   // what a masked-out gather lane reads
 
 constexpr int STATS_REPLICAS = 16;  // == udaseg_bn_replicas() (norm_act.hip)
 constexpr int BK = 32;
@@ -69,7 +76,13 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // BF = true : bf16 storage, v_mfma_f32_32x32x16_bf16, 64 K-elements per tile, fp32 accumulation / bias / statistics.
 // Both stage 128 bytes per row per tile with 16-byte loads, so gather, LDS layout and fragment reads are byte-identical;
 // a lane's 16-byte LDS read is 4 fp32 (-> 4 MFMAs) or 8 bf16 (-> exactly one bf16 MFMA's K slice: k = 16s + 8*lh + j).
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool BF>
+// UNI = true: the uniform-tap main loop.  The generic loop spends ~54 VALU instructions per wave per K-step on gather
+// addresses (tap lookup, bounds tests, 64-bit address arithmetic); fp32 MFMA runs on the same ALUs as the VALU
+// (SQ_VALU_MFMA_COEXEC_CYCLES = 0 on this kernel), so those instructions come straight out of the matrix rate.  Here the
+// tap of a K-step is a scalar, the per-row validity of every tap is a bit mask built once per tile, addresses are 32-bit
+// offsets into range-checked buffer loads (a masked-out lane gets bit 31 set and reads zeros): 3 VALU per A row-load,
+// 1 per B row-load.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool BF, bool UNI>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
   constexpr int ES = BF ? 2 : 4;        // element bytes
   constexpr int EPV = 16 / ES;          // elements per 16-byte vector
@@ -142,6 +155,28 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
     b_off[p] = (n < a.co && (lrow + 32 * p) < BN) ? n * a.tfull * a.ci : -1;
   }
 
+  // uniform path: byte offset of (row's pixel, this thread's 16-byte K column) and the row's per-tap "invalid" bits
+  unsigned u_aoff[A_PASS], u_ainv[A_PASS], u_boff[B_PASS];
+  if constexpr (UNI) {
+#pragma unroll
+    for (int p = 0; p < A_PASS; ++p) {
+      unsigned inv = 0xffffffffu;
+      if (a_iy[p] > -(1 << 19)) {
+        inv = 0u;
+        for (int t = 0; t < cnt; ++t) {
+          const int iy = a_iy[p] + a.dy[toff + t], ix = a_ix[p] + a.dx[toff + t];
+          const bool ok = (unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi;
+          inv |= (ok ? 0u : 1u) << t;
+        }
+      }
+      u_ainv[p] = inv;
+      u_aoff[p] = ((unsigned)(a_base[p] + a_iy[p] * a.wi + a_ix[p]) * (unsigned)a.ci + (unsigned)(kq * EPV)) * (unsigned)ES;
+    }
+#pragma unroll
+    for (int p = 0; p < B_PASS; ++p)
+      u_boff[p] = b_off[p] >= 0 ? ((unsigned)b_off[p] + (unsigned)(kq * EPV)) * (unsigned)ES : 0x80000000u;
+  }
+
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -150,14 +185,51 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
 #pragma unroll
       for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
 
-  f32x4 ra[A_PASS], rb[B_PASS];
+  // Two register stages (S0, S1): the global loads of K-tile kt+2 are issued before the MFMA phase of tile kt and are only
+  // waited for one whole iteration later (just before they are written to LDS), so two tiles' loads are in flight per
+  // wave.  Loads are UNCONDITIONAL: out-of-range taps / rows / K tails read a 16-byte block of zeros in global memory
+  // instead (address select BEFORE the load, nothing to fix up after it).  With exec-masked loads the compiler cannot
+  // count outstanding loads and falls back to s_waitcnt vmcnt(0); with a select after the load it waits for the data in
+  // the iteration that issued it -- either way the two stages would serialise.
+  f32x4 ra0[A_PASS], rb0[B_PASS], ra1[A_PASS], rb1[B_PASS];
   const int nkt = (cK + BKE - 1) / BKE;
-  const char* xb = static_cast<const char*>(a.x);
-  const char* wb = static_cast<const char*>(a.w);
+  // all three as integers: the zero block's address goes through an empty asm so the compiler cannot tell it is a known
+  // global (it would turn  *(ok ? p : zero)  into  ok ? *p : 0  again), and the loads are typed global explicitly
+  typedef const __attribute__((address_space(1))) f32x4* gvec_t;
+  const uint64_t xb = reinterpret_cast<uint64_t>(a.x);
+  const uint64_t wb = reinterpret_cast<uint64_t>(a.w);
+  uint64_t zp = reinterpret_cast<uint64_t>(&g_zero16[0]);
+  asm volatile("" : "+s"(zp));
 
   __syncthreads();  // tap table visible
 
-  auto load_tile = [&](int kt) {
+  __amdgpu_buffer_rsrc_t rsrc_x, rsrc_w;
+  if constexpr (UNI) {
+    rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+    rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, (int)a.w_bytes, 0x00020000);
+  }
+  int u_tl = 0, u_c0 = 0;                     // uniform path: local tap / byte offset inside the tap of the NEXT tile to load
+  const int u_cend = a.ci * ES;
+  auto load_tile = [&](int kt, f32x4* ra, f32x4* rb) {
+    if constexpr (UNI) {
+      // tiles are requested in order 0, 1, 2, ...: scalar bookkeeping instead of a division per K-step
+      const int tl = u_tl, c0 = u_c0;
+      u_c0 += BKE * ES;
+      if (u_c0 == u_cend) {
+        u_c0 = 0;
+        ++u_tl;
+      }
+      const unsigned s_x = (unsigned)(a.tap_xoff[toff + tl] + c0), s_w = (unsigned)(a.tap_woff[toff + tl] + c0);
+#pragma unroll
+      for (int p = 0; p < A_PASS; ++p) {
+        const unsigned voff = (u_aoff[p] + s_x) + ((u_ainv[p] >> tl) << 31);
+        ra[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)voff, 0, 0));
+      }
+#pragma unroll
+      for (int p = 0; p < B_PASS; ++p)
+        rb[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (int)(u_boff[p] + s_w), 0, 0));
+      return;
+    }
     const int kk = kt * BKE + kq * EPV;
     const bool kvalid = kk < cK;
     int t = (int)(((float)kk + 0.5f) * a.inv_ci);
@@ -169,24 +241,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
     for (int p = 0; p < A_PASS; ++p) {
       const int iy = a_iy[p] + dyt, ix = a_ix[p] + dxt;
       const bool ok = kvalid && (unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok) {
-        const size_t off = (size_t)(a_base[p] + iy * a.wi + ix) * (size_t)a.ci + (size_t)c;
-        v = *reinterpret_cast<const f32x4*>(xb + off * ES);
-      }
-      ra[p] = v;
+      const size_t off = (size_t)(a_base[p] + iy * a.wi + ix) * (size_t)a.ci + (size_t)c;
+      ra[p] = *reinterpret_cast<gvec_t>(ok ? xb + off * ES : zp);
     }
 #pragma unroll
     for (int p = 0; p < B_PASS; ++p) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (kvalid && b_off[p] >= 0) {
-        const size_t off = (size_t)b_off[p] + (size_t)(wtt * a.ci + c);
-        v = *reinterpret_cast<const f32x4*>(wb + off * ES);
-      }
-      rb[p] = v;
+      const bool ok = kvalid && b_off[p] >= 0;
+      const size_t off = (size_t)b_off[p] + (size_t)(wtt * a.ci + c);
+      rb[p] = *reinterpret_cast<gvec_t>(ok ? wb + off * ES : zp);
     }
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf, const f32x4* ra, const f32x4* rb) {
     float* Ad = As + buf * BM * LDS_LD;
     float* Bd = Bs + buf * BN * LDS_LD;
 #pragma unroll
@@ -196,19 +261,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
     for (int p = 0; p < B_PASS; ++p)
       if (lrow + 32 * p < BN) *reinterpret_cast<f32x4*>(Bd + (lrow + 32 * p) * LDS_LD + kq * 4) = rb[p];
   };
-
-  if (nkt > 0) {
-    load_tile(0);
-    store_tile(0);
-  }
-  __syncthreads();
-
-  int cur = 0;
-  for (int kt = 0; kt < nkt; ++kt) {
-    const bool more = (kt + 1) < nkt;
-    if (more) load_tile(kt + 1);
-    const float* Ac = As + cur * BM * LDS_LD + (wm + lr) * LDS_LD + lh * 4;
-    const float* Bc = Bs + cur * BN * LDS_LD + (wn + lr) * LDS_LD + lh * 4;
+  auto mfma_tile = [&](int buf) {
+    const float* Ac = As + buf * BM * LDS_LD + (wm + lr) * LDS_LD + lh * 4;
+    const float* Bc = Bs + buf * BN * LDS_LD + (wn + lr) * LDS_LD + lh * 4;
 #pragma unroll
     for (int s = 0; s < BK / 8; ++s) {
       f32x4 af[TM], bf[TN];
@@ -233,10 +288,49 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][k2], bf[j][k2], acc[i][j], 0, 0, 0);
       }
     }
-    if (more) store_tile(cur ^ 1);
-    __syncthreads();
-    cur ^= 1;
+  };
+
+  // invariant at the top of a pair: tile kt sits in LDS buffer 0, tile kt+1 (if any) is in flight in stage S1
+  int kt = 0;
+  if (nkt > 0) {
+    load_tile(0, ra0, rb0);
+    if (nkt > 1) load_tile(1, ra1, rb1);
+    store_tile(0, ra0, rb0);
   }
+  // enter the steady-state loop with no load outstanding: the compiler's wait-count bookkeeping merges the loop-entry
+  // state into the loop header, and loads left pending here (in prologue registers) cost a vmcnt wait at the top of
+  // EVERY iteration
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
+  __syncthreads();
+  for (; kt + 3 < nkt; kt += 2) {
+    load_tile(kt + 2, ra0, rb0);
+    mfma_tile(0);
+    store_tile(1, ra1, rb1);
+    __syncthreads();
+    load_tile(kt + 3, ra1, rb1);
+    mfma_tile(1);
+    store_tile(0, ra0, rb0);
+    __syncthreads();
+  }
+  const int rem = nkt - kt;   // 0 (nkt == 0), 1, 2 or 3 tiles left
+  if (rem == 3) {
+    load_tile(kt + 2, ra0, rb0);
+    mfma_tile(0);
+    store_tile(1, ra1, rb1);
+    __syncthreads();
+    mfma_tile(1);
+    store_tile(0, ra0, rb0);
+    __syncthreads();
+    mfma_tile(0);
+  } else if (rem == 2) {
+    mfma_tile(0);
+    store_tile(1, ra1, rb1);
+    __syncthreads();
+    mfma_tile(1);
+  } else if (rem == 1) {
+    mfma_tile(0);
+  }
+  __syncthreads();   // every wave is done with the LDS tiles (the statistics epilogue reuses them)
 
   // ---- epilogue: D[i][j] reg v of lane (lr, lh) = C[row = (v&3) + 8*(v>>2) + 4*lh][col = lr]
   const int ccy = a.cy[cls], ccx = a.cx[cls];
@@ -331,11 +425,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
 
 // ------------------------------------------------------------------------------------------------- host side
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool BF>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool BF, bool UNI>
 static int launch_cfg_t(const IgemmArgs& a, hipStream_t s) {
   static bool attr_done = false;
   constexpr int lds = igemm_lds_bytes<BM, BN>();
-  auto kern = conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, BF>;
+  auto kern = conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, BF, UNI>;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv_igemm)");
@@ -362,8 +456,40 @@ static int launch_cfg_t(const IgemmArgs& a, hipStream_t s) {
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 static int launch_cfg(const IgemmArgs& a, hipStream_t s) {
-  if (a.bf16) return launch_cfg_t<BM, BN, WAVES_M, WAVES_N, true>(a, s);
-  return launch_cfg_t<BM, BN, WAVES_M, WAVES_N, false>(a, s);
+  if (a.uniform) {
+    if (a.bf16) return launch_cfg_t<BM, BN, WAVES_M, WAVES_N, true, true>(a, s);
+    return launch_cfg_t<BM, BN, WAVES_M, WAVES_N, false, true>(a, s);
+  }
+  if (a.bf16) return launch_cfg_t<BM, BN, WAVES_M, WAVES_N, true, false>(a, s);
+  return launch_cfg_t<BM, BN, WAVES_M, WAVES_N, false, false>(a, s);
+}
+
+static int uniform_off() {
+  static int v = -1;   // tuning aid: UDASEG_IGEMM_GENERIC=1 keeps every layer on the generic gather loop
+  if (v < 0) {
+    const char* e = getenv("UDASEG_IGEMM_GENERIC");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
+
+// Decide whether a fully described launch can take the uniform-tap loop and fill its tables.
+static void finish_args(IgemmArgs& a, long long x_elems, long long w_elems) {
+  const int es = a.bf16 ? 2 : 4, bke = BK * 4 / es;
+  int total = 0;
+  for (int c = 0; c < a.nclass; ++c) total = a.tap_off[c] + a.ntaps[c] > total ? a.tap_off[c] + a.ntaps[c] : total;
+  a.uniform = 0;
+  a.x_bytes = a.w_bytes = 0;
+  if (uniform_off() || a.ci % bke != 0 || total > 32 || x_elems * es > (1LL << 30) || w_elems * es > (1LL << 30)) return;
+  for (int c = 0; c < a.nclass; ++c)
+    if (a.ntaps[c] > 32 || a.K[c] != a.ntaps[c] * a.ci) return;
+  for (int t = 0; t < total; ++t) {
+    a.tap_xoff[t] = (a.dy[t] * a.wi + a.dx[t]) * a.ci * es;
+    a.tap_woff[t] = a.wt[t] * a.ci * es;
+  }
+  a.x_bytes = (unsigned)(x_elems * es);
+  a.w_bytes = (unsigned)(w_elems * es);
+  a.uniform = 1;
 }
 
 static int tile_override() {
@@ -388,16 +514,11 @@ static int launch_igemm(const IgemmArgs& a, hipStream_t s) {
     case 4: return launch_cfg<128, 32, 4, 1>(a, s);
     default: break;
   }
-  // tile choice (measured per shape, profiles/r01_tile_ab.txt): 64x64 wins or ties whenever a 128-row tiling leaves
-  // fewer than ~1.5 blocks per CU; 128-wide tiles only for the big-M layers; 128x32 for <= 32 output channels.
-  if (a.co > 64) {
-    if (tiles128 * cdiv(a.co, 128) >= 384) return launch_cfg<128, 128, 2, 2>(a, s);
-    return launch_cfg<64, 64, 2, 2>(a, s);
-  }
-  if (a.co > 32) {
-    if (tiles128 >= 384) return launch_cfg<128, 64, 2, 2>(a, s);
-    return launch_cfg<64, 64, 2, 2>(a, s);
-  }
+  // tile choice, re-measured per shape after the uniform-tap loop went in (profiles/r01_tile_ab.txt): with the gather
+  // address arithmetic out of the K loop the 64x64 tile (4 blocks per CU) wins or ties on every layer with more than 32
+  // output channels, 128x32 on the rest; the 128-row tiles stay selectable through UDASEG_IGEMM_TILE.
+  (void)tiles128;
+  if (a.co > 32) return launch_cfg<64, 64, 2, 2>(a, s);
   return launch_cfg<128, 32, 4, 1>(a, s);
 }
 
@@ -496,6 +617,7 @@ static int conv2d_fwd_impl(const udaseg_conv_desc* d, const void* x, const void*
       if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(conv out)");
     }
   }
+  finish_args(a, (long long)d->n * d->hi * d->wi * d->ci, (long long)d->co * ntaps * d->ci);
   rc = launch_igemm(a, st);
   prof_end(0, st, udaseg_conv_flops(d), 0, d);
   if (rc == UDASEG_OK && stats && ns > 1) rc = udaseg_bn_stats(static_cast<const float*>(y), (int64_t)M, d->co, stats, stream);
@@ -590,6 +712,7 @@ static int conv2d_dgrad_impl(const udaseg_conv_desc* d, const void* dy, const vo
       }
     }
   }
+  finish_args(a, (long long)d->n * d->ho * d->wo * d->co, (long long)d->ci * d->kh * d->kw * d->co);
   rc = launch_igemm(a, st);
   // dgrad FLOPs equal the forward's (every (pixel, tap, ci, co) product appears once)
   prof_end(0, st, udaseg_conv_flops(d), 1, d);

@@ -30,11 +30,18 @@ struct WgradArgs {
   int kchunk;        // pixels per split (multiple of 32)
   int use_atomic;
   float inv_ci, inv_kw, inv_wo, inv_ho;
+  int row_uniform;   // host-side selector of the row-uniform gather (see conv_wgrad_kernel)
+  unsigned x_bytes, dy_bytes;
 };
 
 constexpr int WBK = 32;  // pixels per K-tile
 
-template <int BMW, int BNW, int WAVES_M, int WAVES_N>
+// ROWU = true: row-uniform gather.  When the output width is a multiple of the rows one load pass covers, the pixels of a
+// pass share their image row: (image, oy, first ox) are SCALARS updated once per K-tile, a thread's gather address is
+// scalar + per-thread constant, and the bounds test is two adds and two compares; loads are range-checked buffer loads
+// (invalid lanes get an out-of-range offset and read zeros).  The generic loop spends two divisions and a 64-bit address
+// per gathered row per K-tile in the VALU, which on gfx950 shares its ALUs with the fp32 MFMA.
+template <int BMW, int BNW, int WAVES_M, int WAVES_N, bool ROWU>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
   constexpr int WM = BMW / WAVES_M, WN = BNW / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -85,7 +92,57 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
   f32x4 ra[A_PASS], rb[B_PASS];
   const int nkt = (kend - kbeg + WBK - 1) / WBK;
 
+  // row-uniform state: per-thread constants and per-pass scalars of the NEXT tile to load (tiles are loaded in order)
+  unsigned u_ac[A_PASS], u_bc = 0;
+  int u_bdy = 0, u_bx = 0;
+  int s_ni[B_PASS], s_oy[B_PASS], s_ox[B_PASS];
+  unsigned s_dyoff = 0;
+  __amdgpu_buffer_rsrc_t rsrc_x, rsrc_dy;
+  if constexpr (ROWU) {
+    rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+    rsrc_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dy), 0, (int)a.dy_bytes, 0x00020000);
+#pragma unroll
+    for (int p = 0; p < A_PASS; ++p)
+      u_ac[p] = a_ok ? (unsigned)((arow + A_ROWS * p) * a.co + a_co) * 4u : 0x80000000u;
+    u_bc = b_ok ? (unsigned)((b_dy * a.wi + brow * a.stride + b_dx) * a.ci + b_c) * 4u : 0x80000000u;
+    u_bdy = b_dy;
+    u_bx = brow * a.stride + b_dx;
+    s_dyoff = (unsigned)kbeg * (unsigned)a.co * 4u;
+#pragma unroll
+    for (int p = 0; p < B_PASS; ++p) {
+      const int m = kbeg + B_ROWS * p;          // uniform
+      const int t1 = m / a.wo;
+      s_ox[p] = m - t1 * a.wo;
+      s_ni[p] = t1 / a.ho;
+      s_oy[p] = t1 - s_ni[p] * a.ho;
+    }
+  }
+
   auto load_tile = [&](int kt) {
+    if constexpr (ROWU) {
+#pragma unroll
+      for (int p = 0; p < A_PASS; ++p)
+        ra[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_dy, (int)(u_ac[p] + s_dyoff), 0, 0));
+      s_dyoff += (unsigned)(WBK * 4) * (unsigned)a.co;
+#pragma unroll
+      for (int p = 0; p < B_PASS; ++p) {
+        const int oys = s_oy[p] * a.stride, oxs = s_ox[p] * a.stride;                                   // scalars
+        const unsigned s_off = (unsigned)(((s_ni[p] * a.hi + oys) * a.wi + oxs) * a.ci) * 4u;          // scalar
+        const bool ok = (unsigned)(oys + u_bdy) < (unsigned)a.hi && (unsigned)(oxs + u_bx) < (unsigned)a.wi;
+        const unsigned voff = ok ? u_bc + s_off : 0x80000000u;
+        rb[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)voff, 0, 0));
+        // advance this pass by one K-tile (32 pixels); wo is a multiple of B_ROWS, so a pass never straddles image rows
+        s_ox[p] += WBK;
+        while (s_ox[p] >= a.wo) {
+          s_ox[p] -= a.wo;
+          if (++s_oy[p] == a.ho) {
+            s_oy[p] = 0;
+            ++s_ni[p];
+          }
+        }
+      }
+      return;
+    }
     const int mb = kbeg + kt * WBK;
 #pragma unroll
     for (int p = 0; p < A_PASS; ++p) {
@@ -341,7 +398,20 @@ static int launch_wgrad(WgradArgs a, int accumulate, hipStream_t s, bool bf16 = 
     hipLaunchKernelGGL((conv_wgrad_bf16_kernel<BMW, BNW, WAVES_M, WAVES_N>), grid, block, 0, s, a);
     kprof_end(13, ev, s, 2.0 * (double)a.M * a.co * a.J);
   } else {
-    hipLaunchKernelGGL((conv_wgrad_kernel<BMW, BNW, WAVES_M, WAVES_N>), grid, block, 0, s, a);
+    constexpr int b_rows = 256 / (BNW / 4);
+    static int generic = -1;   // tuning aid: UDASEG_WGRAD_GENERIC=1 keeps the generic gather loop
+    if (generic < 0) {
+      const char* e = getenv("UDASEG_WGRAD_GENERIC");
+      generic = e ? atoi(e) : 0;
+    }
+    const long long xb = (long long)a.M / (a.ho * a.wo) * a.hi * a.wi * a.ci * 4, dyb = (long long)a.M * a.co * 4;
+    a.row_uniform = !generic && a.wo % b_rows == 0 && xb <= (1LL << 30) && dyb <= (1LL << 30);
+    a.x_bytes = (unsigned)xb;
+    a.dy_bytes = (unsigned)dyb;
+    if (a.row_uniform)
+      hipLaunchKernelGGL((conv_wgrad_kernel<BMW, BNW, WAVES_M, WAVES_N, true>), grid, block, 0, s, a);
+    else
+      hipLaunchKernelGGL((conv_wgrad_kernel<BMW, BNW, WAVES_M, WAVES_N, false>), grid, block, 0, s, a);
     kprof_end(BMW == 64 ? 7 : 8, ev, s, 2.0 * (double)a.M * a.co * a.J);
   }
   UDASEG_LAUNCH_CHECK("conv_wgrad launch");
