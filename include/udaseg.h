@@ -110,16 +110,19 @@ int udaseg_bn_apply_eval(const float* y, const float* gamma, const float* beta, 
  * bias_folded[co] = beta + (bias - mean) * gamma/sqrt(var+eps).  bias may be NULL. */
 int udaseg_bn_fold(const float* w, const float* bias, const float* gamma, const float* beta, const float* running_mean,
                    const float* running_var, float eps, int co, int row_len, float* w_folded, float* bias_folded, void* stream);
-/* backward, pass 1: g = dz * act'(z); bsums[0][c] += sum g, bsums[1][c] += sum g*xhat (doubles, caller-zeroed) */
+/* backward, pass 1: g = dz * act'(z); bsums[0][c] += sum g, bsums[1][c] += sum g*xhat (doubles, caller-zeroed).
+ * z may be NULL when the layer had no residual input: the activation's argument is then re-evaluated from y, gamma and
+ * beta (the same fused multiply-add as udaseg_bn_apply), which saves one pass over the activation; gamma / beta are only
+ * read in that case. */
 int udaseg_bn_bwd_reduce(const float* dz, const float* z, const float* y, const float* save_mean,
-                         const float* save_rstd, int64_t pixels, int c, double* bsums, int act, float slope,
-                         void* stream);
+                         const float* save_rstd, const float* gamma, const float* beta, int64_t pixels, int c,
+                         double* bsums, int act, float slope, void* stream);
 /* backward, pass 2: dy (+)= gamma*rstd*(g - mean(g) - xhat*mean(g*xhat)); dres (+)= g if dres != NULL;
- * dgamma/dbeta (+)= from bsums. */
+ * dgamma/dbeta (+)= from bsums.  z may be NULL as in pass 1 (then beta is read). */
 int udaseg_bn_bwd_apply(const float* dz, const float* z, const float* y, const float* save_mean,
-                        const float* save_rstd, const float* gamma, const double* bsums, float* dy, float* dres,
-                        float* dgamma, float* dbeta, int64_t pixels, int c, int act, float slope, int accumulate_dy,
-                        int accumulate_dres, int accumulate_param, void* stream);
+                        const float* save_rstd, const float* gamma, const float* beta, const double* bsums, float* dy,
+                        float* dres, float* dgamma, float* dbeta, int64_t pixels, int c, int act, float slope,
+                        int accumulate_dy, int accumulate_dres, int accumulate_param, void* stream);
 /* plain activation backward for a conv+bias+act epilogue (discriminator layer 1): dy = dz * act'(z) */
 int udaseg_act_bwd(const float* dz, const float* z, float* dy, int64_t count, int act, float slope, void* stream);
 /* out[c] (+)= sum over pixels of x[p][c]  (bias gradients) */

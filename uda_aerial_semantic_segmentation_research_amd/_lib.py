@@ -46,8 +46,8 @@ SIGNATURES = {
     "udaseg_bn_apply": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _F, _F, _P, _P, _P, _P, _I, _F, _P]),
     "udaseg_bn_apply_eval": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _F, _P]),
     "udaseg_bn_fold": (_I, [_P, _P, _P, _P, _P, _P, _F, _I, _I, _P, _P, _P]),
-    "udaseg_bn_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _L, _I, _P, _I, _F, _P]),
-    "udaseg_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _I, _I, _I, _P]),
+    "udaseg_bn_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _I, _F, _P]),
+    "udaseg_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _I, _I, _I, _P]),
     "udaseg_act_bwd": (_I, [_P, _P, _P, _L, _I, _F, _P]),
     "udaseg_channel_sum": (_I, [_P, _L, _I, _P, _I, _P]),
     "udaseg_maxpool3x3s2_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),

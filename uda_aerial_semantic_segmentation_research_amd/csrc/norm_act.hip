@@ -109,7 +109,10 @@ __global__ void bn_apply_kernel(const f32x4* __restrict__ y, const double* __res
   const float4 sc4 = coef[q], sh4 = coef[c4 + q];
   const f32x4 scale = {sc4.x, sc4.y, sc4.z, sc4.w}, shift = {sh4.x, sh4.y, sh4.z, sh4.w};
   for (int64_t i = g; i < n4; i += T) {
-    f32x4 v = y[i] * scale + shift;
+    const f32x4 yy = y[i];
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(yy[e], scale[e], shift[e]);   // the backward re-evaluates exactly this
     if (residual) v += residual[i];
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], act, slope);
@@ -141,29 +144,44 @@ __global__ void bn_apply_eval_kernel(const f32x4* __restrict__ y, const float* _
   }
 }
 
+// z == nullptr with an activation: the layer had no residual input, so the activation's argument is bn(y) itself and is
+// re-evaluated from y (same fused multiply-add, same coefficients as bn_apply_kernel) instead of reading z: one fewer
+// pass over the activation in each of the two backward kernels.
 __global__ void bn_bwd_reduce_kernel(const f32x4* __restrict__ dz, const f32x4* __restrict__ z,
                                      const f32x4* __restrict__ y, const float* __restrict__ save_mean,
-                                     const float* __restrict__ save_rstd, int64_t n4, int c4,
+                                     const float* __restrict__ save_rstd, const float* __restrict__ gamma,
+                                     const float* __restrict__ beta, int64_t n4, int c4,
                                      double* __restrict__ bsums, int act, float slope) {
   __shared__ d4 red[256];
   const int64_t T = (int64_t)gridDim.x * blockDim.x;
   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int q = (int)(g % c4);
-  f32x4 mean, rstd;
+  f32x4 mean, rstd, sc = {0, 0, 0, 0}, sh = {0, 0, 0, 0};
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     mean[e] = save_mean[q * 4 + e];
     rstd[e] = save_rstd[q * 4 + e];
+    if (!z && act != UDASEG_ACT_NONE) {
+      sc[e] = gamma[q * 4 + e] * rstd[e];
+      sh[e] = beta[q * 4 + e] - mean[e] * sc[e];
+    }
   }
   d4 sg = {{0, 0, 0, 0}}, sgx = {{0, 0, 0, 0}};
   for (int64_t i = g; i < n4; i += T) {
     f32x4 gz = dz[i];
+    const f32x4 yy = y[i];
     if (act != UDASEG_ACT_NONE) {
-      const f32x4 zz = z[i];
+      f32x4 zz;
+      if (z) {
+        zz = z[i];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) zz[e] = __builtin_fmaf(yy[e], sc[e], sh[e]);
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) gz[e] *= act_grad(zz[e], act, slope);
     }
-    const f32x4 xh = (y[i] - mean) * rstd;
+    const f32x4 xh = (yy - mean) * rstd;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       sg.v[e] += (double)gz[e];
@@ -178,13 +196,15 @@ __global__ void bn_bwd_reduce_kernel(const f32x4* __restrict__ dz, const f32x4* 
 __global__ void bn_bwd_apply_kernel(const f32x4* __restrict__ dz, const f32x4* __restrict__ z,
                                     const f32x4* __restrict__ y, const float* __restrict__ save_mean,
                                     const float* __restrict__ save_rstd, const float* __restrict__ gamma,
-                                    const double* __restrict__ bsums, f32x4* __restrict__ dy, f32x4* __restrict__ dres,
+                                    const float* __restrict__ beta, const double* __restrict__ bsums,
+                                    f32x4* __restrict__ dy, f32x4* __restrict__ dres,
                                     float* dgamma, float* dbeta, int64_t n4, int c4, int64_t pixels, int act,
                                     float slope, int acc_dy, int acc_dres, int acc_param) {
-  extern __shared__ __attribute__((aligned(16))) float4 coef[];  // [5][c4]: mean, rstd, scale, mean(g), mean(g*xhat)
+  extern __shared__ __attribute__((aligned(16))) float4 coef[];  // [6][c4]: mean, rstd, scale, mean(g), mean(g*xhat), shift
   const double inv = 1.0 / (double)pixels;
+  const bool recompute = !z && act != UDASEG_ACT_NONE;
   for (int q = threadIdx.x; q < c4; q += blockDim.x) {
-    float4 v[5];
+    float4 v[6];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int c = q * 4 + e;
@@ -200,6 +220,7 @@ __global__ void bn_bwd_apply_kernel(const f32x4* __restrict__ dz, const f32x4* _
       reinterpret_cast<float*>(&v[2])[e] = gamma[c] * rs;
       reinterpret_cast<float*>(&v[3])[e] = (float)(s1 * inv);
       reinterpret_cast<float*>(&v[4])[e] = (float)(s2 * inv);
+      reinterpret_cast<float*>(&v[5])[e] = recompute ? beta[c] - save_mean[c] * (gamma[c] * rs) : 0.f;
       if (blockIdx.x == 0) {
         const float db = (float)s1, dg = (float)s2;
         if (dbeta) dbeta[c] = acc_param ? dbeta[c] + db : db;
@@ -207,15 +228,17 @@ __global__ void bn_bwd_apply_kernel(const f32x4* __restrict__ dz, const f32x4* _
       }
     }
 #pragma unroll
-    for (int k = 0; k < 5; ++k) coef[k * c4 + q] = v[k];
+    for (int k = 0; k < 6; ++k) coef[k * c4 + q] = v[k];
   }
   __syncthreads();
   const int64_t T = (int64_t)gridDim.x * blockDim.x;
   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int q = (int)(g % c4);
-  f32x4 mean, rstd, scale, mg, mgx;
+  f32x4 mean, rstd, scale, mg, mgx, shift;
   {
     const float4 a0 = coef[q], a1 = coef[c4 + q], a2 = coef[2 * c4 + q], a3 = coef[3 * c4 + q], a4 = coef[4 * c4 + q];
+    const float4 a5 = coef[5 * c4 + q];
+    shift = f32x4{a5.x, a5.y, a5.z, a5.w};
     mean = f32x4{a0.x, a0.y, a0.z, a0.w};
     rstd = f32x4{a1.x, a1.y, a1.z, a1.w};
     scale = f32x4{a2.x, a2.y, a2.z, a2.w};
@@ -224,12 +247,19 @@ __global__ void bn_bwd_apply_kernel(const f32x4* __restrict__ dz, const f32x4* _
   }
   for (int64_t i = g; i < n4; i += T) {
     f32x4 gz = dz[i];
+    const f32x4 yy = y[i];
     if (act != UDASEG_ACT_NONE) {
-      const f32x4 zz = z[i];
+      f32x4 zz;
+      if (z) {
+        zz = z[i];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) zz[e] = __builtin_fmaf(yy[e], scale[e], shift[e]);
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) gz[e] *= act_grad(zz[e], act, slope);
     }
-    const f32x4 xh = (y[i] - mean) * rstd;
+    const f32x4 xh = (yy - mean) * rstd;
     f32x4 out = scale * (gz - mg - xh * mgx);
     if (acc_dy) out += dy[i];
     dy[i] = out;
@@ -349,33 +379,35 @@ extern "C" int udaseg_bn_apply_eval(const float* y, const float* gamma, const fl
 }
 
 extern "C" int udaseg_bn_bwd_reduce(const float* dz, const float* z, const float* y, const float* save_mean,
-                                    const float* save_rstd, int64_t pixels, int c, double* bsums, int act, float slope,
-                                    void* stream) {
+                                    const float* save_rstd, const float* gamma, const float* beta, int64_t pixels, int c,
+                                    double* bsums, int act, float slope, void* stream) {
   int rc = check_pc(pixels, c, "bn_bwd_reduce");
   if (rc) return rc;
   UDASEG_CHECK_ARG(dz && y && save_mean && save_rstd && bsums, "bn_bwd_reduce: NULL pointer");
-  UDASEG_CHECK_ARG(act == UDASEG_ACT_NONE || z, "bn_bwd_reduce: z required when an activation follows the norm");
+  UDASEG_CHECK_ARG(act == UDASEG_ACT_NONE || z || (gamma && beta),
+                   "bn_bwd_reduce: an activation follows the norm: pass z, or gamma and beta to re-evaluate its argument");
   const int64_t n4 = pixels * (c / 4);
   const StreamShape s = stream_shape(n4, c / 4, REDUCE_MAX_BLOCKS);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(s.grid), dim3(s.bs), 0, as_stream(stream), (const f32x4*)dz, (const f32x4*)z,
-                     (const f32x4*)y, save_mean, save_rstd, n4, s.c4, bsums, act, slope);
+                     (const f32x4*)y, save_mean, save_rstd, gamma, beta, n4, s.c4, bsums, act, slope);
   UDASEG_LAUNCH_CHECK("bn_bwd_reduce launch");
   return UDASEG_OK;
 }
 
 extern "C" int udaseg_bn_bwd_apply(const float* dz, const float* z, const float* y, const float* save_mean,
-                                   const float* save_rstd, const float* gamma, const double* bsums, float* dy,
-                                   float* dres, float* dgamma, float* dbeta, int64_t pixels, int c, int act,
+                                   const float* save_rstd, const float* gamma, const float* beta, const double* bsums,
+                                   float* dy, float* dres, float* dgamma, float* dbeta, int64_t pixels, int c, int act,
                                    float slope, int accumulate_dy, int accumulate_dres, int accumulate_param,
                                    void* stream) {
   int rc = check_pc(pixels, c, "bn_bwd_apply");
   if (rc) return rc;
   UDASEG_CHECK_ARG(dz && y && save_mean && save_rstd && gamma && bsums && dy, "bn_bwd_apply: NULL pointer");
-  UDASEG_CHECK_ARG(act == UDASEG_ACT_NONE || z, "bn_bwd_apply: z required when an activation follows the norm");
+  UDASEG_CHECK_ARG(act == UDASEG_ACT_NONE || z || beta,
+                   "bn_bwd_apply: an activation follows the norm: pass z, or beta to re-evaluate its argument");
   const int64_t n4 = pixels * (c / 4);
   const StreamShape s = stream_shape(n4, c / 4);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(s.grid), dim3(s.bs), (size_t)5 * s.c4 * sizeof(float4), as_stream(stream), (const f32x4*)dz, (const f32x4*)z,
-                     (const f32x4*)y, save_mean, save_rstd, gamma, bsums, (f32x4*)dy, (f32x4*)dres, dgamma, dbeta, n4, s.c4,
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(s.grid), dim3(s.bs), (size_t)6 * s.c4 * sizeof(float4), as_stream(stream), (const f32x4*)dz, (const f32x4*)z,
+                     (const f32x4*)y, save_mean, save_rstd, gamma, beta, bsums, (f32x4*)dy, (f32x4*)dres, dgamma, dbeta, n4, s.c4,
                      pixels, act, slope, accumulate_dy, accumulate_dres, accumulate_param);
   UDASEG_LAUNCH_CHECK("bn_bwd_apply launch");
   return UDASEG_OK;

@@ -366,7 +366,8 @@ class Plan:
             z = torch.empty((n, d.ho, d.wo, conv.cout_p), device=x.device, dtype=self.adt)
             K.conv2d_fwd_fused(d, x, wf, bf, residual, z, act, slope, self.st)
             return z, None
-        rec = (conv, bn, d, x, y, z, ms, act, slope) if self.save else None
+        # has_res tells the backward whether the activation's argument can be re-evaluated from y alone
+        rec = (conv, bn, d, x, y, z, ms, act, slope, residual is not None) if self.save else None
         return z, rec
 
     # -- backward pieces
@@ -411,22 +412,26 @@ class Plan:
         if dx is not None:
             K.conv2d_dgrad(d, dy, self.packed_wt(conv), dx, dx_acc, self.st)
 
-    def bn_bwd(self, bn, y, z, ms, dz, act, slope, dres=None, dres_acc=False):
-        """In place: dz becomes dy (grad w.r.t. the conv output).  dres (+)= masked grad for the residual branch."""
+    def bn_bwd(self, bn, y, z, ms, dz, act, slope, dres=None, dres_acc=False, has_res=True):
+        """In place: dz becomes dy (grad w.r.t. the conv output).  dres (+)= masked grad for the residual branch.
+        fp32 layers without a residual input do not read z: the kernels re-evaluate the activation's argument from y."""
         c = ceil4(bn.c)
         o = self._bstat_off
         self._bstat_off += 2 * c
         bs = self.bstats[o * self.R:(o + 2 * c) * self.R]
         mean, rstd = ms
         gamma = self.pvec(bn, "weight")
-        K.bn_bwd_reduce(dz, z, y, mean, rstd, bs, act, slope, self.st)
+        beta = None
+        if not has_res and not self.bf16 and act != ACT_NONE:
+            z, beta = None, self.pvec(bn, "bias")
+        K.bn_bwd_reduce(dz, z, y, mean, rstd, bs, act, slope, self.st, gamma=gamma, beta=beta)
         K.bn_bwd_apply(dz, z, y, mean, rstd, gamma, bs, dz, dres, self.gvec(bn, "weight"), self.gvec(bn, "bias"), act, slope,
-                       False, dres_acc, False, self.st)
+                       False, dres_acc, False, self.st, beta=beta)
         return dz
 
     def conv_bn_act_bwd(self, rec, dz, dx=None, dx_acc=False, dres=None, dres_acc=False):
-        conv, bn, d, x, y, z, ms, act, slope = rec
-        dy = self.bn_bwd(bn, y, z, ms, dz, act, slope, dres, dres_acc)
+        conv, bn, d, x, y, z, ms, act, slope, has_res = rec
+        dy = self.bn_bwd(bn, y, z, ms, dz, act, slope, dres, dres_acc, has_res)
         self.conv_bwd(conv, d, x, dy, dx, dx_acc)
 
 

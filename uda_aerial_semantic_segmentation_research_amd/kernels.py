@@ -188,7 +188,8 @@ def bn_apply_eval(y, gamma, beta, running_mean, running_var, residual, z, eps, a
                                             slope, st if st is not None else stream()), "bn_apply_eval")
 
 
-def bn_bwd_reduce(dz, z, y, save_mean, save_rstd, bsums, act, slope, st=None):
+def bn_bwd_reduce(dz, z, y, save_mean, save_rstd, bsums, act, slope, st=None, gamma=None, beta=None):
+    """z=None (fp32 only, layers without a residual input): the activation's argument is re-evaluated from y, gamma, beta."""
     c = y.shape[-1]
     if y.dtype == torch.bfloat16:
         check(_lib.load().udaseg_bn_bwd_reduce_bf16(dz.data_ptr(), _ptr(z), y.data_ptr(), save_mean.data_ptr(),
@@ -196,12 +197,12 @@ def bn_bwd_reduce(dz, z, y, save_mean, save_rstd, bsums, act, slope, st=None):
                                                      st if st is not None else stream()), "bn_bwd_reduce_bf16")
         return
     check(_lib.load().udaseg_bn_bwd_reduce(dz.data_ptr(), _ptr(z), y.data_ptr(), save_mean.data_ptr(), save_rstd.data_ptr(),
-                                            y.numel() // c, c, bsums.data_ptr(), act, slope,
+                                            _ptr(gamma), _ptr(beta), y.numel() // c, c, bsums.data_ptr(), act, slope,
                                             st if st is not None else stream()), "bn_bwd_reduce")
 
 
 def bn_bwd_apply(dz, z, y, save_mean, save_rstd, gamma, bsums, dy, dres, dgamma, dbeta, act, slope, accumulate_dy=False,
-                 accumulate_dres=False, accumulate_param=False, st=None):
+                 accumulate_dres=False, accumulate_param=False, st=None, beta=None):
     c = y.shape[-1]
     if y.dtype == torch.bfloat16:
         check(_lib.load().udaseg_bn_bwd_apply_bf16(dz.data_ptr(), _ptr(z), y.data_ptr(), save_mean.data_ptr(),
@@ -211,7 +212,7 @@ def bn_bwd_apply(dz, z, y, save_mean, save_rstd, gamma, bsums, dy, dres, dgamma,
                                                     st if st is not None else stream()), "bn_bwd_apply_bf16")
         return
     check(_lib.load().udaseg_bn_bwd_apply(dz.data_ptr(), _ptr(z), y.data_ptr(), save_mean.data_ptr(), save_rstd.data_ptr(),
-                                           gamma.data_ptr(), bsums.data_ptr(), dy.data_ptr(), _ptr(dres), _ptr(dgamma),
+                                           gamma.data_ptr(), _ptr(beta), bsums.data_ptr(), dy.data_ptr(), _ptr(dres), _ptr(dgamma),
                                            _ptr(dbeta), y.numel() // c, c, act, slope, int(accumulate_dy),
                                            int(accumulate_dres), int(accumulate_param),
                                            st if st is not None else stream()), "bn_bwd_apply")
