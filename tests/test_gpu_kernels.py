@@ -75,6 +75,8 @@ CONV_CASES = [
     (1, 33, 47, 32, 16, 3, 1, 1),     # direct kernel, two K groups, odd extents
     (2, 16, 16, 8, 32, 3, 1, 1),      # direct kernel, partial K group (ci = 8), two output tiles
     (1, 64, 64, 16, 24, 3, 1, 1),     # head shape through the direct kernel
+    (4, 96, 96, 64, 64, 3, 1, 1),     # enough tiles for the unsliced launches: uniform-tap loop + buffer-store epilogues
+    (2, 96, 96, 128, 32, 3, 1, 1),    # same through the 128x32 tile
 ]
 
 

@@ -337,6 +337,55 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
   float ssum[TN], ssq[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) ssum[j] = ssq[j] = 0.f;
+  // Fast path (fp32, dense output, tile entirely inside the output, plain store): one 32-bit offset per 32x32 block, the
+  // 16 row displacements go into the store's scalar offset -- no per-element address arithmetic or bounds tests.  The
+  // epilogue's VALU work matters: a K = 576 layer spends as many VALU cycles here as in a fifth of its MFMAs.
+  bool fast_epi = false;
+  if constexpr (!BF) {
+    fast_epi = a.dense_out && !a.atomic_out && !a.accumulate && a.residual == nullptr && m0 + BM <= cM && n0 + BN <= a.co &&
+               (long long)cM * a.co * 4 < (1LL << 31);
+  }
+  if (fast_epi) {
+    __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, cM * a.co * 4, 0x00020000);
+    const int row_bytes = a.co * 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn + j * 32 + lr;
+        const int voff = ((m0 + wm + i * 32 + 4 * lh) * a.co + n) * 4;
+        // three uniform variants so that the common launches carry no dead per-element work:
+        // dgrad / plain conv (store only), conv feeding BatchNorm (statistics), and the general one (bias, activation)
+        if (a.bias == nullptr && a.act == UDASEG_ACT_NONE && a.stats == nullptr) {
+#pragma unroll
+          for (int v = 0; v < 16; ++v) {
+            const float val = acc[i][j][v];   // (bit_cast straight from the vector element stored element 0 sixteen times)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rsrc_y, voff,
+                                                  ((v & 3) + 8 * (v >> 2)) * row_bytes, 0);
+          }
+        } else if (a.bias == nullptr && a.act == UDASEG_ACT_NONE) {
+#pragma unroll
+          for (int v = 0; v < 16; ++v) {
+            const float val = acc[i][j][v];
+            ssum[j] += val;
+            ssq[j] = __builtin_fmaf(val, val, ssq[j]);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rsrc_y, voff,
+                                                  ((v & 3) + 8 * (v >> 2)) * row_bytes, 0);
+          }
+        } else {
+          const float bv = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+          for (int v = 0; v < 16; ++v) {
+            float val = acc[i][j][v] + bv;
+            ssum[j] += val;
+            ssq[j] += val * val;
+            val = act_apply(val, a.act, a.slope);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rsrc_y, voff,
+                                                  ((v & 3) + 8 * (v >> 2)) * row_bytes, 0);
+          }
+        }
+      }
+  } else
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
