@@ -263,8 +263,9 @@ def main():
         value = imgs / dt
         conv_tflops = value * R18_CONV_GFLOP_PER_IMAGE / 1e3 / world if args.encoder == "resnet18" and args.size == 512 else None
         out = {
-            "metric": "training images/sec at 512x512" if args.workload == "segmentation" and args.dtype == "fp32"
-            else f"{args.workload} images/sec at 512x512 (informational, {args.dtype})", "value": round(value, 2), "unit": "images/s", "n_gpus": world,
+            "metric": "training images/sec at 512x512" if (args.workload == "segmentation" and args.dtype == "fp32"
+                                                           and args.size == 512 and args.encoder == "resnet18")
+            else f"{args.workload} images/sec at {args.size}x{args.size} (informational, {args.encoder}, {args.dtype})", "value": round(value, 2), "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.encoder}-Unet " + WORKLOAD_TEXT[args.workload] + ", "

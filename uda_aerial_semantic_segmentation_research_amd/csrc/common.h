@@ -106,7 +106,7 @@ int launch_small_wgrad(const float* x, const float* dy, float* dw, int n, int h,
                        hipStream_t s);
 
 // live launch timing (bench.py roofline leg): per API call (prof_*) and per kernel launch (kprof_*)
-constexpr int PROF_NKERNELS = 16;
+constexpr int PROF_NKERNELS = 24;
 hipEvent_t kprof_begin(hipStream_t s);
 void kprof_end(int kid, hipEvent_t a, hipStream_t s, double flops);
 void prof_begin(int family, hipStream_t s);

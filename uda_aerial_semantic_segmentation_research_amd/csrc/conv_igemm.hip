@@ -495,7 +495,8 @@ static int launch_cfg_t(const IgemmArgs& a, hipStream_t s) {
   for (int c = a.nclass; c < NCLS; ++c) b.tile_begin[c + 1] = b.tile_begin[a.nclass];
   if (b.tile_begin[a.nclass] == 0) return UDASEG_OK;
   dim3 grid((unsigned)b.tile_begin[a.nclass]), block(256);
-  constexpr int kid = BF ? 12 : (BM == 128 && BN == 128) ? 0 : (BM == 128 && BN == 64) ? 1 : (BM == 64) ? 2 : 3;
+  constexpr int tile_id = (BM == 128 && BN == 128) ? 0 : (BM == 128 && BN == 64) ? 1 : (BM == 64) ? 2 : 3;
+  constexpr int kid = BF ? 12 : (UNI ? 14 + tile_id : tile_id);
   hipEvent_t ev = kprof_begin(s);
   hipLaunchKernelGGL(kern, grid, block, lds, s, b);
   kprof_end(kid, ev, s, flops);

@@ -412,7 +412,7 @@ static int launch_wgrad(WgradArgs a, int accumulate, hipStream_t s, bool bf16 = 
       hipLaunchKernelGGL((conv_wgrad_kernel<BMW, BNW, WAVES_M, WAVES_N, true>), grid, block, 0, s, a);
     else
       hipLaunchKernelGGL((conv_wgrad_kernel<BMW, BNW, WAVES_M, WAVES_N, false>), grid, block, 0, s, a);
-    kprof_end(BMW == 64 ? 7 : 8, ev, s, 2.0 * (double)a.M * a.co * a.J);
+    kprof_end((a.row_uniform ? 18 : 7) + (BMW == 64 ? 0 : 1), ev, s, 2.0 * (double)a.M * a.co * a.J);
   }
   UDASEG_LAUNCH_CHECK("conv_wgrad launch");
   return UDASEG_OK;
