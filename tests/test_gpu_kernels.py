@@ -77,6 +77,8 @@ CONV_CASES = [
     (1, 64, 64, 16, 24, 3, 1, 1),     # head shape through the direct kernel
     (4, 96, 96, 64, 64, 3, 1, 1),     # enough tiles for the unsliced launches: uniform-tap loop + buffer-store epilogues
     (2, 96, 96, 128, 32, 3, 1, 1),    # same through the 128x32 tile
+    (2, 32, 32, 64, 128, 3, 1, 1),    # halo-resident wgrad: two co tiles, image-border rows / columns in every K-tile
+    (3, 32, 64, 192, 64, 3, 1, 1),    # halo-resident wgrad: three ci tiles, non-square, K-tiles crossing image boundaries
 ]
 
 
