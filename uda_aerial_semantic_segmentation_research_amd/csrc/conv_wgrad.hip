@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
-constexpr int WBKB = 32;  // pixels per K-tile (two 16-deep MFMA steps)
+constexpr int WBKB = 64;  // pixels per K-tile (four 16-deep MFMA steps per barrier; 32 left the kernel barrier-bound)
 
 __device__ __forceinline__ bf16x8w tr_fragment(const unsigned short* row0, int ld) {
   // row0: this lane's address in the first 4-row block; the second block is 4 rows further down
@@ -238,7 +238,7 @@ __device__ __forceinline__ bf16x8w tr_fragment(const unsigned short* row0, int l
   return __builtin_bit_cast(bf16x8w, f);
 }
 
-template <int BMW, int BNW, int WAVES_M, int WAVES_N>
+template <int BMW, int BNW, int WAVES_M, int WAVES_N, bool ROWU>
 __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradArgs a) {
   constexpr int WM = BMW / WAVES_M, WN = BNW / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -291,7 +291,57 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradArgs a)
   f32x4 ra[A_PASS], rb[B_PASS];
   const int nkt = (kend - kbeg + WBKB - 1) / WBKB;
 
+  // row-uniform gather (see conv_wgrad_kernel): a pass covers B_ROWS consecutive pixels of one image row
+  static_assert(!ROWU || (WBKB % A_ROWS == 0 && WBKB % B_ROWS == 0), "row-uniform passes must tile the K-tile");
+  unsigned u_ac[A_PASS], u_bc = 0;
+  int u_bdy = 0, u_bx = 0;
+  int s_ni[B_PASS], s_oy[B_PASS], s_ox[B_PASS];
+  unsigned s_dyoff = 0;
+  __amdgpu_buffer_rsrc_t rsrc_x, rsrc_dy;
+  if constexpr (ROWU) {
+    rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+    rsrc_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dy), 0, (int)a.dy_bytes, 0x00020000);
+#pragma unroll
+    for (int p = 0; p < A_PASS; ++p)
+      u_ac[p] = a_ok ? (unsigned)((arow + A_ROWS * p) * a.co + a_co) * 2u : 0x80000000u;
+    u_bc = b_ok ? (unsigned)((b_dy * a.wi + brow * a.stride + b_dx) * a.ci + b_c) * 2u : 0x80000000u;
+    u_bdy = b_dy;
+    u_bx = brow * a.stride + b_dx;
+    s_dyoff = (unsigned)kbeg * (unsigned)a.co * 2u;
+#pragma unroll
+    for (int p = 0; p < B_PASS; ++p) {
+      const int m = kbeg + B_ROWS * p;
+      const int t1 = m / a.wo;
+      s_ox[p] = m - t1 * a.wo;
+      s_ni[p] = t1 / a.ho;
+      s_oy[p] = t1 - s_ni[p] * a.ho;
+    }
+  }
+
   auto load_tile = [&](int kt) {
+    if constexpr (ROWU) {
+#pragma unroll
+      for (int p = 0; p < A_PASS; ++p)
+        ra[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_dy, (int)(u_ac[p] + s_dyoff), 0, 0));
+      s_dyoff += (unsigned)(WBKB * 2) * (unsigned)a.co;
+#pragma unroll
+      for (int p = 0; p < B_PASS; ++p) {
+        const int oys = s_oy[p] * a.stride, oxs = s_ox[p] * a.stride;
+        const unsigned s_off = (unsigned)(((s_ni[p] * a.hi + oys) * a.wi + oxs) * a.ci) * 2u;
+        const bool ok = (unsigned)(oys + u_bdy) < (unsigned)a.hi && (unsigned)(oxs + u_bx) < (unsigned)a.wi;
+        const unsigned voff = ok ? u_bc + s_off : 0x80000000u;
+        rb[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)voff, 0, 0));
+        s_ox[p] += WBKB;
+        while (s_ox[p] >= a.wo) {
+          s_ox[p] -= a.wo;
+          if (++s_oy[p] == a.ho) {
+            s_oy[p] = 0;
+            ++s_ni[p];
+          }
+        }
+      }
+      return;
+    }
     const int mb = kbeg + kt * WBKB;
 #pragma unroll
     for (int p = 0; p < A_PASS; ++p) {
@@ -384,7 +434,8 @@ static int launch_wgrad(WgradArgs a, int accumulate, hipStream_t s, bool bf16 = 
   const int max_splits = cdiv(a.M, 256);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
-  int kchunk = cdiv(cdiv(a.M, splits), WBK) * WBK;
+  const int ktile = bf16 ? WBKB : WBK;
+  int kchunk = cdiv(cdiv(a.M, splits), ktile) * ktile;
   splits = cdiv(a.M, kchunk);
   a.kchunk = kchunk;
   a.use_atomic = (splits > 1 || accumulate) ? 1 : 0;
@@ -395,7 +446,15 @@ static int launch_wgrad(WgradArgs a, int accumulate, hipStream_t s, bool bf16 = 
   dim3 grid((unsigned)tiles, (unsigned)splits), block(256);
   hipEvent_t ev = kprof_begin(s);
   if (bf16) {
-    hipLaunchKernelGGL((conv_wgrad_bf16_kernel<BMW, BNW, WAVES_M, WAVES_N>), grid, block, 0, s, a);
+    constexpr int b_rows16 = 256 / (BNW / 8);
+    const long long xb16 = (long long)a.M / (a.ho * a.wo) * a.hi * a.wi * a.ci * 2, dyb16 = (long long)a.M * a.co * 2;
+    a.row_uniform = !getenv("UDASEG_WGRAD_GENERIC") && a.wo % b_rows16 == 0 && xb16 <= (1LL << 30) && dyb16 <= (1LL << 30);
+    a.x_bytes = (unsigned)xb16;
+    a.dy_bytes = (unsigned)dyb16;
+    if (a.row_uniform)
+      hipLaunchKernelGGL((conv_wgrad_bf16_kernel<BMW, BNW, WAVES_M, WAVES_N, true>), grid, block, 0, s, a);
+    else
+      hipLaunchKernelGGL((conv_wgrad_bf16_kernel<BMW, BNW, WAVES_M, WAVES_N, false>), grid, block, 0, s, a);
     kprof_end(13, ev, s, 2.0 * (double)a.M * a.co * a.J);
   } else {
     constexpr int b_rows = 256 / (BNW / 4);
