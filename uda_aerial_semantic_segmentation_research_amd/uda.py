@@ -133,12 +133,13 @@ class GradientReverseFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_output):
-        if grad_output.is_cuda and grad_output.dtype == torch.float32:
-            g = grad_output if grad_output.is_contiguous() or _dense_permuted(grad_output) else grad_output.contiguous()
-            out = torch.empty_like(g)                           # preserves g's (dense) strides
-            K.scale(g, -float(ctx.alpha), out)
-            return out, None
-        return grad_output.neg() * ctx.alpha, None
+        if not grad_output.is_cuda:
+            raise RuntimeError("gradient_reverse_layer: gradients must live on the GPU (no CPU path in this build)")
+        g = grad_output.float()
+        g = g if g.is_contiguous() or _dense_permuted(g) else g.contiguous()
+        out = torch.empty_like(g)                               # preserves g's (dense) strides
+        K.scale(g, -float(ctx.alpha), out)
+        return out.to(grad_output.dtype), None
 
 
 def _dense_permuted(t):
