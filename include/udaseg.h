@@ -36,6 +36,12 @@ extern "C" {
 #define UDASEG_ACT_LEAKY 1 /* y = x > 0 ? x : slope * x ; slope 0 => ReLU */
 
 int udaseg_version(void);
+/* runtime switches for cross-checks and tuning.  UDASEG_OPT_GENERIC_GATHER: 1 keeps the convolution kernels on their generic
+ * gather loops, 0 allows the uniform-tap / row-uniform loops, -1 restores the environment default
+ * (UDASEG_IGEMM_GENERIC / UDASEG_WGRAD_GENERIC).  Both loops accumulate in the same order: forward and dgrad results are
+ * bit-identical between them. */
+#define UDASEG_OPT_GENERIC_GATHER 0
+int udaseg_set_option(int key, int value);
 const char* udaseg_last_error(void);
 /* number of HIP devices visible to the library (0 on a CPU-only box; never initialises a context) */
 int udaseg_device_count(void);

@@ -466,3 +466,43 @@ def test_bn_fold_and_fused_inference_conv(K):
     K.conv2d_fwd_fused(d2, nhwc(x2), w_ohwi(conv2.weight.detach()), None, nhwc(r2), y2, act=1, slope=0.1)
     with torch.no_grad():
         assert_close(nchw(y2), F.leaky_relu(conv2(x2) + r2, 0.1), "small conv + residual + leaky", 1e-4)
+
+
+@pytest.mark.parametrize("case", [(8, 128, 128, 64, 64, 3, 1, 1), (8, 64, 64, 128, 128, 3, 1, 1), (8, 256, 256, 128, 32, 3, 1, 1),
+                                  (8, 128, 128, 64, 128, 3, 2, 1), (8, 256, 256, 64, 128, 4, 2, 1), (8, 16, 16, 512, 512, 3, 1, 1)])
+def test_uniform_loops_equal_generic_loops_at_full_size(K, case):
+    """BASELINE-size layers (8 x 512 x 512 network): the uniform-tap igemm loop and the row-uniform wgrad gather against
+    the generic loops of the same kernels.  Forward and dgrad accumulate in the same order -> bit-identical; wgrad adds its
+    split partial sums atomically (order varies) -> 1e-5."""
+    n, h, w, ci, co, k, s, p = case
+    g = torch.Generator(device="cuda").manual_seed(ci + co)
+    d = K.conv_desc(n, h, w, ci, co, k, s, p)
+    x = torch.randn(n, h, w, ci, device="cuda", generator=g)
+    wt = torch.randn(co, k, k, ci, device="cuda", generator=g) / math.sqrt(ci * k * k)
+    dy = torch.randn(n, d.ho, d.wo, co, device="cuda", generator=g)
+    wtp = torch.empty(ci * k * k * co, device="cuda")
+    K.pack_dgrad_weights(d, wt, wtp)
+    R = K.bn_replicas()
+    outs = {}
+    try:
+        for mode in (1, 0):
+            K.set_generic_gather(mode)
+            y = torch.empty(n, d.ho, d.wo, co, device="cuda")
+            stats = torch.zeros(R * 2 * co, dtype=torch.float64, device="cuda")
+            K.conv2d_fwd_bnstats(d, x, wt, None, y, stats)
+            dx = torch.empty_like(x)
+            K.conv2d_dgrad(d, dy, wtp, dx)
+            dw = torch.empty_like(wt)
+            K.conv2d_wgrad(d, x, dy, dw, False)
+            outs[mode] = (y, stats.view(R, -1).sum(0), dx, dw)
+    finally:
+        K.set_generic_gather(-1)
+    (y1, s1, dx1, dw1), (y0, s0, dx0, dw0) = outs[1], outs[0]
+    assert torch.equal(y0, y1), "fwd: uniform-tap loop differs from the generic loop"
+    assert torch.equal(dx0, dx1), "dgrad: uniform-tap loop differs from the generic loop"
+    assert torch.allclose(s0, s1, rtol=1e-12, atol=1e-9)
+    assert (dw0 - dw1).abs().max().item() <= 1e-5 * dw1.abs().max().item()
+    # linearity of the forward in its input (a size-independent property)
+    y2 = torch.empty_like(y0)
+    K.conv2d_fwd(d, 2.0 * x, wt, None, y2)
+    assert torch.equal(y2, 2.0 * y0)

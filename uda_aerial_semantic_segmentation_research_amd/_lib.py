@@ -64,6 +64,7 @@ SIGNATURES = {
     "udaseg_bce_logits_target_fwd": (_I, [_P, _P, _I, _F, _P, _I, _P]),
     "udaseg_bce_logits_target_bwd": (_I, [_P, _P, _I, _F, _P, _P, _I, _P]),
     "udaseg_scale_f32": (_I, [_P, _P, _L, _F, _P]),
+    "udaseg_set_option": (_I, [_I, _I]),
     "udaseg_prepare_batch_u8": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _I, _P, _I, _P]),
     "udaseg_dice_bwd": (_I, [_P, _P, _P, _P, _F, _I, _L, _I, _I, _P, _I, _P]),
     "udaseg_focal_fwd": (_I, [_P, _P, _P, _F, _F, _L, _I, _I, _I, _P, _P, _I, _P]),

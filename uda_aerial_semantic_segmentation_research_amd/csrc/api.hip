@@ -168,6 +168,15 @@ extern "C" int udaseg_prof_records(int family, int max_records, double* ms, doub
   return n;
 }
 
+namespace udaseg { int g_opt_generic_gather = -1; }
+
+extern "C" int udaseg_set_option(int key, int value) {
+  UDASEG_CHECK_ARG(key == UDASEG_OPT_GENERIC_GATHER, "set_option: unknown key %d", key);
+  UDASEG_CHECK_ARG(value >= -1 && value <= 1, "set_option: value must be -1 (environment default), 0 or 1");
+  udaseg::g_opt_generic_gather = value;
+  return UDASEG_OK;
+}
+
 extern "C" int udaseg_prof_kernel_count(void) { return PROF_NKERNELS; }
 extern "C" const char* udaseg_prof_kernel_name(int kid) { return (kid >= 0 && kid < PROF_NKERNELS) ? g_knames[kid] : ""; }
 

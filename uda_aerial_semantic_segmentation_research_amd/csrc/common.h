@@ -10,6 +10,8 @@
 namespace udaseg {
 
 void set_error(const char* fmt, ...);
+// runtime switches (udaseg_set_option): -1 = take the environment default
+extern int g_opt_generic_gather;   // 1: igemm / wgrad keep the generic gather loops (cross-check of the uniform paths)
 int hip_fail(hipError_t e, const char* what);
 
 #define UDASEG_CHECK_ARG(cond, ...)                 \

@@ -515,6 +515,7 @@ static int launch_cfg(const IgemmArgs& a, hipStream_t s) {
 }
 
 static int uniform_off() {
+  if (g_opt_generic_gather >= 0) return g_opt_generic_gather;
   static int v = -1;   // tuning aid: UDASEG_IGEMM_GENERIC=1 keeps every layer on the generic gather loop
   if (v < 0) {
     const char* e = getenv("UDASEG_IGEMM_GENERIC");

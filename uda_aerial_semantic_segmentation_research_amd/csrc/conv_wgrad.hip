@@ -448,7 +448,7 @@ static int launch_wgrad(WgradArgs a, int accumulate, hipStream_t s, bool bf16 = 
   if (bf16) {
     constexpr int b_rows16 = 256 / (BNW / 8);
     const long long xb16 = (long long)a.M / (a.ho * a.wo) * a.hi * a.wi * a.ci * 2, dyb16 = (long long)a.M * a.co * 2;
-    a.row_uniform = !getenv("UDASEG_WGRAD_GENERIC") && a.wo % b_rows16 == 0 && xb16 <= (1LL << 30) && dyb16 <= (1LL << 30);
+    a.row_uniform = !(g_opt_generic_gather >= 0 ? g_opt_generic_gather : getenv("UDASEG_WGRAD_GENERIC") != nullptr) && a.wo % b_rows16 == 0 && xb16 <= (1LL << 30) && dyb16 <= (1LL << 30);
     a.x_bytes = (unsigned)xb16;
     a.dy_bytes = (unsigned)dyb16;
     if (a.row_uniform)
@@ -464,7 +464,7 @@ static int launch_wgrad(WgradArgs a, int accumulate, hipStream_t s, bool bf16 = 
       generic = e ? atoi(e) : 0;
     }
     const long long xb = (long long)a.M / (a.ho * a.wo) * a.hi * a.wi * a.ci * 4, dyb = (long long)a.M * a.co * 4;
-    a.row_uniform = !generic && a.wo % b_rows == 0 && xb <= (1LL << 30) && dyb <= (1LL << 30);
+    a.row_uniform = !(g_opt_generic_gather >= 0 ? g_opt_generic_gather : generic) && a.wo % b_rows == 0 && xb <= (1LL << 30) && dyb <= (1LL << 30);
     a.x_bytes = (unsigned)xb;
     a.dy_bytes = (unsigned)dyb;
     if (a.row_uniform)

@@ -434,6 +434,11 @@ def axpy(y, x, alpha=1.0, st=None):
           "axpy_f32")
 
 
+def set_generic_gather(value):
+    """1: convolution kernels keep their generic gather loops; 0: uniform-tap / row-uniform loops allowed; -1: environment."""
+    check(_lib.load().udaseg_set_option(0, int(value)), "set_option")
+
+
 def prof_enable(on):
     check(_lib.load().udaseg_prof_enable(int(on)))
 
