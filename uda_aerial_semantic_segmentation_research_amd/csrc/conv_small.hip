@@ -65,6 +65,28 @@ struct HaloRegs {
       if (idx < TOTAL) *reinterpret_cast<f32x4*>(halo + idx * 4) = v[it];   // pos*CIP + cq*4 == idx*4
     }
   }
+
+  // Interior tiles (halo entirely inside the image): a piece's byte offset is (tile base) + (a per-thread constant that
+  // never changes): one add per piece, range-checked buffer loads.  off[it] holds the constants, 2^30 for the pieces
+  // a thread does not own (idx >= TOTAL or padded channel groups) -- those read zeros.  The per-element divisions, bounds
+  // tests and 64-bit addresses of issue() are VALU work that competes with the fp32 MFMAs for the same ALUs.
+  __device__ __forceinline__ void offsets(unsigned (&off)[ITER], int w, int ci) const {
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int idx = threadIdx.x + 256 * it;
+      const int pos = idx / Q, cq = idx - pos * Q;
+      const int hy = pos / SH, hx = pos - hy * SH;
+      off[it] = (idx < TOTAL && cq * 4 < ci) ? (unsigned)(((hy - 1) * w + (hx - 1)) * ci + cq * 4) * 4u : 0x40000000u;
+    }
+  }
+  __device__ __forceinline__ void issue_interior(__amdgpu_buffer_rsrc_t rsrc, const unsigned (&off)[ITER], unsigned tile_base) {
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      // real constants are small (|off| < 2^24, the top-left halo row / column being negative); the marker 2^30 plus any
+      // tile base is past the end of a tensor of at most 2^30 bytes
+      v[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(off[it] + tile_base), 0, 0));
+    }
+  }
 };
 
 // 16x16 tile of dy (no halo)
@@ -107,7 +129,7 @@ __device__ __forceinline__ TileCoord tile_coord(int tile, int tiles_x, int tiles
 
 // G = 16-channel K groups of the gathered operand, CO_T = 16-wide output-channel tiles.
 template <int G, int CO_T>
-__global__ __launch_bounds__(256) void conv3x3_small_kernel(const SmallArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G * CO_T == 1 ? 3 : 2))) void conv3x3_small_kernel(const SmallArgs a) {
   constexpr int CIP = 16 * G;
   __shared__ __attribute__((aligned(16))) float halo[SH * SH * CIP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -135,21 +157,30 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(const SmallArgs a) {
   for (int ct = 0; ct < CO_T; ++ct) ssum[ct] = ssq[ct] = 0.f;
 
   HaloRegs<CIP> stage;
+  const bool small_tensors = (long long)a.n * a.h * a.wd * (a.ci > a.co ? a.ci : a.co) * 4 <= (1LL << 30);
+  __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0,
+                                                                    small_tensors ? a.n * a.h * a.wd * a.ci * 4 : 0, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, small_tensors ? a.n * a.h * a.wd * a.co * 4 : 0,
+                                                                    0x00020000);
+  unsigned hoff[HaloRegs<CIP>::ITER];
+  stage.offsets(hoff, a.wd, a.ci);
+  auto issue_tile = [&](int t) {
+    const TileCoord c = tile_coord(t, a.tiles_x, a.tiles_y);
+    // interior: the 18x18 halo lies inside the image (uniform per tile)
+    if (small_tensors && c.ty0 >= 1 && c.tx0 >= 1 && c.ty0 + ST + 1 <= a.h && c.tx0 + ST + 1 <= a.wd)
+      stage.issue_interior(rsrc_x, hoff, (unsigned)(((c.ni * a.h + c.ty0) * a.wd + c.tx0) * a.ci) * 4u);
+    else
+      stage.issue(a.x, c.ni, c.ty0, c.tx0, a.h, a.wd, a.ci);
+  };
   int tile = blockIdx.x;
-  if (tile < a.ntiles) {
-    const TileCoord c = tile_coord(tile, a.tiles_x, a.tiles_y);
-    stage.issue(a.x, c.ni, c.ty0, c.tx0, a.h, a.wd, a.ci);
-  }
+  if (tile < a.ntiles) issue_tile(tile);
   for (; tile < a.ntiles; tile += gridDim.x) {
     const TileCoord tc = tile_coord(tile, a.tiles_x, a.tiles_y);
     const int ni = tc.ni, ty0 = tc.ty0, tx0 = tc.tx0;
     __syncthreads();  // previous tile's readers are done with the halo
     stage.commit(halo);
     __syncthreads();
-    if (tile + (int)gridDim.x < a.ntiles) {  // next tile's halo flies during this tile's MFMA phase
-      const TileCoord c = tile_coord(tile + gridDim.x, a.tiles_x, a.tiles_y);
-      stage.issue(a.x, c.ni, c.ty0, c.tx0, a.h, a.wd, a.ci);
-    }
+    if (tile + (int)gridDim.x < a.ntiles) issue_tile(tile + gridDim.x);  // next tile's halo flies during this tile's MFMAs
 
     f32x4 acc[4][CO_T];
 #pragma unroll
@@ -180,6 +211,28 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(const SmallArgs a) {
     }
 
     // D reg v of lane (li, kq): pixel x = 4*kq + v of the row, channel 16*ct + li
+    // Fast path (tile inside the image, all 16*CO_T channels real, plain store): one 32-bit offset per lane and tile, the
+    // 16 (row, pixel) displacements as scalar offsets of buffer stores.
+    if (small_tensors && ty0 + ST <= a.h && tx0 + ST <= a.wd && a.co == 16 * CO_T && !a.accumulate && a.residual == nullptr) {
+      const int lane_off = (((ni * a.h + ty0 + 4 * wave) * a.wd + tx0 + 4 * kq) * a.co + li) * 4;
+      const int row_b = a.wd * a.co * 4, pix_b = a.co * 4;
+      const bool plain = a.bias == nullptr && a.act == UDASEG_ACT_NONE;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+          for (int ct = 0; ct < CO_T; ++ct) {
+            float val = acc[r][ct][v];
+            if (!plain) val += bias[ct];
+            ssum[ct] += val;
+            ssq[ct] = __builtin_fmaf(val, val, ssq[ct]);
+            if (!plain) val = act_apply(val, a.act, a.slope);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rsrc_y, lane_off + ct * 64,
+                                                  r * row_b + v * pix_b, 0);
+          }
+      continue;
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int gy = ty0 + 4 * wave + r;
