@@ -5,20 +5,28 @@ The reference is single-process: this layer is new.  Image batches 
 statistics stay local (per-GPU batch 8 reproduces the single-GPU semantics; torch-DDP ``broadcast_buffers=False``
 equivalent), gradients are averaged.  Because a network's gradients are ONE contiguous arena filled back-to-front by
 the backward plan, a bucket is just an arena slice: the plan reports "everything at offsets >= o is final" after each
-block and the reducer launches the buckets that became complete -- large (default 32 MiB) collectives, sized for the
+block and the reducer launches the buckets that became complete -- large (default 32 MiB) collectives, plus one short
+(4 MiB) slice for the gradients that finish last, sized for the
 per-link-bound xGMI ring rather than many small ones.
 """
 import torch
 import torch.distributed as dist
 
 
-def bucket_ranges(total, bucket_elems):
-    """Arena slices [a, b) walking from the END of the arena (first gradients to be ready) to the front."""
+def bucket_ranges(total, bucket_elems, tail_elems=0):
+    """Arena slices [a, b) walking from the END of the arena (first gradients to be ready) to the front.
+
+    ``tail_elems`` > 0 makes the front-most slice at most that long: it holds the gradients that finish last (stem and the
+    first encoder stages), its all-reduce cannot overlap with any backward work, so it is kept short; everything behind it
+    goes out in large slices while the expensive high-resolution encoder layers are still computing."""
     out, b = [], total
-    while b > 0:
-        a = max(0, b - bucket_elems)
+    tail = min(max(tail_elems, 0), total)
+    while b > tail:
+        a = max(tail, b - bucket_elems)
         out.append((a, b))
         b = a
+    if tail > 0:
+        out.append((0, tail))
     return out
 
 
@@ -44,11 +52,12 @@ class GradAllReducer:
     """Attach to a network (``Unet``): ``net.grad_ready_hook`` drives bucket launches during backward;
     ``finish()`` (called by the trainer before ``optimizer.step()``) makes the compute stream wait for them."""
 
-    def __init__(self, net, bucket_bytes=32 << 20, group=None):
+    def __init__(self, net, bucket_bytes=32 << 20, group=None, tail_bytes=4 << 20):
         self.net = net
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.bucket_elems = max(1, bucket_bytes // 4)
+        self.tail_elems = max(0, tail_bytes // 4)
         self.comm_stream = None
         self._plan = None
         self._pending = []
@@ -59,7 +68,7 @@ class GradAllReducer:
     def _begin(self, P):
         self._plan = P
         self._garena = P.garena
-        self._pending = bucket_ranges(P.garena.numel(), self.bucket_elems)
+        self._pending = bucket_ranges(P.garena.numel(), self.bucket_elems, self.tail_elems)
         self.launched = []
         if P.garena.is_cuda and self.comm_stream is None:
             self.comm_stream = torch.cuda.Stream(device=P.garena.device)
