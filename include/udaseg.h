@@ -241,6 +241,9 @@ int udaseg_prepare_batch_u8(const uint8_t* images, const uint8_t* masks, const i
 /* ---- scratch: one caller-owned device buffer the library may use for split partial results (currently the
  *      small-channel weight gradient, <= 10 MiB).  Without it those calls take the generic atomics path. ---- */
 int udaseg_set_workspace(void* ptr, size_t bytes);
+/* bytes of that buffer udaseg_conv2d_wgrad would use for this convolution (0 = none); the maximum over a network's layers is
+ * what the caller should provide (the Python host hands over 16 MiB once per device). */
+size_t udaseg_workspace_bytes(const udaseg_conv_desc* d);
 
 /* ---- bf16 storage path (BASELINE configs 3 / 5): the HBM-bound kernels above on bf16 NHWC tensors (channels % 8 == 0),
  *      arithmetic and statistics in fp32 / f64; same meaning as their fp32 namesakes.  Parameters, their gradients and the

@@ -492,6 +492,14 @@ int launch_small_wgrad(const float* x, const float* dy, float* dw, int n, int h,
 
 }  // namespace udaseg
 
+extern "C" size_t udaseg_workspace_bytes(const udaseg_conv_desc* d) {
+  // what udaseg_conv2d_wgrad wants to find in the workspace for this convolution (0: it needs none)
+  if (!d || d->kh != d->kw || !udaseg::small_conv_applicable(d->kh, d->stride, d->pad, d->ci, d->co)) return 0;
+  const int G = (d->ci + 15) / 16, T = (d->co + 15) / 16;
+  const int ntiles = d->n * udaseg::cdiv(d->hi, udaseg::ST) * udaseg::cdiv(d->wi, udaseg::ST);
+  return (size_t)udaseg::small_grid(ntiles, 2) * (16 * T) * 9 * (16 * G) * sizeof(float);
+}
+
 extern "C" int udaseg_set_workspace(void* ptr, size_t bytes) {
   udaseg::g_workspace = ptr;
   udaseg::g_workspace_bytes = ptr ? bytes : 0;
