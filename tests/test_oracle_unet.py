@@ -102,3 +102,16 @@ def test_upsample_mode_switch():
     with torch.no_grad():
         assert a(x).shape == b(x).shape == (1, 23, 64, 64)
         assert not torch.allclose(a(x), b(x))
+
+
+def test_baseline_config0_cpu_plumbing():
+    """BASELINE.json configs[0]: the reference's own CPU-runnable case (tiny encoder-decoder, 4 x 256 x 256 synthetic source
+    batch) through the oracle's train step: finite, and two Adam steps at lr 1e-3 lower the loss on the same batch."""
+    from oracle.adversarial_ref import segmentation_step, synthetic_batch
+    torch.manual_seed(1234)
+    torch.set_num_threads(8)
+    model = UnetRef("resnet18", classes=23).train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    x, y, _ = synthetic_batch(4, 256, 256, seed=0)
+    losses = [float(segmentation_step(model, opt, x, y)[0]) for _ in range(3)]
+    assert all(np.isfinite(v) for v in losses) and losses[-1] < losses[0], losses
