@@ -170,7 +170,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
         }
       }
       u_ainv[p] = inv;
-      u_aoff[p] = ((unsigned)(a_base[p] + a_iy[p] * a.wi + a_ix[p]) * (unsigned)a.ci + (unsigned)(kq * EPV)) * (unsigned)ES;
+      // rows past the end of the class keep offset 0: with every tap marked invalid their address is 2^31 + (a small tap
+      // offset), safely outside any buffer of at most 2^30 bytes (a wrapped garbage offset might not be)
+      u_aoff[p] = inv == 0xffffffffu
+                      ? 0u
+                      : ((unsigned)(a_base[p] + a_iy[p] * a.wi + a_ix[p]) * (unsigned)a.ci + (unsigned)(kq * EPV)) * (unsigned)ES;
     }
 #pragma unroll
     for (int p = 0; p < B_PASS; ++p)
