@@ -1,0 +1,55 @@
+"""Reduce one rocprofv3 PMC pass (--pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA) to the
+matrix-pipe utilisation of every conv kernel symbol.
+
+    python tools/pmc_mfma.py <counter_collection.csv> <out.json>
+
+SQ_VALU_MFMA_BUSY_CYCLES is summed over the chip's 1024 SIMDs; GRBM_GUI_ACTIVE is reported as the sum over the 8 XCDs
+(MI355X_MICROARCH.md, DVFS section), so   mfma_busy = BUSY_CYCLES / (1024 * GUI_ACTIVE / 8)   is the fraction of SIMD cycles
+the matrix pipe was executing, clock-independent.  valu_per_mfma = non-MFMA VALU instructions per MFMA instruction
+(SQ_INSTS_VALU counts MFMAs too) -- on gfx950 fp32 MFMA shares its ALUs with the VALU, so this ratio bounds mfma_busy.
+"""
+import csv
+import json
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = re.sub(r"^void ", "", name)
+    name = re.sub(r"\(.*$", "", name)
+    return name.replace("udaseg::", "")
+
+
+def main():
+    acc = defaultdict(lambda: defaultdict(float))
+    cnt = defaultdict(int)
+    seen = set()
+    for r in csv.DictReader(open(sys.argv[1])):
+        k = short(r["Kernel_Name"])
+        if not k.startswith("conv"):
+            continue
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        key = (k, r["Dispatch_Id"])
+        if key not in seen:
+            seen.add(key)
+            cnt[k] += 1
+            acc[k]["_ns"] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    out = {}
+    for k, v in acc.items():
+        gui = v.get("GRBM_GUI_ACTIVE", 0.0)
+        busy = v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
+        mf = v.get("SQ_INSTS_MFMA", 0.0)
+        out[k] = {"launches": cnt[k], "avg_us": round(v["_ns"] / cnt[k] / 1e3, 1),
+                  "mfma_busy": round(busy / (1024 * gui / 8), 4) if gui else None,
+                  "valu_per_mfma": round((v.get("SQ_INSTS_VALU", 0.0) - mf) / mf, 2) if mf else None,
+                  "clock_ghz": round(gui / 8 / v["_ns"], 3) if v["_ns"] else None}
+    json.dump({"note": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA, r18-Unet "
+                       "8x3x512x512 fp32 train step, single stream; mfma_busy = fraction of SIMD cycles with the matrix pipe busy",
+               "kernels": out}, open(sys.argv[2], "w"), indent=1)
+    for k, v in sorted(out.items(), key=lambda kv: -kv[1]["avg_us"] * kv[1]["launches"]):
+        print(f"{k:52s} n={v['launches']:4d} {v['avg_us']:8.1f} us  mfma_busy {v['mfma_busy']}  valu/mfma {v['valu_per_mfma']}  clk {v['clock_ghz']}")
+
+
+if __name__ == "__main__":
+    main()
