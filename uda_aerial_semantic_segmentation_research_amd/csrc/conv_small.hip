@@ -58,11 +58,16 @@ struct HaloRegs {
       v[it] = t;
     }
   }
+  // HP = floats per halo pixel in LDS (>= CIP).  The forward kernel pads a pixel to CIP + 4 floats: its 16-byte fragment
+  // reads have one lane per PIXEL, and at a stride of 64 or 128 bytes those lanes fall on 4 or 2 bank groups (4- to 8-way
+  // conflicts); +16 bytes spreads 16 consecutive pixels over all 64 banks.
+  template <int HP = CIP>
   __device__ __forceinline__ void commit(float* __restrict__ halo) const {
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
       const int idx = threadIdx.x + 256 * it;
-      if (idx < TOTAL) *reinterpret_cast<f32x4*>(halo + idx * 4) = v[it];   // pos*CIP + cq*4 == idx*4
+      const int pos = idx / Q, cq = idx - pos * Q;
+      if (idx < TOTAL) *reinterpret_cast<f32x4*>(halo + pos * HP + cq * 4) = v[it];
     }
   }
 
@@ -131,7 +136,8 @@ __device__ __forceinline__ TileCoord tile_coord(int tile, int tiles_x, int tiles
 template <int G, int CO_T>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G * CO_T == 1 ? 3 : 2))) void conv3x3_small_kernel(const SmallArgs a) {
   constexpr int CIP = 16 * G;
-  __shared__ __attribute__((aligned(16))) float halo[SH * SH * CIP];
+  constexpr int HP = CIP + 4;   // padded pixel stride, see HaloRegs::commit
+  __shared__ __attribute__((aligned(16))) float halo[SH * SH * HP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, kq = lane >> 4;
 
@@ -178,7 +184,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G * CO_T ==
     const TileCoord tc = tile_coord(tile, a.tiles_x, a.tiles_y);
     const int ni = tc.ni, ty0 = tc.ty0, tx0 = tc.tx0;
     __syncthreads();  // previous tile's readers are done with the halo
-    stage.commit(halo);
+    stage.template commit<HP>(halo);
     __syncthreads();
     if (tile + (int)gridDim.x < a.ntiles) issue_tile(tile + gridDim.x);  // next tile's halo flies during this tile's MFMAs
 
@@ -198,7 +204,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G * CO_T ==
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int hy = 4 * wave + r + 1 + dy, hx = li + 1 + dx;
-          af[r] = *reinterpret_cast<const f32x4*>(halo + (hy * SH + hx) * CIP + 16 * g + 4 * kq);
+          af[r] = *reinterpret_cast<const f32x4*>(halo + (hy * SH + hx) * HP + 16 * g + 4 * kq);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e)
