@@ -91,6 +91,87 @@ __global__ __launch_bounds__(256) void gemm(const float* __restrict__ A, const f
   }
 }
 
+
+// MODE 5: the same GEMM with direct-to-LDS loads (raw_ptr_buffer_load_lds, 16 B per lane): no staging registers, no
+// ds_write; LDS rows are unpadded 128-B rows whose eight 16-B chunks are XOR-swizzled with (row >> 1) & 7 so that the
+// 16-byte fragment reads of 32 consecutive rows stay conflict-free.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+__global__ __launch_bounds__(256) void gemm_glds(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
+                                                 int M, int N, int K) {
+  __shared__ __attribute__((aligned(1024))) float As[2][BM * 32];
+  __shared__ __attribute__((aligned(1024))) float Bs[2][BN * 32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  const int ntn = N / BN;
+  const int m0 = (blockIdx.x / ntn) * BM, n0 = (blockIdx.x % ntn) * BN;
+  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)((long long)M * K * 4 < (1LL << 31) ? (long long)M * K * 4 : 0x7fffffff), 0x00020000);
+  __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)((long long)N * K * 4 < (1LL << 31) ? (long long)N * K * 4 : 0x7fffffff), 0x00020000);
+  // this wave fills LDS slots [(wave*2 + p) * 64, +64) of a tile (16-B slots, 8 per row)
+  unsigned offa[2], offb[2];
+  for (int p = 0; p < 2; ++p) {
+    const int S = (wave * 2 + p) * 64 + lane, row = S >> 3, j = S & 7, c = j ^ ((row >> 1) & 7);
+    offa[p] = (unsigned)((m0 + row) * K + c * 4) * 4u;
+    offb[p] = (unsigned)((n0 + row) * K + c * 4) * 4u;
+  }
+  f32x16 acc;
+  for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+  const int nkt = K / BK;
+  auto load = [&](int kt, int buf) {
+    const unsigned kb = (unsigned)kt * BK * 4u;
+    for (int p = 0; p < 2; ++p) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(&As[buf][(wave * 2 + p) * 256]), 16, (int)(offa[p] + kb), 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)(&Bs[buf][(wave * 2 + p) * 256]), 16, (int)(offb[p] + kb), 0, 0, 0);
+    }
+  };
+  const int ra_row = wm + lr, rb_row = wn + lr;
+  const int sa = (ra_row >> 1) & 7, sb = (rb_row >> 1) & 7;
+  auto mfma = [&](int buf) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int c = 2 * s + lh;
+      const f32x4 af = *reinterpret_cast<const f32x4*>(&As[buf][ra_row * 32 + ((c ^ sa) << 2)]);
+      const f32x4 bf = *reinterpret_cast<const f32x4*>(&Bs[buf][rb_row * 32 + ((c ^ sb) << 2)]);
+#pragma unroll
+      for (int k2 = 0; k2 < 4; ++k2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[k2], bf[k2], acc, 0, 0, 0);
+    }
+  };
+  load(0, 0);
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < nkt; ++kt) {
+    if (kt + 1 < nkt) load(kt + 1, cur ^ 1);
+    mfma(cur);
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's LDS-DMA pieces have landed
+    __syncthreads();
+    cur ^= 1;
+  }
+  for (int v = 0; v < 16; ++v) {
+    const int m = m0 + wm + (v & 3) + 8 * (v >> 2) + 4 * lh;
+    C[(size_t)m * N + n0 + wn + lr] = acc[v];
+  }
+}
+
+void run_glds(const float* A, const float* B, float* C, int M, int N, int K) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  const int grid = (M / BM) * (N / BN);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(gemm_glds, dim3(grid), dim3(256), 0, 0, A, B, C, M, N, K);
+  hipEventRecord(e0);
+  const int it = 10;
+  for (int i = 0; i < it; ++i) hipLaunchKernelGGL(gemm_glds, dim3(grid), dim3(256), 0, 0, A, B, C, M, N, K);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms;
+  hipEventElapsedTime(&ms, e0, e1);
+  ms /= it;
+  printf("  mode 5 %-44s %8.1f us  %7.1f TFLOP/s\n", "direct-to-LDS loads, swizzled rows", ms * 1e3, 2.0 * M * N * K / ms / 1e9);
+}
+
+// checks mode 5 against mode 0 on the current C contents
+
 template <int MODE>
 void run(const float* A, const float* B, float* C, int M, int N, int K, const char* what) {
   hipEvent_t e0, e1;
@@ -124,6 +205,18 @@ int main(int argc, char** argv) {
     printf("M=%d N=%d K=%d\n", M, N, K);
     run<0>(A, B, C, M, N, K, "full loop (load kt+1, mfma, store, barrier)");
     run<4>(A, B, C, M, N, K, "full loop, loads two tiles ahead");
+    {
+      float* C2;
+      hipMalloc(&C2, (size_t)M * N * 4);
+      run_glds(A, B, C2, M, N, K);
+      hipLaunchKernelGGL(gemm<0>, dim3((M / BM) * (N / BN)), dim3(256), 0, 0, A, B, C, M, N, K);
+      hipDeviceSynchronize();
+      float* h1 = (float*)malloc(4096 * 4); float* h2 = (float*)malloc(4096 * 4);
+      hipMemcpy(h1, C, 4096 * 4, hipMemcpyDeviceToHost); hipMemcpy(h2, C2, 4096 * 4, hipMemcpyDeviceToHost);
+      double md = 0; for (int i = 0; i < 4096; ++i) { double d = h1[i] - h2[i]; if (d < 0) d = -d; if (d > md) md = d; }
+      printf("         (mode 5 vs mode 0: max |diff| over the first 4096 outputs = %g)\n", md);
+      free(h1); free(h2); hipFree(C2);
+    }
     run<1>(A, B, C, M, N, K, "no global loads");
     run<2>(A, B, C, M, N, K, "no loads, no LDS stores, no barrier");
     run<3>(A, B, C, M, N, K, "MFMA only");
