@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void gemm(const float* __restrict__ A, const f
   const int kq = tid & 7, lrow = tid >> 3;
   f32x16 acc;
   for (int v = 0; v < 16; ++v) acc[v] = 0.f;
-  f32x4 ra[2][2], rb[2][2];
+  f32x4 ra[3][2], rb[3][2];
   const int nkt = K / BK;
   auto load = [&](int kt, int st) {
     for (int p = 0; p < 2; ++p) {
@@ -58,9 +58,21 @@ __global__ __launch_bounds__(256) void gemm(const float* __restrict__ A, const f
   };
   load(0, 0);
   store(0, 0);
-  if (MODE == 4 && nkt > 1) load(1, 1);
+  if ((MODE == 4 || MODE == 6) && nkt > 1) load(1, 1);
   __syncthreads();
-  if (MODE == 4) {
+  if (MODE == 6) {      // three register stages: tiles kt+1, kt+2, kt+3 in flight around the MFMA phase of kt
+    // (entered with tile 0 in LDS buffer 0 and tile 1 in flight in stage 1, like MODE 4)
+    if (nkt > 2) load(2, 2);
+    int kt = 0;
+    for (; kt + 5 < nkt; kt += 6) {   // buffers alternate 0/1, stages rotate 1 -> 2 -> 0
+      load(kt + 3, 0); mfma(0); store(1, 1); __syncthreads();
+      load(kt + 4, 1); mfma(1); store(0, 2); __syncthreads();
+      load(kt + 5, 2); mfma(0); store(1, 0); __syncthreads();
+      load(kt + 6 < nkt ? kt + 6 : kt, 0); mfma(1); store(0, 1); __syncthreads();
+      load(kt + 7 < nkt ? kt + 7 : kt, 1); mfma(0); store(1, 2); __syncthreads();
+      load(kt + 8 < nkt ? kt + 8 : kt, 2); mfma(1); store(0, 0); __syncthreads();
+    }
+  } else if (MODE == 4) {
     int kt = 0;
     for (; kt + 3 < nkt; kt += 2) {
       load(kt + 2, 0);
@@ -205,6 +217,7 @@ int main(int argc, char** argv) {
     printf("M=%d N=%d K=%d\n", M, N, K);
     run<0>(A, B, C, M, N, K, "full loop (load kt+1, mfma, store, barrier)");
     run<4>(A, B, C, M, N, K, "full loop, loads two tiles ahead");
+    run<6>(A, B, C, M, N, K, "full loop, loads three tiles ahead (timing)");
     {
       float* C2;
       hipMalloc(&C2, (size_t)M * N * 4);
