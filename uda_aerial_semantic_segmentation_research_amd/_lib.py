@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libudaseg_hip.so")
+LIB_PATH = os.environ.get("UDASEG_LIB", os.path.join(_HERE, "libudaseg_hip.so"))   # UDASEG_LIB: an alternative build (tuning)
 
 ACT_NONE = 0
 ACT_LEAKY = 1  # slope 0 => ReLU
