@@ -8,10 +8,17 @@
 Workload (BASELINE.json configs[1]): ResNet-18 encoder + Unet decoder, source-only cross entropy, batch 8 x 3 x 512 x 512
 per GPU, fp32, synthetic N(0,1) images / uniform labels, seeded random-init weights.  A "step" is the reference's timed
 region src/models/train.py:340-344: zero_grad -> forward -> CrossEntropy -> backward -> (gradient all-reduce) ->
-Adam step.  Weak scaling: per-GPU batch fixed; `value` = images processed by all ranks / max-over-ranks wall time.
+Adam step.  Weak scaling: per-GPU batch fixed; `value` = images processed by all ranks / max-over-ranks wall time of
+EXACTLY --steps steps between two barrier + synchronize pairs.
 
-One JSON line on rank 0, with `roofline` (conv implicit-GEMM kernel family, HIP-event timed on the launch stream in a
-separate profiling leg after the timed region) and `cpu_baseline` (the CPU oracle timed on the host cores, N=1 only).
+One JSON line on rank 0:
+  * `step_ms`     -- HIP-event duration of every timed step (median / p10 / p90), next to the wall-clock `ms_per_step`;
+  * `sustained`   -- the same step repeated for ~2.5 s after the timed region (not part of `value`): a 20-step region lasts
+                     a quarter of a second, too short for a sampling monitor to see the GPU busy or for the clock to settle;
+  * `roofline`    -- dominant conv kernel symbol, HIP-event timed on the launch stream in a separate single-stream leg;
+  * `cpu_baseline`-- the CPU oracle timed on the host cores (N=1 only);
+  * `also`        -- short legs of BASELINE configs 3 and 5 (bf16 storage: adversarial iteration 8+8 x 512^2; r50 at 768^2),
+                     each with its own ms_per_step and dominant-kernel roofline (N=1 only; informational).
 """
 import argparse
 import json
@@ -28,13 +35,16 @@ import torch
 import torch.distributed as dist
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0     # same guide: ~2.5 PF dense bf16 (never the 2:1-sparsity figure)
 WORKLOAD_TEXT = {
     "segmentation": "source-only CE train step (zero_grad,fwd,CE,bwd,allreduce,Adam)",
     "adversarial": "adversarial iteration (D step on 8 source + 8 target images, then segmenter step: CE + lambda*BCE)",
     "inference": "validation step (eval forward with folded BN, CE, device-side confusion matrix)",
 }
-BF16_MFMA_PEAK_TFLOPS = 2500.0     # same guide: ~2.5 PF dense bf16 (never the 2:1-sparsity figure)
-R18_CONV_GFLOP_PER_IMAGE = 133.30  # fwd + dgrad + wgrad conv FLOPs per source image, r18-Unet @512^2
+# conv FLOPs per SOURCE image, fwd + dgrad + wgrad (no dgrad for the stem / D's first conv)
+CONV_GFLOP_PER_IMAGE = {("segmentation", "resnet18", 512): 133.30, ("segmentation", "resnet50", 512): 258.93,
+                        ("segmentation", "resnet50", 768): 582.60, ("segmentation", "resnet34", 512): 191.29,
+                        ("adversarial", "resnet18", 512): 251.68}
 
 
 def synthetic(n, h, w, classes, seed, device):
@@ -46,17 +56,19 @@ def synthetic(n, h, w, classes, seed, device):
 
 
 def pmc_traffic(kernel):
-    """HBM-side bytes per launch of `kernel` from the committed PMC reduction (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-    separate passes, corrected as MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py).  None when there is no such file."""
+    """(HBM-side bytes per launch of `kernel`, source file) from the newest committed PMC reduction (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate passes, corrected as MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py).  The PMC
+    passes cannot run inside this script (counter collection needs its own rocprofv3 process): the value is a committed
+    measurement of the same kernel symbol, (None, None) when no committed file knows the symbol."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
-    if not files:
-        return None
-    try:
-        k = json.load(open(files[-1]))["kernels"].get(kernel)
-        return k["hbm_bytes_per_launch"] if k else None
-    except Exception:
-        return None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")), reverse=True):
+        try:
+            k = json.load(open(f))["kernels"].get(kernel)
+        except Exception:
+            continue
+        if k:
+            return k["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
+    return None, None
 
 
 def cpu_baseline(encoder, classes, hw, budget_s=25.0):
@@ -81,8 +93,174 @@ def cpu_baseline(encoder, classes, hw, budget_s=25.0):
         steps += 1
     dt = time.perf_counter() - t0
     return {"value": round(n * steps / dt, 3), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} steps of batch {n}x3x{hw}x{hw} fp32 after 1 warm-up, torch {torch.__version__} CPU, "
-                      f"oracle/unet_ref.py UnetRef({encoder}) + torch.optim.Adam"}
+            "sample": f"{steps} steps of batch {n}x3x{hw}x{hw} fp32 (the GPU leg runs batch 8) after 1 warm-up, "
+                      f"torch {torch.__version__} CPU, oracle/unet_ref.py UnetRef({encoder}) + torch.optim.Adam"}
+
+
+def build_leg(workload, encoder, dtype, batch, size, classes, dev, rank, world, rehearse):
+    """Model + trainer + synthetic batch of one benchmark leg -> (step callable, model, trainer)."""
+    from uda_aerial_semantic_segmentation_research_amd.ddp import GradAllReducer, broadcast_parameters
+    from uda_aerial_semantic_segmentation_research_amd.optim import FusedAdam
+    from uda_aerial_semantic_segmentation_research_amd.train import SegmentationTrainer
+    from uda_aerial_semantic_segmentation_research_amd.unet import Unet
+    torch.manual_seed(1234)
+    model = Unet(encoder_name=encoder, encoder_weights=None, in_channels=3, classes=classes,
+                 compute_dtype=torch.bfloat16 if dtype == "bf16" else torch.float32)
+    if workload == "adversarial":
+        from uda_aerial_semantic_segmentation_research_amd.adversarial_trainer import AdversarialTrainer
+        trainer = AdversarialTrainer(model, dev, lambda_adv=0.001)
+        trainer.discriminator.train()
+    else:
+        trainer = SegmentationTrainer(model, dev)
+    model.train()
+    model.ensure_arena()
+    if world > 1 or rehearse:
+        from uda_aerial_semantic_segmentation_research_amd import ddp as _ddp
+        _ddp.FORCE = os.environ.get("UDASEG_DDP_REHEARSE") == "1"       # "2": hooks and streams only, no collectives
+        if world > 1:
+            broadcast_parameters(model)
+        else:
+            dist.broadcast(model._arena, 0)
+        if os.environ.get("UDASEG_DDP_REHEARSE") != "3":               # "3": process group only
+            trainer.grad_reducer = GradAllReducer(model, bucket_bytes=int(os.environ.get("UDASEG_DDP_BUCKET_MB", "32")) << 20)
+            if workload == "adversarial":
+                broadcast_parameters(trainer.discriminator)
+                trainer.d_grad_reducer = GradAllReducer          # its allreduce_now(): one collective over D's gradient arena
+    opt = FusedAdam(model.parameters(), lr=1e-4)
+    x, y = synthetic(batch, size, size, classes, seed=100 * rank, device=dev)
+    if workload == "inference":
+        # validate()'s inner loop (train.py:398-408): eval forward + CE + metrics, BatchNorm folded into the convs
+        model.eval()
+        from uda_aerial_semantic_segmentation_research_amd.metrics import confusion_matrix
+
+        def step():
+            with torch.no_grad():
+                out = model(x)
+                loss = trainer.criterion(out, y)
+                confusion_matrix(out, y, classes)
+            return loss
+    elif workload == "adversarial":
+        xt, _ = synthetic(batch, size, size, classes, seed=100 * rank + 2, device=dev)
+        trainer.discriminator_optimizer = FusedAdam(trainer.discriminator.parameters(), lr=1e-4)
+
+        def step():
+            return trainer.adversarial_step(x, y, xt, opt, update_metrics=False)[3]
+    else:
+        def step():
+            return trainer.train_step(x, y, opt)[0]
+    return step, model, trainer
+
+
+def percentile(v, q):
+    v = sorted(v)
+    return v[min(len(v) - 1, max(0, int(round(q * (len(v) - 1)))))]
+
+
+def timed_region(step, steps, warmup, world, dev, rehearse):
+    """W untimed steps, then EXACTLY `steps` steps between barrier + synchronize pairs.  Returns (max-over-ranks wall
+    seconds, per-step HIP-event milliseconds, last loss)."""
+    for _ in range(warmup):
+        step()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for a, b in evs:
+        a.record()
+        loss = step()
+        b.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1 or rehearse:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, [a.elapsed_time(b) for a, b in evs], loss
+
+
+def roofline_leg(step, model, trainer, dtype, psteps=3, layer_table=False):
+    """Separate leg: HIP events around every conv-kernel launch on the launch stream (C-ABI udaseg_prof_*), single stream --
+    with the weight gradients on their side stream concurrent kernels stretch each other's durations and a per-kernel rate
+    would under-state the kernel (the timed region keeps the overlap).  No collective may be issued here."""
+    from uda_aerial_semantic_segmentation_research_amd import engine as _engine
+    from uda_aerial_semantic_segmentation_research_amd import kernels as K
+    was_side = _engine.SIDE_STREAM_WGRAD
+    _engine.SIDE_STREAM_WGRAD = False
+    trainer.grad_reducer = None
+    model.grad_ready_hook = None
+    if hasattr(trainer, "d_grad_reducer"):
+        trainer.d_grad_reducer = None
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    K.prof_reset()
+    K.prof_enable(True)
+    for _ in range(psteps):
+        step()
+    torch.cuda.synchronize()
+    K.prof_enable(False)
+    _engine.SIDE_STREAM_WGRAD = was_side
+    if layer_table:
+        agg = {}
+        for fam in (0, 1):
+            for ms, fl, kind, d in K.prof_records(fam):
+                a = agg.setdefault((kind, d), [0.0, 0.0, 0])
+                a[0] += ms
+                a[1] += fl
+                a[2] += 1
+        print("kind  n  hi  wi   ci   co k s |  calls/step  ms/call   GFLOP   TFLOP/s", file=sys.stderr)
+        for (kind, d), (ms, fl, cnt) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+            print(f"{('fwd', 'dgrad', 'wgrad')[kind]:5s} {d[0]:2d} {d[1]:3d} {d[2]:3d} {d[3]:4d} {d[6]:4d} {d[7]} {d[9]} | "
+                  f"{cnt / psteps:5.1f} {ms / cnt:9.4f} {fl / cnt / 1e9:8.2f} {fl / ms / 1e9:8.1f}", file=sys.stderr)
+    kern = [k for k in K.prof_kernels() if k[3] > 0]
+    K.prof_reset()
+    kern.sort(key=lambda k: -k[1])
+    dom = kern[0]                                   # the kernel symbol with the most device time
+    achieved = dom[2] / (dom[1] * 1e-3) / 1e12
+    conv_ms = sum(k[1] for k in kern) / psteps
+    peak = BF16_MFMA_PEAK_TFLOPS if dtype == "bf16" else FP32_MFMA_PEAK_TFLOPS
+    traffic, traffic_src = pmc_traffic(dom[0])
+    return {"bound": "mfma", "kernel": dom[0], "achieved": round(achieved, 2), "peak": peak,
+            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+            "traffic_source": (traffic_src + " (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this symbol; "
+                               "counters cannot be collected from inside the timed process)") if traffic_src else None,
+            "launches_per_step": dom[3] // psteps, "avg_launch_us": round(1e3 * dom[1] / dom[3], 2),
+            "gflop_per_launch": round(dom[2] / dom[3] / 1e9, 3),
+            "ms_per_step": round(dom[1] / psteps, 3),
+            "all_conv_kernels": {"ms_per_step": round(conv_ms, 3),
+                                 "achieved": round(sum(k[2] for k in kern) / psteps / (conv_ms * 1e-3) / 1e12, 2),
+                                 "flops_note": "per-kernel GEMM FLOPs count PHYSICAL channels (image 3->4, logits 23->24): the "
+                                               "stem and head rows are overstated by 33 % / 4 %; the headline "
+                                               "conv_mfma_util_per_gpu uses the logical 133.30 GFLOP per image",
+                                 "by_kernel": {k[0]: {"ms_per_step": round(k[1] / psteps, 3),
+                                                      "tflops": round(k[2] / (k[1] * 1e-3) / 1e12, 1),
+                                                      "launches_per_step": k[3] // psteps} for k in kern}}}
+
+
+def also_leg(name, workload, encoder, dtype, batch, size, classes, dev, steps=8, warmup=3):
+    """A short informational leg of another BASELINE config in the same process (N=1 only)."""
+    step, model, trainer = build_leg(workload, encoder, dtype, batch, size, classes, dev, 0, 1, False)
+    dt, ev_ms, loss = timed_region(step, steps, warmup, 1, dev, False)
+    roof = roofline_leg(step, model, trainer, dtype, psteps=2)
+    value = batch * steps / dt
+    gf = CONV_GFLOP_PER_IMAGE.get((workload, encoder, size))
+    peak = BF16_MFMA_PEAK_TFLOPS if dtype == "bf16" else FP32_MFMA_PEAK_TFLOPS
+    out = {"config": name, "workload": f"{encoder}-Unet {WORKLOAD_TEXT[workload]}, batch {batch}x3x{size}x{size}, {dtype}",
+           "value": round(value, 2), "unit": "images/s", "steps": steps, "warmup": warmup,
+           "ms_per_step": round(1e3 * dt / steps, 3), "step_ms_median": round(percentile(ev_ms, 0.5), 3),
+           "final_loss": round(float(loss.item()), 5),
+           "conv_mfma_util": round(value * gf / 1e3 / peak, 4) if gf else None,
+           "roofline": {k: roof[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launches_per_step",
+                                             "avg_launch_us", "ms_per_step")},
+           "all_conv_kernels_ms_per_step": roof["all_conv_kernels"]["ms_per_step"]}
+    del step, model, trainer
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -96,6 +274,8 @@ def main():
     ap.add_argument("--classes", type=int, default=23)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the short cfg 3 / cfg 5 legs")
+    ap.add_argument("--no-sustain", action="store_true", help="skip the ~2.5 s sustained leg after the timed region")
     ap.add_argument("--layer-table", action="store_true", help="print TFLOP/s per conv shape (stderr)")
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
                     help="fp32 = BASELINE configs[1] (headline); bf16 = bf16 storage / MFMA with fp32 master (configs 3, 5), "
@@ -127,157 +307,67 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    from uda_aerial_semantic_segmentation_research_amd import kernels as K
-    from uda_aerial_semantic_segmentation_research_amd.ddp import GradAllReducer, broadcast_parameters
-    from uda_aerial_semantic_segmentation_research_amd.optim import FusedAdam
-    from uda_aerial_semantic_segmentation_research_amd.train import SegmentationTrainer
-    from uda_aerial_semantic_segmentation_research_amd.unet import Unet
-
-    torch.manual_seed(1234)
-    model = Unet(encoder_name=args.encoder, encoder_weights=None, in_channels=3, classes=args.classes,
-                 compute_dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32)
-    if args.workload == "adversarial":
-        from uda_aerial_semantic_segmentation_research_amd.adversarial_trainer import AdversarialTrainer
-        trainer = AdversarialTrainer(model, dev, lambda_adv=0.001)
-        trainer.discriminator.train()
-    else:
-        trainer = SegmentationTrainer(model, dev)
-    model.train()
-    model.ensure_arena()
-    if world > 1 or rehearse:
-        from uda_aerial_semantic_segmentation_research_amd import ddp as _ddp
-        _ddp.FORCE = os.environ.get("UDASEG_DDP_REHEARSE") == "1"       # "2": hooks and streams only, no collectives
-        if world > 1:
-            broadcast_parameters(model)
-        else:
-            dist.broadcast(model._arena, 0)
-        if os.environ.get("UDASEG_DDP_REHEARSE") != "3":               # "3": process group only
-            trainer.grad_reducer = GradAllReducer(model, bucket_bytes=int(os.environ.get("UDASEG_DDP_BUCKET_MB", "32")) << 20)
-            if args.workload == "adversarial":
-                broadcast_parameters(trainer.discriminator)
-                trainer.d_grad_reducer = GradAllReducer          # its allreduce_now(): one collective over D's gradient arena
-    opt = FusedAdam(model.parameters(), lr=1e-4)
-    x, y = synthetic(args.batch, args.size, args.size, args.classes, seed=100 * rank, device=dev)
-    if args.workload == "inference":
-        # validate()'s inner loop (train.py:398-408): eval forward + CE + metrics, BatchNorm folded into the convs
-        model.eval()
-        from uda_aerial_semantic_segmentation_research_amd.metrics import confusion_matrix
-
-        def step():
-            with torch.no_grad():
-                out = model(x)
-                loss = trainer.criterion(out, y)
-                confusion_matrix(out, y, args.classes)
-            return loss, None
-    elif args.workload == "adversarial":
-        xt, _ = synthetic(args.batch, args.size, args.size, args.classes, seed=100 * rank + 2, device=dev)
-        trainer.discriminator_optimizer = FusedAdam(trainer.discriminator.parameters(), lr=1e-4)
-
-        def step():
-            seg, d_loss, adv, total = trainer.adversarial_step(x, y, xt, opt, update_metrics=False)
-            return total, None
-    else:
-        def step():
-            return trainer.train_step(x, y, opt)
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, _ = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1 or rehearse:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    headline = (args.workload == "segmentation" and args.dtype == "fp32" and args.size == 512 and args.encoder == "resnet18"
+                and args.batch == 8)
+    step, model, trainer = build_leg(args.workload, args.encoder, args.dtype, args.batch, args.size, args.classes, dev, rank,
+                                     world, rehearse)
+    dt, ev_ms, loss = timed_region(step, args.steps, args.warmup, world, dev, rehearse)
     final_loss = float(loss.item())
+
+    sustained = None
+    if not args.no_sustain and world == 1:
+        # the timed region is a fraction of a second: keep stepping (outside `value`) so that a sampling monitor sees the GPU
+        # busy and the rate is also known with the clock settled
+        per = dt / args.steps
+        n_sus = max(10, min(2000, int(2.5 / max(per, 1e-4))))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_sus):
+            step()
+        torch.cuda.synchronize()
+        ds = time.perf_counter() - t0
+        sustained = {"steps": n_sus, "seconds": round(ds, 3), "ms_per_step": round(1e3 * ds / n_sus, 3),
+                     "images_per_s": round(args.batch * n_sus / ds, 2)}
 
     roofline = None
     if not args.no_roofline and rank == 0:
-        # separate leg: HIP events around every conv-kernel launch on the launch stream (C-ABI udaseg_prof_*)
-        # single stream for this leg: with the weight gradients on their side stream, concurrent kernels stretch each
-        # other's durations and a per-kernel rate would under-state the kernel (the timed region above keeps the overlap)
-        from uda_aerial_semantic_segmentation_research_amd import engine as _engine
-        was_side = _engine.SIDE_STREAM_WGRAD
-        _engine.SIDE_STREAM_WGRAD = False
-        # only rank 0 runs this leg: no collective may be issued in it (the other ranks are already at the barrier below)
-        trainer.grad_reducer = None
-        model.grad_ready_hook = None
-        if hasattr(trainer, "d_grad_reducer"):
-            trainer.d_grad_reducer = None
-        for _ in range(2):
-            step()
-        torch.cuda.synchronize()
-        K.prof_reset()
-        K.prof_enable(True)
-        psteps = 3
-        for _ in range(psteps):
-            step()
-        torch.cuda.synchronize()
-        K.prof_enable(False)
-        _engine.SIDE_STREAM_WGRAD = was_side
-        ms0, fl0, n0 = K.prof_read(0)
-        ms1, fl1, n1 = K.prof_read(1)
-        if args.layer_table:
-            agg = {}
-            for fam in (0, 1):
-                for ms, fl, kind, d in K.prof_records(fam):
-                    a = agg.setdefault((kind, d), [0.0, 0.0, 0])
-                    a[0] += ms
-                    a[1] += fl
-                    a[2] += 1
-            print("kind  n  hi  wi   ci   co k s |  calls/step  ms/call   GFLOP   TFLOP/s", file=sys.stderr)
-            for (kind, d), (ms, fl, cnt) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
-                print(f"{('fwd', 'dgrad', 'wgrad')[kind]:5s} {d[0]:2d} {d[1]:3d} {d[2]:3d} {d[3]:4d} {d[6]:4d} {d[7]} {d[9]} | "
-                      f"{cnt / psteps:5.1f} {ms / cnt:9.4f} {fl / cnt / 1e9:8.2f} {fl / ms / 1e9:8.1f}", file=sys.stderr)
-        kern = [k for k in K.prof_kernels() if k[3] > 0]
-        K.prof_reset()
-        kern.sort(key=lambda k: -k[1])
-        dom = kern[0]                                   # the kernel symbol with the most device time
-        achieved = dom[2] / (dom[1] * 1e-3) / 1e12
-        conv_ms = sum(k[1] for k in kern) / psteps
-        peak = BF16_MFMA_PEAK_TFLOPS if args.dtype == "bf16" else FP32_MFMA_PEAK_TFLOPS
-        roofline = {"bound": "mfma", "kernel": dom[0], "achieved": round(achieved, 2), "peak": peak,
-                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": pmc_traffic(dom[0]),
-                    "launches_per_step": dom[3] // psteps, "avg_launch_us": round(1e3 * dom[1] / dom[3], 2),
-                    "gflop_per_launch": round(dom[2] / dom[3] / 1e9, 3),
-                    "ms_per_step": round(dom[1] / psteps, 3),
-                    "all_conv_kernels": {"ms_per_step": round(conv_ms, 3),
-                                         "achieved": round(sum(k[2] for k in kern) / psteps / (conv_ms * 1e-3) / 1e12, 2),
-                                         "by_kernel": {k[0]: {"ms_per_step": round(k[1] / psteps, 3),
-                                                              "tflops": round(k[2] / (k[1] * 1e-3) / 1e12, 1),
-                                                              "launches_per_step": k[3] // psteps} for k in kern}}}
+        # only rank 0 runs this leg (the other ranks are already at the barrier below)
+        roofline = roofline_leg(step, model, trainer, args.dtype, layer_table=args.layer_table)
     if world > 1:
         dist.barrier()
 
     if rank == 0:
         imgs = args.batch * world * args.steps
         value = imgs / dt
-        conv_tflops = value * R18_CONV_GFLOP_PER_IMAGE / 1e3 / world if args.encoder == "resnet18" and args.size == 512 else None
+        gf = CONV_GFLOP_PER_IMAGE.get((args.workload, args.encoder, args.size))
+        peak = BF16_MFMA_PEAK_TFLOPS if args.dtype == "bf16" else FP32_MFMA_PEAK_TFLOPS
         out = {
-            "metric": "training images/sec at 512x512" if (args.workload == "segmentation" and args.dtype == "fp32"
-                                                           and args.size == 512 and args.encoder == "resnet18")
-            else f"{args.workload} images/sec at {args.size}x{args.size} (informational, {args.encoder}, {args.dtype})", "value": round(value, 2), "unit": "images/s", "n_gpus": world,
+            "metric": "training images/sec at 512x512" if headline
+            else f"{args.workload} images/sec at {args.size}x{args.size} (informational, {args.encoder}, {args.dtype})",
+            "value": round(value, 2), "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.encoder}-Unet " + WORKLOAD_TEXT[args.workload] + ", "
                                    f"batch {args.batch}x3x{args.size}x{args.size} per GPU, {args.classes} classes, random init",
                        "global_batch": args.batch * world, "image": f"{args.size}x{args.size}", "parallelism": f"dp{world}",
                        "final_loss": round(final_loss, 5),
-                       "conv_mfma_util_per_gpu": round(conv_tflops / (BF16_MFMA_PEAK_TFLOPS if args.dtype == "bf16"
-                                                                      else FP32_MFMA_PEAK_TFLOPS), 4) if conv_tflops else None},
+                       # whole-job conv FLOP rate per GPU over the dense MFMA peak of the dtype; only for workloads whose conv
+                       # FLOPs per image are tabulated
+                       "conv_mfma_util_per_gpu": round(value * gf / 1e3 / world / peak, 4) if gf else None},
+            "step_ms": {"median": round(percentile(ev_ms, 0.5), 3), "p10": round(percentile(ev_ms, 0.1), 3),
+                        "p90": round(percentile(ev_ms, 0.9), 3), "timer": "hipEvent pair per step on the compute stream"},
+            "sustained": sustained,
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.encoder, args.classes, args.size)
+        if world == 1 and headline and not args.no_also and not rehearse:
+            del step, model, trainer
+            torch.cuda.empty_cache()
+            out["also"] = [
+                also_leg("BASELINE cfg 3", "adversarial", "resnet18", "bf16", 8, 512, args.classes, dev),
+                also_leg("BASELINE cfg 5 (per-GPU work)", "segmentation", "resnet50", "bf16", 8, 768, args.classes, dev),
+            ]
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -86,6 +86,30 @@ int udaseg_conv2d_dgrad(const udaseg_conv_desc* d, const float* dy, const float*
  * Split-K partials are combined with fp32 atomics. */
 int udaseg_conv2d_wgrad(const udaseg_conv_desc* d, const float* x, const float* dy, float* dw, int accumulate,
                         void* stream);
+/* ---- fused decoder input: smp's DecoderBlock computes conv(cat([interpolate(a, 2, 'nearest'), skip], 1)) (reference model
+ *      created at src/test_system.py:90-95; trace fixture: aten::upsample_nearest2d + aten::cat in front of every decoder
+ *      conv1).  The concatenation is never materialised: the convolution reads a [n][hi/2][wi/2][ca] at (iy >> 1, ix >> 1)
+ *      for its first ca input channels and skip [n][hi][wi][ci-ca] for the rest (skip == NULL when ca == ci).  d describes
+ *      the convolution on the VIRTUAL input (ci = ca + cb, hi x wi = full resolution), stride 1.  Channel counts must be
+ *      multiples of the K-tile (32 fp32 / 64 bf16) unless the small-channel kernel applies (ci <= 32, no skip). ---- */
+int udaseg_conv2d_fwd_upcat(const udaseg_conv_desc* d, const float* a, const float* skip, int ca, const float* w,
+                            const float* bias, float* y, int act, float slope, double* stats, void* stream);
+int udaseg_conv2d_fwd_upcat_bf16(const udaseg_conv_desc* d, const void* a, const void* skip, int ca, const void* w,
+                                 const float* bias, void* y, int act, float slope, double* stats, void* stream);
+/* its data gradient, written straight into the two gradient tensors: dx_a [n][hi][wi][ca] = gradient of the UP-SAMPLED a
+ * (the caller reduces it 2x2 with udaseg_upsample2x_concat_bwd, cb = 0), dx_b [n][hi][wi][ci-ca] = gradient of skip.
+ * ca must be a multiple of 64. */
+int udaseg_conv2d_dgrad_split(const udaseg_conv_desc* d, const float* dy, const float* w_t, float* dx_a, float* dx_b, int ca,
+                              void* stream);
+int udaseg_conv2d_dgrad_split_bf16(const udaseg_conv_desc* d, const void* dy, const void* w_t, void* dx_a, void* dx_b, int ca,
+                                   void* stream);
+/* and its weight gradient, one call per source: the columns (tap, c_off + c), c < src_c, of dw[co][kh*kw][d->ci] from the
+ * source tensor src ([..][src_c] channels; up != 0: at half resolution behind the nearest x2 up-sampling).  accumulate must
+ * be set unless the slice is the whole gradient (src_c == d->ci). */
+int udaseg_conv2d_wgrad_part(const udaseg_conv_desc* d, const float* src, int src_c, int c_off, int up, const float* dy,
+                             float* dw, int accumulate, void* stream);
+int udaseg_conv2d_wgrad_part_bf16(const udaseg_conv_desc* d, const void* src, int src_c, int c_off, int up, const void* dy,
+                                  float* dw, int accumulate, void* stream);
 /* w[co][kh*kw][ci] -> w_t[ci][kh*kw][co] */
 int udaseg_pack_dgrad_weights(const udaseg_conv_desc* d, const float* w, float* w_t, void* stream);
 /* The same for every convolution of a network in one launch: table[i] = {src float-offset into arena, dst float-offset
@@ -146,6 +170,14 @@ int udaseg_upsample2x_concat_fwd(const float* a, const float* skip, float* out, 
 /* da (+)= 2x2 sum of dout[..., :ca]; dskip (+)= dout[..., ca:] */
 int udaseg_upsample2x_concat_bwd(const float* dout, float* da, float* dskip, int n, int h, int w, int ca, int cb,
                                  int accumulate_da, int accumulate_dskip, void* stream);
+
+/* The decoder's alternate up-sampling mode (north_star: "bilinear-upsample + conv"; the reference's traced model uses nearest,
+ * SURVEY F5): out = cat(interpolate(a, scale_factor=2, mode="bilinear", align_corners=False), skip) and its backward in
+ * gather form.  a / skip / out / gradients are fp32 (channels % 4 == 0) or, with bf16 != 0, bf16 (channels % 8 == 0). */
+int udaseg_upsample2x_bilinear_concat_fwd(const void* a, const void* skip, void* out, int n, int h, int w, int ca, int cb,
+                                          int bf16, void* stream);
+int udaseg_upsample2x_bilinear_concat_bwd(const void* dout, void* da, void* dskip, int n, int h, int w, int ca, int cb,
+                                          int accumulate_da, int accumulate_dskip, int bf16, void* stream);
 
 /* ---- per-pixel cross entropy: nn.CrossEntropyLoss() at train.py:208,342 (mean, no weights/ignore) ----
  * logits[p][ldc] with `classes` valid channels; target int64[p]; lse[p] saved for backward;
@@ -238,8 +270,9 @@ int udaseg_prepare_batch_u8(const uint8_t* images, const uint8_t* masks, const i
                             const float* mean255, const float* inv_std255, void* out_images, int cpad, int out_bf16,
                             int64_t* out_masks, int square_checked, void* stream);
 
-/* ---- scratch: one caller-owned device buffer the library may use for split partial results (currently the
- *      small-channel weight gradient, <= 10 MiB).  Without it those calls take the generic atomics path. ---- */
+/* ---- scratch: one caller-owned device buffer PER DEVICE the library may use for split partial results (currently the
+ *      small-channel weight gradient, <= 10 MiB); the call binds it to the device that is current when it is made.
+ *      Without it those calls take the generic atomics path. ---- */
 int udaseg_set_workspace(void* ptr, size_t bytes);
 /* bytes of that buffer udaseg_conv2d_wgrad would use for this convolution (0 = none); the maximum over a network's layers is
  * what the caller should provide (the Python host hands over 16 MiB once per device). */

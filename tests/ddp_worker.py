@@ -1,0 +1,129 @@
+"""Child process of tests/test_gpu_ddp.py: one data-parallel rank driving the REAL network.
+
+Started as a fresh process (never a fork / exec of one that has touched the GPU).  All ranks share device 0 and talk
+through gloo -- the wire is not what is tested here; what is: ``Unet._backward_plan``'s "gradients at offsets >= o are
+final" reports, ``Plan.ready_events``, ``GradAllReducer``'s bucket bookkeeping, ``broadcast_parameters`` and the trainer's
+``finish()`` -> Adam ordering, i.e. everything between the kernels and the collective.
+
+    python tests/ddp_worker.py RANK WORLD PORT OUT.json
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    rank, world, port, out_path = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from oracle.adversarial_ref import synthetic_batch
+    from uda_aerial_semantic_segmentation_research_amd import engine
+    from uda_aerial_semantic_segmentation_research_amd.ddp import GradAllReducer, broadcast_parameters
+    from uda_aerial_semantic_segmentation_research_amd.optim import FusedAdam
+    from uda_aerial_semantic_segmentation_research_amd.train import SegmentationTrainer
+    from uda_aerial_semantic_segmentation_research_amd.unet import Unet
+
+    res = {"rank": rank}
+    torch.manual_seed(1000 + rank)                      # different init per rank: the broadcast has to make them equal
+    net = Unet("resnet18", encoder_weights=None, in_channels=3, classes=23)
+    tr = SegmentationTrainer(net, torch.device("cuda", 0))
+    net.train()
+    net.ensure_arena()
+    broadcast_parameters(net)
+    x, y, _ = synthetic_batch(2, 64, 64, seed=10 + rank)   # each rank its own shard of the global batch
+    x, y = x.cuda(), y.cuda()
+    total = net._arena.numel()
+
+    def gather(t):
+        parts = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(parts, t)
+        return parts
+
+    w0 = gather(net._arena.detach().cpu())
+    res["broadcast_equal"] = all(torch.equal(w0[0], w) for w in w0)
+
+    # (1) single-process gradients, no reducer
+    tr.criterion(net(x), y).backward()
+    torch.cuda.synchronize()
+    g_local = net._grad_arena.detach().cpu().clone()
+    g_mean = torch.stack(gather(g_local)).double().mean(0)
+    net.zero_grad()
+
+    # (2) the same backward with the reducer attached; log which gradient destinations the plan has handed to a kernel
+    # before each "offsets >= o are final" report
+    red = GradAllReducer(net, bucket_bytes=8 << 20, tail_bytes=1 << 20)
+    tr.grad_reducer = red
+    issued, reports, violations = set(), [], []
+    orig_gw, orig_gvec = engine.Plan.gw, engine.Plan.gvec
+
+    def gw(self, conv):
+        issued.add(self.idx[(id(conv), "weight")][0])
+        return orig_gw(self, conv)
+
+    def gvec(self, mod, name):
+        issued.add(self.idx[(id(mod), name)][0])
+        return orig_gvec(self, mod, name)
+    engine.Plan.gw, engine.Plan.gvec = gw, gvec
+    offsets = sorted(e[1] for e in net._entries)
+    hook = net.grad_ready_hook
+
+    def checked_hook(P, o):
+        reports.append(o)
+        missing = [q for q in offsets if q >= o and q not in issued]
+        if missing:
+            violations.append((o, missing[:4]))
+        hook(P, o)
+    net.grad_ready_hook = checked_hook
+    tr.criterion(net(x), y).backward()
+    red.finish()
+    torch.cuda.synchronize()
+    engine.Plan.gw, engine.Plan.gvec = orig_gw, orig_gvec
+    net.grad_ready_hook = hook
+    g_red = net._grad_arena.detach().cpu().double()
+    res["reports_descending"] = all(a >= b for a, b in zip(reports, reports[1:])) and reports[-1] == 0
+    res["violations"] = violations
+    res["n_reports"] = len(reports)
+    ranges = sorted(red.launched)
+    res["n_buckets"] = len(ranges)
+    res["covers_once"] = (ranges[0][0] == 0 and ranges[-1][1] == total
+                          and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:])))
+    res["launched_back_to_front"] = red.launched == sorted(red.launched, key=lambda r: -r[1])
+    res["avg_err"] = float((g_red - g_mean).abs().max() / g_mean.abs().max())
+    res["local_vs_mean"] = float((g_local.double() - g_mean).abs().max() / g_mean.abs().max())   # must be large: ranks differ
+
+    # (3) three optimizer steps through the trainer: weights stay bit-identical across ranks
+    opt = FusedAdam(net.parameters(), lr=1e-3)
+    for _ in range(3):
+        tr.train_step(x, y, opt)
+    torch.cuda.synchronize()
+    ws = gather(net._arena.detach().cpu())
+    res["weights_equal_after_steps"] = all(torch.equal(ws[0], w) for w in ws)
+    res["weights_moved"] = not torch.equal(ws[0], w0[0])
+    bn = gather(net._buf_arena.detach().cpu())
+    res["bn_buffers_local"] = not all(torch.equal(bn[0], b) for b in bn)     # local statistics, as designed
+
+    # (4) a second backward without zero_grad while the reducer is attached must raise, not race
+    try:
+        tr.criterion(net(x), y).backward()
+        red.finish()
+        tr.criterion(net(x), y).backward()
+        res["double_backward_raises"] = False
+    except RuntimeError as e:
+        res["double_backward_raises"] = "GradAllReducer" in str(e)
+    red._pending = []
+    red._plan = None
+    torch.cuda.synchronize()
+    dist.barrier()
+    with open(out_path, "w") as f:
+        json.dump(res, f)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -77,8 +77,8 @@ CONV_CASES = [
     (1, 64, 64, 16, 24, 3, 1, 1),     # head shape through the direct kernel
     (4, 96, 96, 64, 64, 3, 1, 1),     # enough tiles for the unsliced launches: uniform-tap loop + buffer-store epilogues
     (2, 96, 96, 128, 32, 3, 1, 1),    # same through the 128x32 tile
-    (2, 32, 32, 64, 128, 3, 1, 1),    # halo-resident wgrad: two co tiles, image-border rows / columns in every K-tile
-    (3, 32, 64, 192, 64, 3, 1, 1),    # halo-resident wgrad: three ci tiles, non-square, K-tiles crossing image boundaries
+    (2, 32, 32, 64, 128, 3, 1, 1),    # two co tiles, image-border rows / columns in every K-tile
+    (3, 32, 64, 192, 64, 3, 1, 1),    # three ci tiles, non-square, K-tiles crossing image boundaries
 ]
 
 
@@ -123,6 +123,140 @@ def test_conv_fwd_dgrad_wgrad(K, case):
     dw2 = torch.full((co, k, k, ci), 0.5, device="cuda")
     K.conv2d_wgrad(d, xd, dyd, dw2, accumulate=True)
     assert_close(dw2.cpu().permute(0, 3, 1, 2), wr.grad + 0.5, "wgrad+acc")
+
+
+UPCAT_CASES = [
+    # n, h, w (of the HALF-resolution a), ca, cb, co, dtype        stands for
+    (2, 6, 10, 64, 32, 64, "fp32"),      # generic: 64 up-sampled + 32 skip channels, non-square, K-slices (few tiles)
+    (2, 8, 8, 128, 64, 32, "fp32"),      # dec.3.conv1 shape class: Co = 32 -> 128x32 igemm tile, 32x128 wgrad tile
+    (8, 24, 24, 64, 64, 64, "fp32"),     # enough tiles for unsliced launches and the buffer-store epilogues
+    (1, 4, 4, 512, 256, 256, "fp32"),    # dec.0.conv1 channel counts at a tiny extent
+    (2, 20, 12, 32, 0, 16, "fp32"),      # dec.4.conv1: no skip, small-channel direct kernels (halo read through the up-sampling)
+    (1, 9, 7, 16, 0, 16, "fp32"),        # same, one K group, odd half-resolution extents (ragged 16x16 tiles)
+    (2, 8, 8, 64, 0, 64, "fp32"),        # no skip through the implicit-GEMM kernels
+    (2, 8, 12, 64, 64, 64, "bf16"),      # bf16 storage
+    (2, 8, 8, 128, 64, 64, "bf16"),
+]
+
+
+@pytest.mark.parametrize("case", UPCAT_CASES, ids=["n%d_%dx%d_ca%d_cb%d_co%d_%s" % c for c in UPCAT_CASES])
+def test_conv_over_fused_upsample_concat(K, case):
+    """conv(cat([nearest_x2(a), skip])) with the concatenation never written (udaseg_conv2d_fwd_upcat, _dgrad_split,
+    _wgrad_part) against torch, and BIT FOR BIT (forward, data gradients) against the same library on the materialised
+    concatenation: both walk the same K order."""
+    n, h, w, ca, cb, co, dt = case
+    bf = dt == "bf16"
+    tol = 2 ** -7 if bf else RTOL
+    g = torch.Generator().manual_seed(ca * 131 + cb * 7 + co)
+    rnd = (lambda *s: torch.randn(*s, generator=g).bfloat16().float()) if bf else (lambda *s: torch.randn(*s, generator=g))
+    a = rnd(n, ca, h, w).requires_grad_(True)
+    skip = rnd(n, cb, 2 * h, 2 * w).requires_grad_(True) if cb else None
+    ci = ca + cb
+    wt = (rnd(co, ci, 3, 3) / math.sqrt(9 * ci)).requires_grad_(True)
+    if bf:
+        wt = (wt.detach().bfloat16().float()).requires_grad_(True)
+    up = F.interpolate(a, scale_factor=2.0, mode="nearest")
+    cat_ref = torch.cat([up, skip], dim=1) if cb else up
+    y_ref = F.conv2d(cat_ref, wt, None, 1, 1)
+    dy = rnd(*y_ref.shape)
+    y_ref.backward(dy)
+
+    cast = (lambda t: t.bfloat16()) if bf else (lambda t: t)
+    ad, sd = cast(nhwc(a.detach())), (cast(nhwc(skip.detach())) if cb else None)
+    wd, dyd = cast(w_ohwi(wt.detach())), cast(nhwc(dy))
+    d = K.conv_desc(n, 2 * h, 2 * w, ci, co, 3, 1, 1)
+    adt = torch.bfloat16 if bf else torch.float32
+    assert K.upcat_fusable(ca, cb, co, adt)
+    R = K.bn_replicas()
+    # forward + BatchNorm statistics
+    y = torch.full((n, 2 * h, 2 * w, co), float("nan"), device="cuda", dtype=adt)
+    stats = torch.zeros(R * 2 * co, dtype=torch.float64, device="cuda")
+    K.conv2d_fwd_upcat(d, ad, sd, wd, None, y, stats=stats)
+    assert_close(nchw(y.float()), y_ref.detach(), "fused fwd", tol)
+    cat = K.upsample2x_concat_fwd(ad, sd)
+    y_mat = torch.empty_like(y)
+    stats_mat = torch.zeros_like(stats)
+    K.conv2d_fwd_bnstats(d, cat, wd, None, y_mat, stats_mat)
+    assert torch.equal(y, y_mat), "fused forward differs from the forward on the materialised concatenation"
+    s1, s2 = stats.view(R, 2, co).sum(0), stats_mat.view(R, 2, co).sum(0)
+    assert torch.allclose(s1, s2, rtol=1e-9, atol=1e-9)
+    # with bias + activation (the eval-mode folded-BatchNorm form)
+    bias = torch.randn(co, generator=g)
+    y2 = torch.empty_like(y)
+    K.conv2d_fwd_upcat(d, ad, sd, wd, bias.cuda(), y2, act=1, slope=0.0)
+    assert_close(nchw(y2.float()), torch.relu(y_ref.detach() + bias.view(1, -1, 1, 1)), "fused fwd + bias + relu", tol)
+    # data gradient: two outputs
+    wtp = torch.empty((ci, 3, 3, co), device="cuda", dtype=adt)
+    if bf:
+        wtp.copy_(wd.permute(3, 1, 2, 0))
+    else:
+        K.pack_dgrad_weights(d, wd, wtp)
+    d_cat = torch.empty((n, 2 * h, 2 * w, ci), device="cuda", dtype=adt)
+    K.conv2d_dgrad(d, dyd, wtp, d_cat)
+    d_up = torch.full((n, 2 * h, 2 * w, ca), float("nan"), device="cuda", dtype=adt)
+    if cb:
+        d_skip = torch.full((n, 2 * h, 2 * w, cb), float("nan"), device="cuda", dtype=adt)
+        K.conv2d_dgrad_split(d, dyd, wtp, d_up, d_skip)
+        assert torch.equal(d_skip, d_cat[..., ca:]) and torch.equal(d_up, d_cat[..., :ca]), "split dgrad != slices of the plain one"
+        assert_close(nchw(d_skip.float()), skip.grad, "d skip", 4 * tol if bf else tol)
+    else:
+        d_up = d_cat
+    da = torch.empty((n, h, w, ca), device="cuda", dtype=adt)
+    K.upsample2x_concat_bwd(d_up.contiguous(), da, None, ca, 0)
+    assert_close(nchw(da.float()), a.grad, "d a (2x2 sum of the up-sampled gradient)", 4 * tol if bf else tol)
+    # weight gradient: one launch per source, accumulated onto a zeroed gradient
+    dw = torch.zeros((co, 3, 3, ci), device="cuda")
+    K.conv2d_wgrad_part(d, ad, 0, True, dyd, dw, True)
+    if cb:
+        K.conv2d_wgrad_part(d, sd, ca, False, dyd, dw, True)
+    assert_close(dw.cpu().permute(0, 3, 1, 2), wt.grad, "wgrad by source", 4 * tol if bf else tol)
+    dw_mat = torch.zeros_like(dw)
+    K.conv2d_wgrad(d, cat, dyd, dw_mat, accumulate=True)
+    assert relerr(dw.cpu(), dw_mat.cpu()) < 1e-5, "wgrad by source vs wgrad on the materialised concatenation"
+
+
+@pytest.mark.parametrize("n,h,w,ca,cb,dt", [(2, 5, 6, 32, 16, "fp32"), (1, 1, 1, 8, 0, "fp32"), (2, 1, 7, 4, 4, "fp32"),
+                                            (1, 9, 2, 64, 64, "fp32"), (2, 6, 5, 32, 16, "bf16"), (1, 3, 3, 8, 0, "bf16")])
+def test_bilinear_upsample_concat_vs_interpolate(K, n, h, w, ca, cb, dt):
+    """cat(F.interpolate(a, scale_factor=2, mode='bilinear', align_corners=False), skip), forward and backward (SURVEY 8(c)
+    item 5: nearest vs bilinear micro-vectors), including 1-pixel extents where both neighbours clamp onto the same row."""
+    bf = dt == "bf16"
+    g = torch.Generator().manual_seed(h * 100 + w)
+    rnd = (lambda *s: torch.randn(*s, generator=g).bfloat16().float()) if bf else (lambda *s: torch.randn(*s, generator=g))
+    a = rnd(n, ca, h, w).requires_grad_(True)
+    skip = rnd(n, cb, 2 * h, 2 * w).requires_grad_(True) if cb else None
+    up = F.interpolate(a, scale_factor=2.0, mode="bilinear", align_corners=False)
+    ref = torch.cat([up, skip], 1) if cb else up
+    dout = rnd(*ref.shape)
+    ref.backward(dout)
+    cast = (lambda t: t.bfloat16()) if bf else (lambda t: t)
+    tol = 2 ** -7 if bf else 1e-6
+    out = K.upsample2x_bilinear_concat_fwd(cast(nhwc(a.detach())), cast(nhwc(skip.detach())) if cb else None)
+    assert_close(nchw(out.float()), ref.detach(), "bilinear fwd", tol)
+    da = torch.full((n, h, w, ca), float("nan"), device="cuda", dtype=out.dtype)
+    ds = torch.full((n, 2 * h, 2 * w, cb), float("nan"), device="cuda", dtype=out.dtype) if cb else None
+    K.upsample2x_bilinear_concat_bwd(cast(nhwc(dout)), da, ds, ca, cb)
+    assert_close(nchw(da.float()), a.grad, "bilinear bwd", 4 * tol)
+    if cb:
+        assert torch.equal(nchw(ds.float()), skip.grad)
+    # accumulate forms
+    da2 = torch.ones_like(da)
+    K.upsample2x_bilinear_concat_bwd(cast(nhwc(dout)), da2, None, ca, cb, accumulate_da=True)
+    assert_close(nchw(da2.float()), a.grad + 1.0, "bilinear bwd + acc", 8 * tol if bf else 4 * tol)
+
+
+def test_fused_upcat_rejects_what_it_cannot_do(K):
+    d = K.conv_desc(1, 8, 8, 48, 64, 3, 1, 1)
+    a, skip = torch.zeros(1, 4, 4, 24, device="cuda"), torch.zeros(1, 8, 8, 24, device="cuda")
+    w, y = torch.zeros(64, 3, 3, 48, device="cuda"), torch.zeros(1, 8, 8, 64, device="cuda")
+    assert not K.upcat_fusable(24, 24, 64, torch.float32)
+    with pytest.raises(RuntimeError, match="multiples of the K-tile"):
+        K.conv2d_fwd_upcat(d, a, skip, w, None, y)
+    with pytest.raises(RuntimeError, match="up_ca"):
+        K.conv2d_fwd_upcat(d, torch.zeros(1, 4, 4, 48, device="cuda"), skip, w, None, y)      # ca == ci but a skip is given
+    dw = torch.zeros(64, 3, 3, 48, device="cuda")
+    with pytest.raises(RuntimeError, match="accumulated"):
+        K.conv2d_wgrad_part(d, a, 0, True, y, dw, accumulate=False)
 
 
 @pytest.mark.parametrize("case", [(2, 24, 24, 64, 64, 3, 1, 1), (2, 20, 36, 16, 16, 3, 1, 1), (4, 40, 40, 32, 16, 3, 1, 1),

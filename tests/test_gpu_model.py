@@ -12,20 +12,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-RTOL = 1e-3
-
-
-def rel(got, ref):
-    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
-    return ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
-
-
-def check(got, ref, what, rtol=RTOL):
-    assert tuple(got.shape) == tuple(ref.shape), (what, got.shape, ref.shape)
-    assert torch.isfinite(got).all(), f"{what}: non-finite"
-    e = rel(got, ref)
-    assert e <= rtol, f"{what}: rel err {e:.3e} > {rtol:g}"
-    return e
+from _parity import RTOL, check, grads_vs_oracle, pair as _pair, rel  # noqa: F401  (tests/ is on sys.path via conftest)
 
 
 @pytest.fixture(scope="module")
@@ -34,106 +21,6 @@ def pkg():
     _lib.require_gpu()
     import uda_aerial_semantic_segmentation_research_amd as p
     return p
-
-
-def _pair(name, classes=23):
-    from oracle.unet_ref import UnetRef
-    from uda_aerial_semantic_segmentation_research_amd.unet import Unet
-    torch.manual_seed(1234)
-    ref = UnetRef(name, classes=classes).train()
-    net = Unet(encoder_name=name, encoder_weights=None, in_channels=3, classes=classes)
-    net.load_state_dict(ref.state_dict())
-    return ref, net.to("cuda").train()
-
-
-def _f64_twin(ref):
-    import copy
-    r64 = copy.deepcopy(ref).double()
-    return r64
-
-
-def cos(a, b):
-    a, b = a.detach().double().cpu().flatten(), b.detach().double().cpu().flatten()
-    return (a @ b / (a.norm() * b.norm()).clamp_min(1e-300)).item()
-
-
-def _unit_of(name):
-    """Execution-order index of the block a parameter belongs to: stem, encoder blocks, decoder blocks, head."""
-    parts = name.split(".")
-    if parts[0] == "encoder":
-        if parts[1].startswith("layer"):
-            return (1, int(parts[1][5:]), int(parts[2]))
-        return (0, 0, 0)
-    if parts[0] == "decoder":
-        return (2, int(parts[2]), 0)
-    return (3, 0, 0)
-
-
-def _gpu_relu_outputs(net):
-    """(unit, NCHW cpu tensor) of every ReLU output of the last training forward, in execution order."""
-    from uda_aerial_semantic_segmentation_research_amd import unet as U
-    P, tape, (r_stem, f1, pooled, pidx), _, _ = net._last_tape
-    names = {id(m): n for n, m in net.named_modules()}
-    outs = [((0, 0, 0), f1)]
-    for blk, rec, out in tape:
-        unit = _unit_of(names[id(blk)] + ".x")
-        if isinstance(blk, U.BasicBlock):
-            zs = [rec[1], out]
-        elif isinstance(blk, U.Bottleneck):
-            zs = [rec[1], rec[2], out]
-        else:
-            zs = [rec[3], out]
-        outs += [(unit, z) for z in zs]
-    return [(u, z.detach().cpu().permute(0, 3, 1, 2)) for u, z in outs]
-
-
-def grads_vs_oracle(net, ref32, x, loss_fn, label, forward_fn=None, skip_none=False):
-    """Gradient parity at north_star's 1e-3 (norm-wise per tensor) on EVERY parameter tensor.
-
-    The loss is piecewise smooth: each ReLU mask bit is a kink, and two correct fp32 evaluations that disagree on a
-    single bit in block u differ by 1e-2..1e-1 on every gradient of the blocks <= u (fp32 vs fp64 CPU oracle: 2 of
-    913k bits differ for r18 at 2x64x64 and deep gradients move by up to 0.12; in fp64 alone a 1e-7 input
-    perturbation moves them by 6e-3 -- tools/diag_parity.py).  A bit can only disagree where the
-    pre-activation is ~1e-6 from zero, so the oracle is re-run with every ReLU's mask taken from the HIP path's
-    activations (y = t * mask): its forward is unchanged to rounding, and both paths now differentiate the same linear
-    piece.  Returns the number of bits that disagreed."""
-    import oracle.unet_ref as R
-    gpu = _gpu_relu_outputs(net)
-    masks = [(z > 0).to(torch.float32) for _, z in gpu]
-    natural, forced_in = [], []
-    orig = R._relu
-    state = {k: v.clone() for k, v in ref32.state_dict().items()}
-    it = iter(masks)
-
-    def forced(t):
-        m = next(it)
-        natural.append((t.detach() > 0).to(torch.float32))
-        return t * m
-    R._relu = forced
-    try:
-        ref32.zero_grad()
-        out = (forward_fn or ref32)(x)
-        loss_fn(out).backward()
-    finally:
-        R._relu = orig
-        ref32.load_state_dict(state)
-    assert len(natural) == len(masks)
-    nflip = int(sum((a != b).sum() for a, b in zip(natural, masks)))
-    for (unit, zg), a in zip(gpu, natural):
-        assert zg.shape == a.shape
-    g32 = dict(ref32.named_parameters())
-    worst = ("", 0.0)
-    for k, p in net.named_parameters():
-        if skip_none and g32[k].grad is None:
-            assert p.grad is None or p.grad.abs().max().item() == 0.0, k
-            continue
-        assert p.grad is not None, k
-        e = check(p.grad, g32[k].grad, f"{label} grad {k}")
-        if e > worst[1]:
-            worst = (k, e)
-    print(f"{label}: {nflip} of {sum(m.numel() for m in masks)} ReLU mask bits disagreed; worst gradient rel err "
-          f"{worst[1]:.2e} at {worst[0]}")
-    return nflip
 
 
 @pytest.mark.parametrize("name", ["resnet18", "resnet50"])
@@ -160,13 +47,17 @@ def test_unet_train_forward_vs_golden_fixture(pkg, name, golden_dir):
 
 # r50 is checked at 128x128: at 64x64 its layer4 BatchNorm sees 8 values per channel, an ill-conditioned regime in which
 # a change of fp32 summation ORDER alone moves layer4 gradients by ~1e-3
-@pytest.mark.parametrize("name,size", [("resnet18", 64), ("resnet34", 64), ("resnet50", 128)])
-def test_unet_forward_backward_adam_vs_oracle(pkg, name, size):
+# ("resnet18", 256, 4) is BASELINE.json configs[0]: the reference's own CPU-runnable training case (4 x 3 x 256 x 256)
+@pytest.mark.parametrize("name,size,batch", [("resnet18", 64, 2), ("resnet34", 64, 2), ("resnet50", 128, 2),
+                                             ("resnet18", 256, 4)])
+def test_unet_forward_backward_adam_vs_oracle(pkg, name, size, batch):
+    """One train step (reference src/models/train.py:340-344): logits, loss, EVERY gradient, BN running statistics and the
+    Adam update against the CPU oracle."""
     from oracle.adversarial_ref import synthetic_batch
     from uda_aerial_semantic_segmentation_research_amd.losses import CrossEntropyLoss
     from uda_aerial_semantic_segmentation_research_amd.optim import FusedAdam
     ref, net = _pair(name)
-    x, y, _ = synthetic_batch(2, size, size, seed=0)
+    x, y, _ = synthetic_batch(batch, size, size, seed=0)
 
     opt_ref = torch.optim.Adam(ref.parameters(), lr=1e-4)
     opt_ref.zero_grad()
@@ -178,15 +69,14 @@ def test_unet_forward_backward_adam_vs_oracle(pkg, name, size):
     opt.zero_grad()
     net.debug_keep_tape = True
     logits = net(x.cuda())
-    assert logits.shape == (2, 23, size, size)
+    assert logits.shape == (batch, 23, size, size)
     loss = CrossEntropyLoss()(logits, y.cuda())
     assert loss.dim() == 0 and loss.grad_fn is not None
     loss.backward()
 
     check(logits, logits_ref, "logits")
     assert abs(loss.item() - loss_ref.item()) <= 1e-5 * abs(loss_ref.item())
-    gpu_logits_err = check(logits, logits_ref, "logits")
-    grads_vs_oracle(net, ref, x, lambda o: torch.nn.functional.cross_entropy(o, y), name)
+    grads_vs_oracle(net, ref, x, lambda o: torch.nn.functional.cross_entropy(o, y), f"{name} {batch}x{size}x{size}")
     gref = dict(ref.named_parameters())
     # BN running statistics after one training forward
     sd, sdr = net.state_dict(), ref.state_dict()
@@ -209,7 +99,7 @@ def test_unet_forward_backward_adam_vs_oracle(pkg, name, size):
         upd = (p.detach().cpu() - before[k])[sel]
         upd_ref = (gref[k].detach() - before[k])[sel]
         assert (upd - upd_ref).abs().max() <= 0.01 * 1e-4, k
-    assert ("flat", 0) in opt.state, "FusedAdam did not take the flat-arena path"
+    assert opt.flat_launches == 1, "FusedAdam did not take the flat-arena path"
 
 
 def _harness(block):
@@ -312,6 +202,76 @@ def test_decoder_block_plan(pkg, cin, cskip, cout):
     gr = dict(rb.named_parameters())
     for (k, p), g in zip(h.named_parameters(), h.grad_views(P.garena)):
         check(g, gr[k[len("block."):]].grad, f"decoder grad {k}", 1e-3)
+
+
+@pytest.mark.parametrize("name,dtype", [("resnet18", torch.float32), ("resnet50", torch.float32), ("resnet18", torch.bfloat16)])
+def test_fused_decoder_input_equals_materialised(pkg, name, dtype):
+    """The decoder's cat([nearest_x2(x), skip]) gathered inside conv1 (default) against the same network with the
+    concatenation written by the stand-alone kernel: logits bit for bit (train and eval mode), gradients to atomics noise."""
+    from oracle.adversarial_ref import synthetic_batch
+    from uda_aerial_semantic_segmentation_research_amd import unet as U
+    from uda_aerial_semantic_segmentation_research_amd.losses import CrossEntropyLoss
+    _, net = _pair(name, compute_dtype=dtype)
+    x, y, _ = synthetic_batch(2, 64, 64, seed=4)
+    xd, yd = x.cuda(), y.cuda()
+    out = {}
+    assert U.FUSE_UPCAT
+    try:
+        for fused in (False, True):
+            U.FUSE_UPCAT = fused
+            net.zero_grad()
+            net.train()
+            state = {k: v.clone() for k, v in net.state_dict().items()}
+            net.debug_keep_tape = True
+            logits = net(xd)
+            kinds = [type(rec[2]).__name__ for blk, rec, _ in net._last_tape[1] if isinstance(blk, U.DecoderBlock)]
+            CrossEntropyLoss()(logits, yd).backward()
+            g = net._grad_arena.clone()
+            net.load_state_dict(state)
+            net.eval()
+            with torch.no_grad():
+                ev = net(xd)
+            out[fused] = (logits.detach().clone(), g, ev.clone(), kinds)
+    finally:
+        U.FUSE_UPCAT = True
+    assert out[False][3] == ["Tensor"] * 5
+    assert out[True][3].count("UpCat") >= (4 if dtype == torch.bfloat16 else 5), out[True][3]
+    assert torch.equal(out[True][0], out[False][0]), "train-mode logits differ"
+    assert torch.equal(out[True][2], out[False][2]), "eval-mode logits differ"
+    e = ((out[True][1] - out[False][1]).abs().max() / out[False][1].abs().max()).item()
+    assert e <= 1e-5, f"gradient arenas differ by {e:.3e}"
+
+
+def test_unet_bilinear_decoder_vs_oracle(pkg):
+    """Unet(..., upsample="bilinear") -- the up-sampling mode north_star names (the reference's traced model uses nearest,
+    SURVEY F5) -- against the oracle's bilinear mode: logits, loss, every gradient, eval mode."""
+    from oracle.adversarial_ref import synthetic_batch
+    from uda_aerial_semantic_segmentation_research_amd.losses import CrossEntropyLoss
+    from uda_aerial_semantic_segmentation_research_amd.unet import Unet
+    ref, net = _pair("resnet18", upsample="bilinear")
+    assert net.upsample == "bilinear" and all(b.upsample == "bilinear" for b in net.decoder.blocks)
+    assert Unet("resnet18", classes=23, decoder_interpolation="bilinear").upsample == "bilinear"     # newer smp's keyword
+    with pytest.raises(ValueError):
+        Unet("resnet18", classes=23, upsample="bicubic")
+    x, y, _ = synthetic_batch(2, 64, 96, seed=2)
+    net.debug_keep_tape = True
+    logits = net(x.cuda())
+    loss = CrossEntropyLoss()(logits, y.cuda())
+    loss.backward()
+    state = {k: v.clone() for k, v in ref.state_dict().items()}
+    logits_ref = ref(x)
+    ref.load_state_dict(state)
+    check(logits, logits_ref, "bilinear logits")
+    assert abs(loss.item() - torch.nn.functional.cross_entropy(logits_ref, y).item()) <= 1e-5 * abs(loss.item())
+    grads_vs_oracle(net, ref, x, lambda o: torch.nn.functional.cross_entropy(o, y), "bilinear decoder")
+    # and it is not the nearest network in disguise
+    _, nearest = _pair("resnet18")
+    with torch.no_grad():
+        assert rel(nearest(x.cuda()), logits_ref) > 1e-2
+    ref.load_state_dict({k: v.cpu() for k, v in net.state_dict().items()})     # same BatchNorm running statistics
+    net.eval(), ref.eval()
+    with torch.no_grad():
+        check(net(x.cuda()), ref(x), "bilinear eval logits")
 
 
 def test_unet_eval_mode_and_state_dict_roundtrip(pkg):

@@ -110,9 +110,13 @@ def test_adversarial_training_suite(pkg):
 
 
 def test_full_size_step_properties(pkg):
-    """BASELINE cfg 2 size (8 x 3 x 512 x 512, r18): forward against the CPU oracle (one forward is seconds), and
-    size-independent properties of the step: per-pixel gradient rows of the CE sum to zero, gradients are linear in the
-    upstream gradient, BN output statistics are (beta, gamma^2), a repeated step is bitwise reproducible in its forward."""
+    """BASELINE cfg 2 size (8 x 3 x 512 x 512, r18).  Against the CPU oracle at FULL size: logits, loss, every ReLU output,
+    EVERY parameter gradient (teacher-forced masks, with the overridden bits counted and bounded) and the head / last
+    decoder block gradients against the oracle's natural backward (tests/_parity.py::grads_vs_oracle).  Then the
+    size-independent properties: a repeated step is bitwise reproducible in its forward and reproducible to the fp32
+    atomics' ordering noise in its gradients, gradients are linear in the upstream gradient, per-pixel gradient rows of
+    the CE sum to zero, BN output statistics are (beta, gamma^2)."""
+    from _parity import grads_vs_oracle
     from oracle.adversarial_ref import synthetic_batch
     from oracle.unet_ref import UnetRef
     from uda_aerial_semantic_segmentation_research_amd.losses import CrossEntropyLoss
@@ -125,10 +129,13 @@ def test_full_size_step_properties(pkg):
     x, y, _ = synthetic_batch(8, 512, 512, seed=0)
     xd, yd = x.cuda(), y.cuda()
     torch.set_num_threads(min(16, os.cpu_count() or 1))
+    state = {k: v.clone() for k, v in ref.state_dict().items()}
     with torch.no_grad():
         logits_ref = ref(x)
         loss_ref = torch.nn.functional.cross_entropy(logits_ref, y)
+    ref.load_state_dict(state)
     crit = CrossEntropyLoss()
+    net.debug_keep_tape = True
     logits = net(xd)
     loss = crit(logits, yd)
     err = (logits.detach().cpu() - logits_ref).abs().max() / logits_ref.abs().max()
@@ -137,14 +144,23 @@ def test_full_size_step_properties(pkg):
     loss.backward()
     g1 = net._grad_arena.clone()
     assert torch.isfinite(g1).all()
-    # CE: every pixel's gradient row sums to zero; linear in the upstream gradient
+    grads_vs_oracle(net, ref, x, lambda o: torch.nn.functional.cross_entropy(o, y), "cfg2 r18 8x512x512")
+    net.debug_keep_tape = False
+    net._last_tape = None
+    # the same step again: forward bitwise reproducible; gradients differ by the order of the split-K fp32 atomics only
     net.zero_grad()
     logits2 = net(xd)
-    assert torch.equal(logits2.detach(), logits.detach())               # forward is bitwise reproducible
-    (3.0 * crit(logits2, yd)).backward()
+    assert torch.equal(logits2.detach(), logits.detach())
+    crit(logits2, yd).backward()
+    spread = ((net._grad_arena - g1).abs().max() / g1.abs().max()).item()
+    # linear in the upstream gradient (x3 is not a power of two: every product re-rounds)
+    net.zero_grad()
+    (3.0 * crit(net(xd), yd)).backward()
     g3 = net._grad_arena
-    rel = (g3 - 3.0 * g1).abs().max() / g1.abs().max()
-    assert rel < 2e-3, f"gradient linearity {rel:.3e}"                   # split-K / atomics order only
+    rel = ((g3 - 3.0 * g1).abs().max() / g1.abs().max()).item()
+    print(f"cfg2 gradients: run-to-run spread {spread:.3e} (fp32 atomics order), linearity under x3 {rel:.3e}")
+    assert spread < 2e-6, f"run-to-run gradient spread {spread:.3e}"      # observed 1.4e-7
+    assert rel < 2e-5, f"gradient linearity {rel:.3e}"                    # observed 2.3e-6 (round 1 allowed 2e-3)
     lg = logits.detach().requires_grad_(True)
     crit(lg, yd).backward()
     assert lg.grad.sum(dim=1).abs().max().item() < 1e-9

@@ -6,7 +6,7 @@ import copy
 import pytest
 import torch
 
-from test_gpu_model import check, cos, grads_vs_oracle, rel
+from _parity import check, cos, grads_vs_oracle, rel
 
 pytestmark = pytest.mark.gpu
 

@@ -66,4 +66,11 @@ def test_bench_constants_match_survey():
     from oracle.unet_ref import UnetRef, conv_flops_fwd
     fwd = conv_flops_fwd(UnetRef("resnet18", classes=23), 1, 512, 512)
     assert abs(fwd / 1e9 - 44.85) < 0.05
-    assert abs(bench.R18_CONV_GFLOP_PER_IMAGE - 133.30) < 1e-9
+    assert abs(bench.CONV_GFLOP_PER_IMAGE[("segmentation", "resnet18", 512)] - 133.30) < 1e-9
+    # fwd + dgrad + wgrad = 3 x fwd minus the stem's data gradient (the image needs none): SURVEY B.4
+    stem = 2 * 64 * 256 * 256 * 3 * 49 / 1e9
+    assert abs(3 * fwd / 1e9 - stem - 133.30) < 0.05
+    # the adversarial iteration adds three discriminator passes (fwd + bwd, no dgrad for D's first conv) over 8 + 8 images
+    assert abs(bench.CONV_GFLOP_PER_IMAGE[("adversarial", "resnet18", 512)] - 251.68) < 1e-9
+    # percentile helper used for the per-step HIP-event report
+    assert bench.percentile([5.0, 1.0, 3.0], 0.5) == 3.0 and bench.percentile([1.0], 0.9) == 1.0

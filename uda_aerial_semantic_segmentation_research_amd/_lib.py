@@ -37,6 +37,12 @@ SIGNATURES = {
     "udaseg_conv2d_wgrad_bf16": (_I, [_D, _P, _P, _P, _I, _P]),
     "udaseg_conv2d_dgrad": (_I, [_D, _P, _P, _P, _I, _P]),
     "udaseg_conv2d_wgrad": (_I, [_D, _P, _P, _P, _I, _P]),
+    "udaseg_conv2d_fwd_upcat": (_I, [_D, _P, _P, _I, _P, _P, _P, _I, _F, _P, _P]),
+    "udaseg_conv2d_fwd_upcat_bf16": (_I, [_D, _P, _P, _I, _P, _P, _P, _I, _F, _P, _P]),
+    "udaseg_conv2d_dgrad_split": (_I, [_D, _P, _P, _P, _P, _I, _P]),
+    "udaseg_conv2d_dgrad_split_bf16": (_I, [_D, _P, _P, _P, _P, _I, _P]),
+    "udaseg_conv2d_wgrad_part": (_I, [_D, _P, _I, _I, _I, _P, _P, _I, _P]),
+    "udaseg_conv2d_wgrad_part_bf16": (_I, [_D, _P, _I, _I, _I, _P, _P, _I, _P]),
     "udaseg_pack_dgrad_weights": (_I, [_D, _P, _P, _P]),
     "udaseg_pack_dgrad_batched": (_I, [_P, _P, _P, _I, _P]),
     "udaseg_conv_flops": (C.c_double, [_D]),
@@ -54,6 +60,8 @@ SIGNATURES = {
     "udaseg_maxpool3x3s2_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "udaseg_upsample2x_concat_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "udaseg_upsample2x_concat_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "udaseg_upsample2x_bilinear_concat_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "udaseg_upsample2x_bilinear_concat_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "udaseg_ce_partials": (_I, []),
     "udaseg_ce_fwd": (_I, [_P, _P, _L, _I, _I, _P, _P, _P, _P]),
     "udaseg_ce_bwd": (_I, [_P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _P]),

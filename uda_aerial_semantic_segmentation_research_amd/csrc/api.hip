@@ -35,17 +35,18 @@ struct KRec {
 // exactly the symbols rocprofv3 prints (minus "void udaseg::" and the parameter list), so HIP-event and rocprof averages
 // can be compared per kernel
 static const char* const g_knames[PROF_NKERNELS] = {
-    "conv_igemm_kernel<128, 128, 2, 2, false, false>", "conv_igemm_kernel<128, 64, 2, 2, false, false>",
-    "conv_igemm_kernel<64, 64, 2, 2, false, false>",   "conv_igemm_kernel<128, 32, 4, 1, false, false>",
-    "conv3x3_small_kernel<1, 1>",                      "conv3x3_small_kernel<2, 1>",
-    "conv3x3_small_kernel<1, 2>",                      "conv_wgrad_kernel<64, 64, 2, 2, false>",
-    "conv_wgrad_kernel<32, 128, 1, 4, false>",         "conv3x3_small_wgrad_kernel<1, 1>",
-    "conv3x3_small_wgrad_kernel<2, 1>",                "conv3x3_small_wgrad_kernel<1, 2>",
-    "conv_igemm_kernel<*, bf16>",                      "conv_wgrad_bf16_kernel",
-    "conv_igemm_kernel<128, 128, 2, 2, false, true>",  "conv_igemm_kernel<128, 64, 2, 2, false, true>",
-    "conv_igemm_kernel<64, 64, 2, 2, false, true>",    "conv_igemm_kernel<128, 32, 4, 1, false, true>",
-    "conv_wgrad_kernel<64, 64, 2, 2, true>",           "conv_wgrad_kernel<32, 128, 1, 4, true>",
-    "reserved20", "reserved21", "reserved22", "reserved23"};
+    "conv_igemm_kernel<128, 128, 2, 2, false, false, false>", "conv_igemm_kernel<128, 64, 2, 2, false, false, false>",
+    "conv_igemm_kernel<64, 64, 2, 2, false, false, false>",   "conv_igemm_kernel<128, 32, 4, 1, false, false, false>",
+    "conv3x3_small_kernel<1, 1>",                             "conv3x3_small_kernel<2, 1>",
+    "conv3x3_small_kernel<1, 2>",                             "conv_wgrad_kernel<64, 64, 2, 2, false>",
+    "conv_wgrad_kernel<32, 128, 1, 4, false>",                "conv3x3_small_wgrad_kernel<1, 1>",
+    "conv3x3_small_wgrad_kernel<2, 1>",                       "conv3x3_small_wgrad_kernel<1, 2>",
+    "conv_igemm_kernel<*, bf16>",                             "conv_wgrad_bf16_kernel",
+    "conv_igemm_kernel<128, 128, 2, 2, false, true, false>",  "conv_igemm_kernel<128, 64, 2, 2, false, true, false>",
+    "conv_igemm_kernel<64, 64, 2, 2, false, true, false>",    "conv_igemm_kernel<128, 32, 4, 1, false, true, false>",
+    "conv_wgrad_kernel<64, 64, 2, 2, true>",                  "conv_wgrad_kernel<32, 128, 1, 4, true>",
+    "conv_igemm_kernel<128, 128, 2, 2, false, true, true>",   "conv_igemm_kernel<128, 64, 2, 2, false, true, true>",
+    "conv_igemm_kernel<64, 64, 2, 2, false, true, true>",     "conv_igemm_kernel<128, 32, 4, 1, false, true, true>"};
 static std::vector<KRec> g_krecs[PROF_NKERNELS];
 static std::vector<ProfRec> g_recs[2];
 static std::vector<hipEvent_t> g_pool;

@@ -101,11 +101,13 @@ static inline StreamShape stream_shape(int64_t n4, int c4, int max_blocks = 2048
 
 // small-channel direct 3x3 kernels (conv_small.hip)
 bool small_conv_applicable(int k, int stride, int pad, int ci_gather, int co_out);
+// up != 0: x is the half-resolution tensor [n][h/2][wd/2][ci], read through nearest x2 up-sampling (pixel (y >> 1, x >> 1))
 int launch_small_conv(const float* x, const float* w, const float* bias, float* y, int n, int h, int wd, int ci, int co,
-                      int flip, int accumulate, int act, float slope, double* stats, const float* residual, hipStream_t s);
+                      int flip, int accumulate, int act, float slope, double* stats, const float* residual, hipStream_t s,
+                      int up = 0);
 bool small_wgrad_applicable(int k, int stride, int pad, int ci, int co, int ntiles);
 int launch_small_wgrad(const float* x, const float* dy, float* dw, int n, int h, int wd, int ci, int co, int accumulate,
-                       hipStream_t s);
+                       hipStream_t s, int up = 0);
 
 // live launch timing (bench.py roofline leg): per API call (prof_*) and per kernel launch (kprof_*)
 constexpr int PROF_NKERNELS = 24;

@@ -59,6 +59,16 @@ struct IgemmArgs {
   unsigned x_bytes, w_bytes;   // operand sizes for the buffer descriptors (range-checked loads: out of range reads 0)
   int tap_xoff[32];            // ((dy*wi + dx) * ci) * element_size
   int tap_woff[32];            // wt * ci * element_size
+  // fused nearest-x2-upsample + concat input (decoder blocks of smp.Unet: cat([up(a), skip], 1) is never materialised):
+  // the gathered tensor is VIRTUAL, channels [0, up_ca) come from x = a [n][hi/2][wi/2][up_ca] read at (iy >> 1, ix >> 1),
+  // channels [up_ca, ci) from x2 = skip [n][hi][wi][ci - up_ca].  Uniform-tap loop only (up_ca, ci multiples of the K-tile).
+  const void* x2;
+  int up_ca;
+  unsigned x2_bytes;
+  // split output (data gradient of such a convolution): output channels [0, split_n) go to y with row length split_n,
+  // channels [split_n, co) to y2 with row length co - split_n.  split_n is a multiple of every tile width, or 0.
+  void* y2;
+  int split_n;
 };
 
 __device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};   // what a masked-out gather lane reads
@@ -82,8 +92,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // tap of a K-step is a scalar, the per-row validity of every tap is a bit mask built once per tile, addresses are 32-bit
 // offsets into range-checked buffer loads (a masked-out lane gets bit 31 set and reads zeros): 3 VALU per A row-load,
 // 1 per B row-load.
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool BF, bool UNI>
+// UP = true (with UNI): the fused upsample + concat gather described at IgemmArgs::x2.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool BF, bool UNI, bool UP>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
+  static_assert(UNI || !UP, "the fused gather lives in the uniform-tap loop");
   constexpr int ES = BF ? 2 : 4;        // element bytes
   constexpr int EPV = 16 / ES;          // elements per 16-byte vector
   constexpr int BKE = BK * 4 / ES;      // K elements per tile
@@ -157,6 +169,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
 
   // uniform path: byte offset of (row's pixel, this thread's 16-byte K column) and the row's per-tap "invalid" bits
   unsigned u_aoff[A_PASS], u_ainv[A_PASS], u_boff[B_PASS];
+  unsigned u_acur[A_PASS];   // gather offset of each row for the tap (and source) the loop is in: recomputed when the tap changes
   if constexpr (UNI) {
 #pragma unroll
     for (int p = 0; p < A_PASS; ++p) {
@@ -175,6 +188,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
       u_aoff[p] = inv == 0xffffffffu
                       ? 0u
                       : ((unsigned)(a_base[p] + a_iy[p] * a.wi + a_ix[p]) * (unsigned)a.ci + (unsigned)(kq * EPV)) * (unsigned)ES;
+      u_acur[p] = 0x80000000u;
+      if constexpr (UP) {
+        if (inv == 0xffffffffu) a_base[p] = a_iy[p] = a_ix[p] = 0;   // keeps the recomputed offsets of dead rows small
+      }
     }
 #pragma unroll
     for (int p = 0; p < B_PASS; ++p)
@@ -207,31 +224,60 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
 
   __syncthreads();  // tap table visible
 
-  __amdgpu_buffer_rsrc_t rsrc_x, rsrc_w;
+  __amdgpu_buffer_rsrc_t rsrc_x, rsrc_w, rsrc_x2;
   if constexpr (UNI) {
     rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (int)a.x_bytes, 0x00020000);
     rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, (int)a.w_bytes, 0x00020000);
+    if constexpr (UP) rsrc_x2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x2), 0, (int)a.x2_bytes, 0x00020000);
   }
   int u_tl = 0, u_c0 = 0;                     // uniform path: local tap / byte offset inside the tap of the NEXT tile to load
   const int u_cend = a.ci * ES;
+  const int u_ca = UP ? a.up_ca * ES : 0;     // bytes of a virtual pixel that come from the up-sampled source
   auto load_tile = [&](int kt, f32x4* ra, f32x4* rb) {
     if constexpr (UNI) {
-      // tiles are requested in order 0, 1, 2, ...: scalar bookkeeping instead of a division per K-step
+      // tiles are requested in order 0, 1, 2, ...: scalar bookkeeping instead of a division per K-step.  A row's gather
+      // offset only changes with the tap (and, fused input, with the source): it is recomputed then (a uniform branch) and
+      // the position inside the tap travels in the load's SCALAR offset -- no vector ALU work per K-step at all.
       const int tl = u_tl, c0 = u_c0;
       u_c0 += BKE * ES;
       if (u_c0 == u_cend) {
         u_c0 = 0;
         ++u_tl;
       }
-      const unsigned s_x = (unsigned)(a.tap_xoff[toff + tl] + c0), s_w = (unsigned)(a.tap_woff[toff + tl] + c0);
+      if constexpr (UP) {
+        if (c0 == 0) {                        // new tap, channels [0, up_ca): nearest-x2 source, pixel (iy >> 1, ix >> 1)
+          const int dyt = a.dy[toff + tl], dxt = a.dx[toff + tl], w2 = a.wi >> 1;
 #pragma unroll
-      for (int p = 0; p < A_PASS; ++p) {
-        const unsigned voff = (u_aoff[p] + s_x) + ((u_ainv[p] >> tl) << 31);
-        ra[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)voff, 0, 0));
+          for (int p = 0; p < A_PASS; ++p) {
+            const int pix = (a_base[p] >> 2) + ((a_iy[p] + dyt) >> 1) * w2 + ((a_ix[p] + dxt) >> 1);
+            u_acur[p] = ((unsigned)pix * (unsigned)u_ca + (unsigned)(kq * 16)) | ((u_ainv[p] >> tl) << 31);
+          }
+        } else if (c0 == u_ca) {              // same tap, channels [up_ca, ci): the skip tensor at full resolution
+          const int dyt = a.dy[toff + tl], dxt = a.dx[toff + tl];
+#pragma unroll
+          for (int p = 0; p < A_PASS; ++p) {
+            const int pix = a_base[p] + (a_iy[p] + dyt) * a.wi + (a_ix[p] + dxt);
+            u_acur[p] = ((unsigned)pix * (unsigned)(u_cend - u_ca) + (unsigned)(kq * 16)) | ((u_ainv[p] >> tl) << 31);
+          }
+        }
+      } else {
+        if (c0 == 0) {
+          const unsigned s_x = (unsigned)a.tap_xoff[toff + tl];
+#pragma unroll
+          for (int p = 0; p < A_PASS; ++p) u_acur[p] = (u_aoff[p] + s_x) + ((u_ainv[p] >> tl) << 31);
+        }
       }
+      const bool second = UP && c0 >= u_ca;
+      const int s_a = second ? c0 - u_ca : c0;
+      __amdgpu_buffer_rsrc_t rs = rsrc_x;
+      if constexpr (UP) rs = second ? rsrc_x2 : rsrc_x;      // scalar select of the descriptor
+#pragma unroll
+      for (int p = 0; p < A_PASS; ++p)
+        ra[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)u_acur[p], s_a, 0));
+      const int s_w = a.tap_woff[toff + tl] + c0;
 #pragma unroll
       for (int p = 0; p < B_PASS; ++p)
-        rb[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (int)(u_boff[p] + s_w), 0, 0));
+        rb[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (int)u_boff[p], s_w, 0));
       return;
     }
     const int kk = kt * BKE + kq * EPV;
@@ -338,6 +384,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
 
   // ---- epilogue: D[i][j] reg v of lane (lr, lh) = C[row = (v&3) + 8*(v>>2) + 4*lh][col = lr]
   const int ccy = a.cy[cls], ccx = a.cx[cls];
+  // split output: this block's channel tile lies entirely on one side of split_n (block-uniform)
+  void* yb = a.y;
+  int yld = a.co, nsub = 0;
+  if (a.split_n > 0) {
+    if (n0 >= a.split_n) {
+      yb = a.y2;
+      yld = a.co - a.split_n;
+      nsub = a.split_n;
+    } else {
+      yld = a.split_n;
+    }
+  }
   float ssum[TN], ssq[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) ssum[j] = ssq[j] = 0.f;
@@ -350,14 +408,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
                (long long)cM * a.co * 4 < (1LL << 31);
   }
   if (fast_epi) {
-    __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, cM * a.co * 4, 0x00020000);
-    const int row_bytes = a.co * 4;
+    __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(yb, 0, cM * yld * 4, 0x00020000);
+    const int row_bytes = yld * 4;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn + j * 32 + lr;
-        const int voff = ((m0 + wm + i * 32 + 4 * lh) * a.co + n) * 4;
+        const int voff = ((m0 + wm + i * 32 + 4 * lh) * yld + (n - nsub)) * 4;
         // three uniform variants so that the common launches carry no dead per-element work:
         // dgrad / plain conv (store only), conv feeding BatchNorm (statistics), and the general one (bias, activation)
         if (a.bias == nullptr && a.act == UDASEG_ACT_NONE && a.stats == nullptr) {
@@ -410,9 +468,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
       for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn + j * 32 + lr;
         if (n < a.co) {
-          const size_t o = pix * (size_t)a.co + n;
+          const size_t o = pix * (size_t)yld + (size_t)(n - nsub);
           if constexpr (!BF) {
-            float* dst = static_cast<float*>(a.y) + o;
+            float* dst = static_cast<float*>(yb) + o;
             if (a.atomic_out) {
               atomicAdd(dst, acc[i][j][v]);
             } else {
@@ -433,11 +491,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
             if (a.residual) val += (float)static_cast<const __bf16*>(a.residual)[o];
             val = act_apply(val, a.act, a.slope);
             if (a.out_f32) {
-              float* dst = static_cast<float*>(a.y) + o;
+              float* dst = static_cast<float*>(yb) + o;
               if (a.accumulate) val += *dst;
               *dst = val;
             } else {
-              __bf16* dst = static_cast<__bf16*>(a.y) + o;
+              __bf16* dst = static_cast<__bf16*>(yb) + o;
               if (a.accumulate) val += (float)*dst;
               *dst = (__bf16)val;
             }
@@ -478,11 +536,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
 
 // ------------------------------------------------------------------------------------------------- host side
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool BF, bool UNI>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool BF, bool UNI, bool UP>
 static int launch_cfg_t(const IgemmArgs& a, hipStream_t s) {
   static bool attr_done = false;
   constexpr int lds = igemm_lds_bytes<BM, BN>();
-  auto kern = conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, BF, UNI>;
+  auto kern = conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, BF, UNI, UP>;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv_igemm)");
@@ -498,9 +556,13 @@ static int launch_cfg_t(const IgemmArgs& a, hipStream_t s) {
   }
   for (int c = a.nclass; c < NCLS; ++c) b.tile_begin[c + 1] = b.tile_begin[a.nclass];
   if (b.tile_begin[a.nclass] == 0) return UDASEG_OK;
+  if (a.split_n > 0 && a.split_n % BN != 0) {
+    set_error("conv_igemm: split output at channel %d is not a multiple of the %d-wide tile", a.split_n, BN);
+    return UDASEG_E_UNSUPPORTED;
+  }
   dim3 grid((unsigned)b.tile_begin[a.nclass]), block(256);
   constexpr int tile_id = (BM == 128 && BN == 128) ? 0 : (BM == 128 && BN == 64) ? 1 : (BM == 64) ? 2 : 3;
-  constexpr int kid = BF ? 12 : (UNI ? 14 + tile_id : tile_id);
+  constexpr int kid = BF ? 12 : (UP ? 20 + tile_id : (UNI ? 14 + tile_id : tile_id));
   hipEvent_t ev = kprof_begin(s);
   hipLaunchKernelGGL(kern, grid, block, lds, s, b);
   kprof_end(kid, ev, s, flops);
@@ -510,12 +572,20 @@ static int launch_cfg_t(const IgemmArgs& a, hipStream_t s) {
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 static int launch_cfg(const IgemmArgs& a, hipStream_t s) {
-  if (a.uniform) {
-    if (a.bf16) return launch_cfg_t<BM, BN, WAVES_M, WAVES_N, true, true>(a, s);
-    return launch_cfg_t<BM, BN, WAVES_M, WAVES_N, false, true>(a, s);
+  if (a.up_ca > 0) {
+    if (!a.uniform) {
+      set_error("conv_igemm: the fused upsample+concat input needs channel counts that are multiples of the K-tile");
+      return UDASEG_E_UNSUPPORTED;
+    }
+    if (a.bf16) return launch_cfg_t<BM, BN, WAVES_M, WAVES_N, true, true, true>(a, s);
+    return launch_cfg_t<BM, BN, WAVES_M, WAVES_N, false, true, true>(a, s);
   }
-  if (a.bf16) return launch_cfg_t<BM, BN, WAVES_M, WAVES_N, true, false>(a, s);
-  return launch_cfg_t<BM, BN, WAVES_M, WAVES_N, false, false>(a, s);
+  if (a.uniform) {
+    if (a.bf16) return launch_cfg_t<BM, BN, WAVES_M, WAVES_N, true, true, false>(a, s);
+    return launch_cfg_t<BM, BN, WAVES_M, WAVES_N, false, true, false>(a, s);
+  }
+  if (a.bf16) return launch_cfg_t<BM, BN, WAVES_M, WAVES_N, true, false, false>(a, s);
+  return launch_cfg_t<BM, BN, WAVES_M, WAVES_N, false, false, false>(a, s);
 }
 
 static int uniform_off() {
@@ -535,7 +605,9 @@ static void finish_args(IgemmArgs& a, long long x_elems, long long w_elems) {
   for (int c = 0; c < a.nclass; ++c) total = a.tap_off[c] + a.ntaps[c] > total ? a.tap_off[c] + a.ntaps[c] : total;
   a.uniform = 0;
   a.x_bytes = a.w_bytes = 0;
-  if (uniform_off() || a.ci % bke != 0 || total > 32 || x_elems * es > (1LL << 30) || w_elems * es > (1LL << 30)) return;
+  if ((uniform_off() && a.up_ca == 0) || a.ci % bke != 0 || a.up_ca % bke != 0 || total > 32 || x_elems * es > (1LL << 30) ||
+      w_elems * es > (1LL << 30))
+    return;
   for (int c = 0; c < a.nclass; ++c)
     if (a.ntaps[c] > 32 || a.K[c] != a.ntaps[c] * a.ci) return;
   for (int t = 0; t < total; ++t) {
@@ -624,19 +696,33 @@ extern "C" double udaseg_conv_flops(const udaseg_conv_desc* d) {
   return 2.0 * (double)d->n * d->ho * d->wo * (double)d->co * (double)d->ci * d->kh * d->kw;
 }
 
+// skip / up_ca: the fused nearest-x2-upsample + concat input (IgemmArgs::x2): x is then the HALF-resolution tensor
+// [n][hi/2][wi/2][up_ca], skip the full-resolution [n][hi][wi][ci - up_ca] (NULL when ci == up_ca), d describes the conv on
+// the virtual concatenation.
 static int conv2d_fwd_impl(const udaseg_conv_desc* d, const void* x, const void* w, const float* bias, void* y,
                            int act, float slope, int accumulate, double* stats, const void* residual, void* stream,
-                           int bf16 = 0, int out_f32 = 0) {
+                           int bf16 = 0, int out_f32 = 0, const void* skip = nullptr, int up_ca = 0) {
   int rc = check_desc(d);
   if (rc) return rc;
   UDASEG_CHECK_ARG(x && w && y, "conv2d_fwd: NULL pointer");
   UDASEG_CHECK_ARG(!bf16 || (d->ci % 8 == 0 && d->co % 8 == 0), "conv2d_fwd(bf16): channels must be multiples of 8 (ci=%d co=%d)",
                    d->ci, d->co);
+  if (up_ca > 0) {
+    UDASEG_CHECK_ARG(d->stride == 1 && d->hi % 2 == 0 && d->wi % 2 == 0, "conv2d_fwd_upcat: stride 1 and even extents only");
+    UDASEG_CHECK_ARG(up_ca <= d->ci && (up_ca == d->ci) == (skip == nullptr),
+                     "conv2d_fwd_upcat: up_ca=%d of ci=%d channels, skip %s", up_ca, d->ci, skip ? "given" : "NULL");
+    UDASEG_CHECK_ARG(!accumulate && residual == nullptr, "conv2d_fwd_upcat: accumulate / residual are not supported");
+  }
   hipStream_t st = as_stream(stream);
   if (!bf16 && d->kh == d->kw && small_conv_applicable(d->kh, d->stride, d->pad, d->ci, d->co)) {
+    if (up_ca > 0 && skip != nullptr) {
+      set_error("conv2d_fwd_upcat: the small-channel kernel has no skip input (ci=%d)", d->ci);
+      return UDASEG_E_UNSUPPORTED;
+    }
     prof_begin(0, st);
     rc = launch_small_conv(static_cast<const float*>(x), static_cast<const float*>(w), bias, static_cast<float*>(y), d->n,
-                           d->hi, d->wi, d->ci, d->co, 0, accumulate, act, slope, stats, static_cast<const float*>(residual), st);
+                           d->hi, d->wi, d->ci, d->co, 0, accumulate, act, slope, stats, static_cast<const float*>(residual), st,
+                           up_ca > 0 ? 1 : 0);
     prof_end(0, st, udaseg_conv_flops(d), 0, d);
     return rc;
   }
@@ -655,6 +741,9 @@ static int conv2d_fwd_impl(const udaseg_conv_desc* d, const void* x, const void*
   a.residual = residual;
   a.bf16 = bf16;
   a.out_f32 = out_f32;
+  a.x2 = skip;
+  a.up_ca = up_ca;
+  a.x2_bytes = (unsigned)((long long)d->n * d->hi * d->wi * (d->ci - up_ca) * (bf16 ? 2 : 4));
   const int ns = k_slices(M, d->co, ntaps, !bf16 && bias == nullptr && act == UDASEG_ACT_NONE && residual == nullptr);
   a.stats = (ns == 1) ? stats : nullptr;  // squares of partial sums do not add up: sliced launches take the separate pass
   a.nclass = ns;
@@ -672,7 +761,13 @@ static int conv2d_fwd_impl(const udaseg_conv_desc* d, const void* x, const void*
       if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(conv out)");
     }
   }
-  finish_args(a, (long long)d->n * d->hi * d->wi * d->ci, (long long)d->co * ntaps * d->ci);
+  if (up_ca > 0) {
+    UDASEG_CHECK_ARG((long long)d->n * d->hi * d->wi * (d->ci - up_ca) * (bf16 ? 2 : 4) <= (1LL << 30),
+                     "conv2d_fwd_upcat: skip tensor exceeds 2^30 bytes");
+    finish_args(a, (long long)d->n * (d->hi / 2) * (d->wi / 2) * up_ca, (long long)d->co * ntaps * d->ci);
+  } else {
+    finish_args(a, (long long)d->n * d->hi * d->wi * d->ci, (long long)d->co * ntaps * d->ci);
+  }
   rc = launch_igemm(a, st);
   prof_end(0, st, udaseg_conv_flops(d), 0, d);
   if (rc == UDASEG_OK && stats && ns > 1) rc = udaseg_bn_stats(static_cast<const float*>(y), (int64_t)M, d->co, stats, stream);
@@ -702,16 +797,36 @@ extern "C" int udaseg_conv2d_fwd_bnstats(const udaseg_conv_desc* d, const float*
   return conv2d_fwd_impl(d, x, w, bias, y, UDASEG_ACT_NONE, 0.f, 0, stats, nullptr, stream);
 }
 
+extern "C" int udaseg_conv2d_fwd_upcat(const udaseg_conv_desc* d, const float* a, const float* skip, int ca, const float* w,
+                                       const float* bias, float* y, int act, float slope, double* stats, void* stream) {
+  UDASEG_CHECK_ARG(ca > 0, "conv2d_fwd_upcat: ca must be positive");
+  return conv2d_fwd_impl(d, a, w, bias, y, act, slope, 0, stats, nullptr, stream, 0, 0, skip, ca);
+}
+
+extern "C" int udaseg_conv2d_fwd_upcat_bf16(const udaseg_conv_desc* d, const void* a, const void* skip, int ca, const void* w,
+                                            const float* bias, void* y, int act, float slope, double* stats, void* stream) {
+  UDASEG_CHECK_ARG(ca > 0 && ca % 8 == 0, "conv2d_fwd_upcat_bf16: ca must be a positive multiple of 8");
+  return conv2d_fwd_impl(d, a, w, bias, y, act, slope, 0, stats, nullptr, stream, 1, 0, skip, ca);
+}
+
+// dx2 / split: the data gradient of a convolution over a virtual concatenation lands in two tensors: input channels
+// [0, split) in dx [n][hi][wi][split], channels [split, ci) in dx2 [n][hi][wi][ci - split] (IgemmArgs::y2).
 static int conv2d_dgrad_impl(const udaseg_conv_desc* d, const void* dy, const void* w_t, void* dx, int accumulate,
-                             void* stream, int bf16) {
+                             void* stream, int bf16, void* dx2 = nullptr, int split = 0) {
   int rc = check_desc(d);
   if (rc) return rc;
   UDASEG_CHECK_ARG(dy && w_t && dx, "conv2d_dgrad: NULL pointer");
+  UDASEG_CHECK_ARG(split == 0 || (dx2 != nullptr && split > 0 && split < d->ci && d->stride == 1 && !accumulate),
+                   "conv2d_dgrad_split: needs dx2, 0 < split < ci, stride 1, no accumulation");
   UDASEG_CHECK_ARG(!bf16 || (d->ci % 8 == 0 && d->co % 8 == 0), "conv2d_dgrad(bf16): channels must be multiples of 8");
   hipStream_t st = as_stream(stream);
   const int s = d->stride;
   prof_begin(0, st);
   if (!bf16 && d->kh == d->kw && small_conv_applicable(d->kh, d->stride, d->pad, d->co, d->ci)) {
+    if (split > 0) {
+      set_error("conv2d_dgrad_split: not available on the small-channel kernel (co=%d ci=%d)", d->co, d->ci);
+      return UDASEG_E_UNSUPPORTED;
+    }
     // dx = correlation of dy with the flipped taps; w_t is already [ci][9][co]
     rc = launch_small_conv(static_cast<const float*>(dy), static_cast<const float*>(w_t), nullptr, static_cast<float*>(dx), d->n,
                            d->hi, d->wi, d->co, d->ci, 1, accumulate, UDASEG_ACT_NONE, 0.f, nullptr, nullptr, st);
@@ -748,6 +863,8 @@ static int conv2d_dgrad_impl(const udaseg_conv_desc* d, const void* dy, const vo
     }
   a.nclass = nc;
   a.bf16 = bf16;
+  a.y2 = dx2;
+  a.split_n = split;
   if (s == 1 && nc == 1 && !bf16) {
     // single class: K-slices for the deep layers, as in the forward
     const int ntaps = a.ntaps[0];
@@ -762,7 +879,9 @@ static int conv2d_dgrad_impl(const udaseg_conv_desc* d, const void* dy, const vo
       a.nclass = ns;
       a.atomic_out = 1;
       if (!accumulate) {
-        hipError_t e = hipMemsetAsync(dx, 0, (size_t)d->n * d->hi * d->wi * d->ci * sizeof(float), st);  // fp32 only
+        const size_t pix = (size_t)d->n * d->hi * d->wi;
+        hipError_t e = hipMemsetAsync(dx, 0, pix * (split > 0 ? split : d->ci) * sizeof(float), st);  // fp32 only
+        if (e == hipSuccess && split > 0) e = hipMemsetAsync(dx2, 0, pix * (d->ci - split) * sizeof(float), st);
         if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(dgrad out)");
       }
     }
@@ -782,4 +901,15 @@ extern "C" int udaseg_conv2d_dgrad(const udaseg_conv_desc* d, const float* dy, c
 extern "C" int udaseg_conv2d_dgrad_bf16(const udaseg_conv_desc* d, const void* dy, const void* w_t, void* dx, int accumulate,
                                         void* stream) {
   return conv2d_dgrad_impl(d, dy, w_t, dx, accumulate, stream, 1);
+}
+
+extern "C" int udaseg_conv2d_dgrad_split(const udaseg_conv_desc* d, const float* dy, const float* w_t, float* dx_a, float* dx_b,
+                                         int ca, void* stream) {
+  return conv2d_dgrad_impl(d, dy, w_t, dx_a, 0, stream, 0, dx_b, ca);
+}
+
+extern "C" int udaseg_conv2d_dgrad_split_bf16(const udaseg_conv_desc* d, const void* dy, const void* w_t, void* dx_a, void* dx_b,
+                                              int ca, void* stream) {
+  UDASEG_CHECK_ARG(ca % 8 == 0, "conv2d_dgrad_split_bf16: ca must be a multiple of 8");
+  return conv2d_dgrad_impl(d, dy, w_t, dx_a, 0, stream, 1, dx_b, ca);
 }

@@ -18,8 +18,15 @@ namespace udaseg {
 constexpr int ST = 16;            // tile edge (pixels)
 constexpr int SH = ST + 2;        // halo edge
 
-static void* g_workspace = nullptr;
-static size_t g_workspace_bytes = 0;
+// one caller-owned scratch buffer PER DEVICE (udaseg_set_workspace binds it to the device that is current at the call)
+constexpr int MAX_DEVICES = 16;
+static void* g_workspace[MAX_DEVICES] = {};
+static size_t g_workspace_bytes[MAX_DEVICES] = {};
+static int current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return -1;
+  return dev;
+}
 
 struct SmallArgs {
   const float* x;     // gathered operand [n][h][w][ci]
@@ -30,6 +37,7 @@ struct SmallArgs {
   const float* residual;  // added before the activation, same layout as y, or null
   double* stats;      // BN statistics of the output, [R][2][co] f64 accumulators, or null
   int flip;           // 0: tap (r,s) reads (y+r-1, x+s-1) (forward); 1: (y+1-r, x+1-s) (data gradient)
+  int up;             // 1: x is [n][h/2][wd/2][ci], read through nearest x2 up-sampling (fused decoder up-sample)
   int accumulate, act;
   float slope;
   int tiles_x, tiles_y, ntiles;
@@ -45,7 +53,8 @@ struct HaloRegs {
   static constexpr int ITER = (TOTAL + 255) / 256;
   f32x4 v[ITER];
 
-  __device__ __forceinline__ void issue(const float* __restrict__ x, int ni, int ty0, int tx0, int h, int w, int ci) {
+  // up: the tensor behind x is [n][h/2][w/2][ci] and halo pixel (gy, gx) reads its pixel (gy >> 1, gx >> 1)
+  __device__ __forceinline__ void issue(const float* __restrict__ x, int ni, int ty0, int tx0, int h, int w, int ci, int up = 0) {
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
       const int idx = threadIdx.x + 256 * it;
@@ -53,8 +62,10 @@ struct HaloRegs {
       const int hy = pos / SH, hx = pos - hy * SH;
       const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
       f32x4 t = {0.f, 0.f, 0.f, 0.f};
-      if (idx < TOTAL && (unsigned)gy < (unsigned)h && (unsigned)gx < (unsigned)w && cq * 4 < ci)
-        t = *reinterpret_cast<const f32x4*>(x + ((size_t)(ni * h + gy) * w + gx) * (size_t)ci + cq * 4);
+      if (idx < TOTAL && (unsigned)gy < (unsigned)h && (unsigned)gx < (unsigned)w && cq * 4 < ci) {
+        const size_t pix = up ? (size_t)(ni * (h >> 1) + (gy >> 1)) * (w >> 1) + (gx >> 1) : (size_t)(ni * h + gy) * w + gx;
+        t = *reinterpret_cast<const f32x4*>(x + pix * (size_t)ci + cq * 4);
+      }
       v[it] = t;
     }
   }
@@ -75,13 +86,15 @@ struct HaloRegs {
   // never changes): one add per piece, range-checked buffer loads.  off[it] holds the constants, 2^30 for the pieces
   // a thread does not own (idx >= TOTAL or padded channel groups) -- those read zeros.  The per-element divisions, bounds
   // tests and 64-bit addresses of issue() are VALU work that competes with the fp32 MFMAs for the same ALUs.
-  __device__ __forceinline__ void offsets(unsigned (&off)[ITER], int w, int ci) const {
+  __device__ __forceinline__ void offsets(unsigned (&off)[ITER], int w, int ci, int up = 0) const {
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
       const int idx = threadIdx.x + 256 * it;
       const int pos = idx / Q, cq = idx - pos * Q;
       const int hy = pos / SH, hx = pos - hy * SH;
-      off[it] = (idx < TOTAL && cq * 4 < ci) ? (unsigned)(((hy - 1) * w + (hx - 1)) * ci + cq * 4) * 4u : 0x40000000u;
+      // up: tile origins are even, so (ty0 + hy - 1) >> 1 == ty0 / 2 + ((hy - 1) >> 1) with an arithmetic shift
+      const int rel = up ? ((hy - 1) >> 1) * (w >> 1) + ((hx - 1) >> 1) : (hy - 1) * w + (hx - 1);
+      off[it] = (idx < TOTAL && cq * 4 < ci) ? (unsigned)(rel * ci + cq * 4) * 4u : 0x40000000u;
     }
   }
   __device__ __forceinline__ void issue_interior(__amdgpu_buffer_rsrc_t rsrc, const unsigned (&off)[ITER], unsigned tile_base) {
@@ -164,19 +177,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G * CO_T ==
 
   HaloRegs<CIP> stage;
   const bool small_tensors = (long long)a.n * a.h * a.wd * (a.ci > a.co ? a.ci : a.co) * 4 <= (1LL << 30);
-  __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0,
-                                                                    small_tensors ? a.n * a.h * a.wd * a.ci * 4 : 0, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.x), 0, small_tensors ? (a.up ? a.n * (a.h >> 1) * (a.wd >> 1) : a.n * a.h * a.wd) * a.ci * 4 : 0, 0x00020000);
   __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, small_tensors ? a.n * a.h * a.wd * a.co * 4 : 0,
                                                                     0x00020000);
   unsigned hoff[HaloRegs<CIP>::ITER];
-  stage.offsets(hoff, a.wd, a.ci);
+  stage.offsets(hoff, a.wd, a.ci, a.up);
   auto issue_tile = [&](int t) {
     const TileCoord c = tile_coord(t, a.tiles_x, a.tiles_y);
     // interior: the 18x18 halo lies inside the image (uniform per tile)
-    if (small_tensors && c.ty0 >= 1 && c.tx0 >= 1 && c.ty0 + ST + 1 <= a.h && c.tx0 + ST + 1 <= a.wd)
-      stage.issue_interior(rsrc_x, hoff, (unsigned)(((c.ni * a.h + c.ty0) * a.wd + c.tx0) * a.ci) * 4u);
-    else
-      stage.issue(a.x, c.ni, c.ty0, c.tx0, a.h, a.wd, a.ci);
+    if (small_tensors && c.ty0 >= 1 && c.tx0 >= 1 && c.ty0 + ST + 1 <= a.h && c.tx0 + ST + 1 <= a.wd) {
+      const int base = a.up ? (c.ni * (a.h >> 1) + (c.ty0 >> 1)) * (a.wd >> 1) + (c.tx0 >> 1) : (c.ni * a.h + c.ty0) * a.wd + c.tx0;
+      stage.issue_interior(rsrc_x, hoff, (unsigned)(base * a.ci) * 4u);
+    } else {
+      stage.issue(a.x, c.ni, c.ty0, c.tx0, a.h, a.wd, a.ci, a.up);
+    }
   };
   int tile = blockIdx.x;
   if (tile < a.ntiles) issue_tile(tile);
@@ -301,6 +316,7 @@ struct SmallWgradArgs {
   const float* dy;   // [n][h][w][co]
   float* partial;    // [gridDim.x][COP*9*CIP]
   int n, h, w, ci, co;
+  int up;            // 1: x is [n][h/2][w/2][ci] behind a nearest x2 up-sampling
   int tiles_x, tiles_y, ntiles;
 };
 
@@ -329,7 +345,7 @@ __global__ __launch_bounds__(256) void conv3x3_small_wgrad_kernel(const SmallWgr
   int tile = blockIdx.x;
   if (tile < a.ntiles) {
     const TileCoord c = tile_coord(tile, a.tiles_x, a.tiles_y);
-    hx.issue(a.x, c.ni, c.ty0, c.tx0, a.h, a.w, a.ci);
+    hx.issue(a.x, c.ni, c.ty0, c.tx0, a.h, a.w, a.ci, a.up);
     hd.issue(a.dy, c.ni, c.ty0, c.tx0, a.h, a.w, a.co);
   }
   for (; tile < a.ntiles; tile += gridDim.x) {
@@ -339,7 +355,7 @@ __global__ __launch_bounds__(256) void conv3x3_small_wgrad_kernel(const SmallWgr
     __syncthreads();
     if (tile + (int)gridDim.x < a.ntiles) {  // next tile's operands fly during this tile's MFMA phase
       const TileCoord c = tile_coord(tile + gridDim.x, a.tiles_x, a.tiles_y);
-      hx.issue(a.x, c.ni, c.ty0, c.tx0, a.h, a.w, a.ci);
+      hx.issue(a.x, c.ni, c.ty0, c.tx0, a.h, a.w, a.ci, a.up);
       hd.issue(a.dy, c.ni, c.ty0, c.tx0, a.h, a.w, a.co);
     }
 
@@ -426,8 +442,10 @@ bool small_conv_applicable(int k, int stride, int pad, int ci_gather, int co_out
 }
 
 int launch_small_conv(const float* x, const float* w, const float* bias, float* y, int n, int h, int wd, int ci, int co,
-                      int flip, int accumulate, int act, float slope, double* stats, const float* residual, hipStream_t s) {
+                      int flip, int accumulate, int act, float slope, double* stats, const float* residual, hipStream_t s,
+                      int up) {
   SmallArgs a = {};
+  a.up = up;
   a.x = x; a.w = w; a.bias = bias; a.y = y; a.stats = stats; a.residual = residual;
   a.n = n; a.h = h; a.wd = wd; a.ci = ci; a.co = co;
   a.flip = flip; a.accumulate = accumulate; a.act = act; a.slope = slope;
@@ -457,13 +475,20 @@ bool small_wgrad_applicable(int k, int stride, int pad, int ci, int co, int ntil
   if (!small_conv_applicable(k, stride, pad, ci, co)) return false;
   const int G = (ci + 15) / 16, T = (co + 15) / 16;
   const size_t need = (size_t)small_grid(ntiles, 2) * (16 * T) * 9 * (16 * G) * sizeof(float);
-  return g_workspace != nullptr && g_workspace_bytes >= need;
+  const int dev = current_device();
+  return dev >= 0 && g_workspace[dev] != nullptr && g_workspace_bytes[dev] >= need;
 }
 
 int launch_small_wgrad(const float* x, const float* dy, float* dw, int n, int h, int wd, int ci, int co, int accumulate,
-                       hipStream_t s) {
+                       hipStream_t s, int up) {
   SmallWgradArgs a = {};
-  a.x = x; a.dy = dy; a.partial = static_cast<float*>(g_workspace);
+  a.up = up;
+  const int dev = current_device();
+  if (dev < 0 || g_workspace[dev] == nullptr) {
+    set_error("small wgrad: no workspace bound to the current device");
+    return UDASEG_E_WORKSPACE;
+  }
+  a.x = x; a.dy = dy; a.partial = static_cast<float*>(g_workspace[dev]);
   a.n = n; a.h = h; a.w = wd; a.ci = ci; a.co = co;
   a.tiles_x = cdiv(wd, ST); a.tiles_y = cdiv(h, ST); a.ntiles = n * a.tiles_x * a.tiles_y;
   const int G = cdiv(ci, 16), T = cdiv(co, 16);
@@ -507,7 +532,9 @@ extern "C" size_t udaseg_workspace_bytes(const udaseg_conv_desc* d) {
 }
 
 extern "C" int udaseg_set_workspace(void* ptr, size_t bytes) {
-  udaseg::g_workspace = ptr;
-  udaseg::g_workspace_bytes = ptr ? bytes : 0;
+  const int dev = udaseg::current_device();
+  UDASEG_CHECK_ARG(dev >= 0, "set_workspace: no current HIP device (or more than %d devices)", udaseg::MAX_DEVICES);
+  udaseg::g_workspace[dev] = ptr;
+  udaseg::g_workspace_bytes[dev] = ptr ? bytes : 0;
   return UDASEG_OK;
 }

@@ -32,6 +32,11 @@ struct WgradArgs {
   float inv_ci, inv_kw, inv_wo, inv_ho;
   int row_uniform;   // host-side selector of the row-uniform gather (see conv_wgrad_kernel)
   unsigned x_bytes, dy_bytes;
+  // A launch may produce only a channel SLICE of dW -- the weight gradient of a convolution over a virtual concatenation
+  // (fused decoder input cat([up(a), skip])) is one launch per source: x is that source ([..][ci] with ci = ITS channel
+  // count), its columns land at dw[co][tap * ci_full + c_off + c], dW rows are J_ld = taps * ci_full long.
+  // up: the source sits at half resolution behind a nearest x2 up-sampling: pixel (iy, ix) reads (iy >> 1, ix >> 1).
+  int ci_full, c_off, J_ld, up;
 };
 
 constexpr int WBK = 32;  // pixels per K-tile
@@ -104,9 +109,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
     for (int p = 0; p < A_PASS; ++p)
       u_ac[p] = a_ok ? (unsigned)((arow + A_ROWS * p) * a.co + a_co) * 4u : 0x80000000u;
-    u_bc = b_ok ? (unsigned)((b_dy * a.wi + brow * a.stride + b_dx) * a.ci + b_c) * 4u : 0x80000000u;
     u_bdy = b_dy;
     u_bx = brow * a.stride + b_dx;
+    // up-sampled source: the column part of (ix >> 1) splits into scalar + constant because a pass starts at an even ox;
+    // the row part (iy >> 1) depends on the parity of the scalar oy and is formed per load
+    u_bc = !b_ok ? 0x80000000u
+                 : a.up ? (unsigned)((u_bx >> 1) * a.ci + b_c) * 4u
+                        : (unsigned)((b_dy * a.wi + brow * a.stride + b_dx) * a.ci + b_c) * 4u;
     s_dyoff = (unsigned)kbeg * (unsigned)a.co * 4u;
 #pragma unroll
     for (int p = 0; p < B_PASS; ++p) {
@@ -127,9 +136,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
       for (int p = 0; p < B_PASS; ++p) {
         const int oys = s_oy[p] * a.stride, oxs = s_ox[p] * a.stride;                                   // scalars
-        const unsigned s_off = (unsigned)(((s_ni[p] * a.hi + oys) * a.wi + oxs) * a.ci) * 4u;          // scalar
         const bool ok = (unsigned)(oys + u_bdy) < (unsigned)a.hi && (unsigned)(oxs + u_bx) < (unsigned)a.wi;
-        const unsigned voff = ok ? u_bc + s_off : 0x80000000u;
+        unsigned voff;
+        if (a.up) {   // uniform branch
+          const int w2 = a.wi >> 1;
+          const unsigned s_off = (unsigned)((s_ni[p] * (a.hi >> 1) * w2 + (oxs >> 1)) * a.ci) * 4u;   // scalar
+          voff = u_bc + s_off + (unsigned)(((oys + u_bdy) >> 1) * w2 * a.ci) * 4u;
+        } else {
+          const unsigned s_off = (unsigned)(((s_ni[p] * a.hi + oys) * a.wi + oxs) * a.ci) * 4u;        // scalar
+          voff = u_bc + s_off;
+        }
+        voff = ok ? voff : 0x80000000u;
         rb[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)voff, 0, 0));
         // advance this pass by one K-tile (32 pixels); wo is a multiple of B_ROWS, so a pass never straddles image rows
         s_ox[p] += WBK;
@@ -161,8 +178,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
         const int ni = fast_div(t1, a.ho, a.inv_ho);
         const int oy = t1 - ni * a.ho;
         const int iy = oy * a.stride + b_dy, ix = ox * a.stride + b_dx;
-        if ((unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi)
-          v = *reinterpret_cast<const f32x4*>(static_cast<const float*>(a.x) + ((size_t)(ni * a.hi + iy) * a.wi + ix) * (size_t)a.ci + b_c);
+        if ((unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi) {
+          const size_t pix = a.up ? (size_t)(ni * (a.hi >> 1) + (iy >> 1)) * (a.wi >> 1) + (ix >> 1) : (size_t)(ni * a.hi + iy) * a.wi + ix;
+          v = *reinterpret_cast<const f32x4*>(static_cast<const float*>(a.x) + pix * (size_t)a.ci + b_c);
+        }
       }
       rb[p] = v;
     }
@@ -202,6 +221,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
   }
 
   // D reg v of lane (lr, lh): row co = (v&3) + 8*(v>>2) + 4*lh, col j = lr
+  int col[TN];   // this lane's dW column per tile: (tap, c) of the launch's source -> tap * ci_full + c_off + c
+#pragma unroll
+  for (int jn = 0; jn < TN; ++jn) {
+    const int jj = j0 + wn + jn * 32 + lr;
+    const int tap = fast_div(jj, a.ci, a.inv_ci);
+    col[jn] = jj < a.J ? tap * a.ci_full + a.c_off + (jj - tap * a.ci) : -1;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -210,9 +236,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
       if (co >= a.co) continue;
 #pragma unroll
       for (int jn = 0; jn < TN; ++jn) {
-        const int jj = j0 + wn + jn * 32 + lr;
-        if (jj < a.J) {
-          float* dst = a.dw + (size_t)co * a.J + jj;
+        if (col[jn] >= 0) {
+          float* dst = a.dw + (size_t)co * a.J_ld + col[jn];
           if (a.use_atomic) atomicAdd(dst, acc[i][jn][v]);
           else *dst = acc[i][jn][v];
         }
@@ -304,9 +329,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradArgs a)
 #pragma unroll
     for (int p = 0; p < A_PASS; ++p)
       u_ac[p] = a_ok ? (unsigned)((arow + A_ROWS * p) * a.co + a_co) * 2u : 0x80000000u;
-    u_bc = b_ok ? (unsigned)((b_dy * a.wi + brow * a.stride + b_dx) * a.ci + b_c) * 2u : 0x80000000u;
     u_bdy = b_dy;
     u_bx = brow * a.stride + b_dx;
+    // up-sampled source: the column part of (ix >> 1) splits into scalar + constant because a pass starts at an even ox;
+    // the row part (iy >> 1) depends on the parity of the scalar oy and is formed per load
+    u_bc = !b_ok ? 0x80000000u
+                 : a.up ? (unsigned)((u_bx >> 1) * a.ci + b_c) * 2u
+                        : (unsigned)((b_dy * a.wi + brow * a.stride + b_dx) * a.ci + b_c) * 2u;
     s_dyoff = (unsigned)kbeg * (unsigned)a.co * 2u;
 #pragma unroll
     for (int p = 0; p < B_PASS; ++p) {
@@ -327,9 +356,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradArgs a)
 #pragma unroll
       for (int p = 0; p < B_PASS; ++p) {
         const int oys = s_oy[p] * a.stride, oxs = s_ox[p] * a.stride;
-        const unsigned s_off = (unsigned)(((s_ni[p] * a.hi + oys) * a.wi + oxs) * a.ci) * 2u;
         const bool ok = (unsigned)(oys + u_bdy) < (unsigned)a.hi && (unsigned)(oxs + u_bx) < (unsigned)a.wi;
-        const unsigned voff = ok ? u_bc + s_off : 0x80000000u;
+        unsigned voff;
+        if (a.up) {   // uniform branch
+          const int w2 = a.wi >> 1;
+          const unsigned s_off = (unsigned)((s_ni[p] * (a.hi >> 1) * w2 + (oxs >> 1)) * a.ci) * 2u;
+          voff = u_bc + s_off + (unsigned)(((oys + u_bdy) >> 1) * w2 * a.ci) * 2u;
+        } else {
+          const unsigned s_off = (unsigned)(((s_ni[p] * a.hi + oys) * a.wi + oxs) * a.ci) * 2u;
+          voff = u_bc + s_off;
+        }
+        voff = ok ? voff : 0x80000000u;
         rb[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)voff, 0, 0));
         s_ox[p] += WBKB;
         while (s_ox[p] >= a.wo) {
@@ -360,8 +397,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradArgs a)
         const int ni = fast_div(t1, a.ho, a.inv_ho);
         const int oy = t1 - ni * a.ho;
         const int iy = oy * a.stride + b_dy, ix = ox * a.stride + b_dx;
-        if ((unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi)
-          v = *reinterpret_cast<const f32x4*>(xg + ((size_t)(ni * a.hi + iy) * a.wi + ix) * (size_t)a.ci + b_c);
+        if ((unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi) {
+          const size_t pix = a.up ? (size_t)(ni * (a.hi >> 1) + (iy >> 1)) * (a.wi >> 1) + (ix >> 1) : (size_t)(ni * a.hi + iy) * a.wi + ix;
+          v = *reinterpret_cast<const f32x4*>(xg + pix * (size_t)a.ci + b_c);
+        }
       }
       rb[p] = v;
     }
@@ -402,6 +441,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradArgs a)
     cur ^= 1;
   }
 
+  int col[TN];   // this lane's dW column per tile: (tap, c) of the launch's source -> tap * ci_full + c_off + c
+#pragma unroll
+  for (int jn = 0; jn < TN; ++jn) {
+    const int jj = j0 + wn + jn * 32 + lr;
+    const int tap = fast_div(jj, a.ci, a.inv_ci);
+    col[jn] = jj < a.J ? tap * a.ci_full + a.c_off + (jj - tap * a.ci) : -1;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -410,9 +456,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradArgs a)
       if (co >= a.co) continue;
 #pragma unroll
       for (int jn = 0; jn < TN; ++jn) {
-        const int jj = j0 + wn + jn * 32 + lr;
-        if (jj < a.J) {
-          float* dst = a.dw + (size_t)co * a.J + jj;
+        if (col[jn] >= 0) {
+          float* dst = a.dw + (size_t)co * a.J_ld + col[jn];
           if (a.use_atomic) atomicAdd(dst, acc[i][jn][v]);
           else *dst = acc[i][jn][v];
         }
@@ -440,6 +485,10 @@ static int launch_wgrad(WgradArgs a, int accumulate, hipStream_t s, bool bf16 = 
   a.kchunk = kchunk;
   a.use_atomic = (splits > 1 || accumulate) ? 1 : 0;
   if (a.use_atomic && !accumulate) {
+    if (a.J != a.J_ld) {
+      set_error("conv2d_wgrad_part: a channel slice of dW must be accumulated onto a caller-zeroed gradient");
+      return UDASEG_E_BADARG;
+    }
     hipError_t e = hipMemsetAsync(a.dw, 0, (size_t)a.co * a.J * sizeof(float), s);
     if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(dw)");
   }
@@ -447,7 +496,8 @@ static int launch_wgrad(WgradArgs a, int accumulate, hipStream_t s, bool bf16 = 
   hipEvent_t ev = kprof_begin(s);
   if (bf16) {
     constexpr int b_rows16 = 256 / (BNW / 8);
-    const long long xb16 = (long long)a.M / (a.ho * a.wo) * a.hi * a.wi * a.ci * 2, dyb16 = (long long)a.M * a.co * 2;
+    const long long xb16 = (long long)a.M / (a.ho * a.wo) * (a.up ? (a.hi >> 1) * (a.wi >> 1) : a.hi * a.wi) * a.ci * 2,
+                    dyb16 = (long long)a.M * a.co * 2;
     a.row_uniform = !(g_opt_generic_gather >= 0 ? g_opt_generic_gather : getenv("UDASEG_WGRAD_GENERIC") != nullptr) && a.wo % b_rows16 == 0 && xb16 <= (1LL << 30) && dyb16 <= (1LL << 30);
     a.x_bytes = (unsigned)xb16;
     a.dy_bytes = (unsigned)dyb16;
@@ -463,7 +513,8 @@ static int launch_wgrad(WgradArgs a, int accumulate, hipStream_t s, bool bf16 = 
       const char* e = getenv("UDASEG_WGRAD_GENERIC");
       generic = e ? atoi(e) : 0;
     }
-    const long long xb = (long long)a.M / (a.ho * a.wo) * a.hi * a.wi * a.ci * 4, dyb = (long long)a.M * a.co * 4;
+    const long long xb = (long long)a.M / (a.ho * a.wo) * (a.up ? (a.hi >> 1) * (a.wi >> 1) : a.hi * a.wi) * a.ci * 4,
+                    dyb = (long long)a.M * a.co * 4;
     a.row_uniform = !(g_opt_generic_gather >= 0 ? g_opt_generic_gather : generic) && a.wo % b_rows == 0 && xb <= (1LL << 30) && dyb <= (1LL << 30);
     a.x_bytes = (unsigned)xb;
     a.dy_bytes = (unsigned)dyb;
@@ -481,51 +532,68 @@ static int launch_wgrad(WgradArgs a, int accumulate, hipStream_t s, bool bf16 = 
 
 using namespace udaseg;
 
-extern "C" int udaseg_conv2d_wgrad(const udaseg_conv_desc* d, const float* x, const float* dy, float* dw,
-                                   int accumulate, void* stream) {
+// One implementation behind the four entry points.  src_c / c_off / up describe a channel slice of dW (WgradArgs::ci_full):
+// the whole gradient is src_c == d->ci, c_off == 0, up == 0.
+static int conv2d_wgrad_impl(const udaseg_conv_desc* d, const void* x, int src_c, int c_off, int up, const void* dy, float* dw,
+                             int accumulate, void* stream, int bf16) {
   UDASEG_CHECK_ARG(d && x && dy && dw, "conv2d_wgrad: NULL pointer");
-  UDASEG_CHECK_ARG(d->ci % 4 == 0 && d->co % 4 == 0 && d->ci > 0 && d->co > 0, "conv2d_wgrad: channels must be multiples of 4");
+  const int g = bf16 ? 8 : 4;
+  UDASEG_CHECK_ARG(d->ci % g == 0 && d->co % g == 0 && d->ci > 0 && d->co > 0, "conv2d_wgrad: channels must be multiples of %d", g);
   UDASEG_CHECK_ARG(d->kh > 0 && d->kw > 0 && d->stride >= 1, "conv2d_wgrad: bad kernel/stride");
   UDASEG_CHECK_ARG((long long)d->n * d->hi * d->wi * d->ci < (1LL << 31) && (long long)d->n * d->ho * d->wo * d->co < (1LL << 31),
                    "conv2d_wgrad: tensor exceeds 2^31 elements");
+  UDASEG_CHECK_ARG(src_c > 0 && src_c % g == 0 && c_off >= 0 && c_off % g == 0 && c_off + src_c <= d->ci,
+                   "conv2d_wgrad_part: channel slice [%d, %d) of %d", c_off, c_off + src_c, d->ci);
+  UDASEG_CHECK_ARG(!up || (d->stride == 1 && d->hi % 2 == 0 && d->wi % 2 == 0), "conv2d_wgrad_part: an up-sampled source needs stride 1 and even extents");
+  const bool whole = src_c == d->ci;
+  UDASEG_CHECK_ARG(whole || accumulate, "conv2d_wgrad_part: a channel slice of dW must be accumulated onto a caller-zeroed gradient");
   WgradArgs a = {};
   a.x = x; a.dy = dy; a.dw = dw;
-  a.hi = d->hi; a.wi = d->wi; a.ci = d->ci; a.ho = d->ho; a.wo = d->wo; a.co = d->co;
+  a.hi = d->hi; a.wi = d->wi; a.ci = src_c; a.ho = d->ho; a.wo = d->wo; a.co = d->co;
   a.kw = d->kw; a.stride = d->stride; a.pad = d->pad;
   a.M = d->n * d->ho * d->wo;
-  a.J = d->kh * d->kw * d->ci;
-  a.inv_ci = 1.0f / d->ci; a.inv_kw = 1.0f / d->kw; a.inv_wo = 1.0f / d->wo; a.inv_ho = 1.0f / d->ho;
+  a.J = d->kh * d->kw * src_c;
+  a.ci_full = d->ci; a.c_off = c_off; a.J_ld = d->kh * d->kw * d->ci; a.up = up;
+  a.inv_ci = 1.0f / src_c; a.inv_kw = 1.0f / d->kw; a.inv_wo = 1.0f / d->wo; a.inv_ho = 1.0f / d->ho;
   hipStream_t st = as_stream(stream);
   prof_begin(1, st);
   int rc;
-  if (d->kh == d->kw &&
-      small_wgrad_applicable(d->kh, d->stride, d->pad, d->ci, d->co, d->n * cdiv(d->hi, 16) * cdiv(d->wi, 16)))
-    rc = launch_small_wgrad(x, dy, dw, d->n, d->hi, d->wi, d->ci, d->co, accumulate, st);
+  udaseg_conv_desc dp = *d;     // FLOPs of this launch: the slice's share
+  dp.ci = src_c;
+  if (bf16)
+    rc = launch_wgrad<64, 64, 2, 2>(a, accumulate, st, true);
+  else if (whole && d->kh == d->kw &&
+           small_wgrad_applicable(d->kh, d->stride, d->pad, d->ci, d->co, d->n * cdiv(d->hi, 16) * cdiv(d->wi, 16)))
+    rc = launch_small_wgrad(static_cast<const float*>(x), static_cast<const float*>(dy), dw, d->n, d->hi, d->wi, d->ci, d->co,
+                            accumulate, st, up);
   else if (d->co > 32) rc = launch_wgrad<64, 64, 2, 2>(a, accumulate, st);
   else rc = launch_wgrad<32, 128, 1, 4>(a, accumulate, st);
-  prof_end(1, st, udaseg_conv_flops(d), 2, d);
+  prof_end(1, st, udaseg_conv_flops(&dp), 2, &dp);
   return rc;
+}
+
+extern "C" int udaseg_conv2d_wgrad(const udaseg_conv_desc* d, const float* x, const float* dy, float* dw,
+                                   int accumulate, void* stream) {
+  UDASEG_CHECK_ARG(d != nullptr, "conv2d_wgrad: NULL desc");
+  return conv2d_wgrad_impl(d, x, d->ci, 0, 0, dy, dw, accumulate, stream, 0);
 }
 
 extern "C" int udaseg_conv2d_wgrad_bf16(const udaseg_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate,
                                         void* stream) {
-  UDASEG_CHECK_ARG(d && x && dy && dw, "conv2d_wgrad_bf16: NULL pointer");
-  UDASEG_CHECK_ARG(d->ci % 8 == 0 && d->co % 8 == 0 && d->ci > 0 && d->co > 0, "conv2d_wgrad_bf16: channels must be multiples of 8");
-  UDASEG_CHECK_ARG(d->kh > 0 && d->kw > 0 && d->stride >= 1, "conv2d_wgrad_bf16: bad kernel/stride");
-  UDASEG_CHECK_ARG((long long)d->n * d->hi * d->wi * d->ci < (1LL << 31) && (long long)d->n * d->ho * d->wo * d->co < (1LL << 31),
-                   "conv2d_wgrad_bf16: tensor exceeds 2^31 elements");
-  WgradArgs a = {};
-  a.x = x; a.dy = dy; a.dw = dw;
-  a.hi = d->hi; a.wi = d->wi; a.ci = d->ci; a.ho = d->ho; a.wo = d->wo; a.co = d->co;
-  a.kw = d->kw; a.stride = d->stride; a.pad = d->pad;
-  a.M = d->n * d->ho * d->wo;
-  a.J = d->kh * d->kw * d->ci;
-  a.inv_ci = 1.0f / d->ci; a.inv_kw = 1.0f / d->kw; a.inv_wo = 1.0f / d->wo; a.inv_ho = 1.0f / d->ho;
-  hipStream_t st = as_stream(stream);
-  prof_begin(1, st);
-  const int rc = launch_wgrad<64, 64, 2, 2>(a, accumulate, st, true);
-  prof_end(1, st, udaseg_conv_flops(d), 2, d);
-  return rc;
+  UDASEG_CHECK_ARG(d != nullptr, "conv2d_wgrad_bf16: NULL desc");
+  return conv2d_wgrad_impl(d, x, d->ci, 0, 0, dy, dw, accumulate, stream, 1);
+}
+
+extern "C" int udaseg_conv2d_wgrad_part(const udaseg_conv_desc* d, const float* src, int src_c, int c_off, int up,
+                                        const float* dy, float* dw, int accumulate, void* stream) {
+  UDASEG_CHECK_ARG(d != nullptr, "conv2d_wgrad_part: NULL desc");
+  return conv2d_wgrad_impl(d, src, src_c, c_off, up, dy, dw, accumulate, stream, 0);
+}
+
+extern "C" int udaseg_conv2d_wgrad_part_bf16(const udaseg_conv_desc* d, const void* src, int src_c, int c_off, int up,
+                                             const void* dy, float* dw, int accumulate, void* stream) {
+  UDASEG_CHECK_ARG(d != nullptr, "conv2d_wgrad_part_bf16: NULL desc");
+  return conv2d_wgrad_impl(d, src, src_c, c_off, up, dy, dw, accumulate, stream, 1);
 }
 
 // ---- weight repack for dgrad: w[co][t][ci] -> w_t[ci][t][co] ------------------------------------------------

@@ -14,6 +14,7 @@ import torch
 
 from . import _lib
 from ._lib import check
+from .engine import mark_padded_input
 
 IMAGENET_MEAN = (0.485, 0.456, 0.406)      # A.Normalize() defaults
 IMAGENET_STD = (0.229, 0.224, 0.225)
@@ -115,6 +116,7 @@ def prepare_batch(images_u8, masks_u8=None, d4_codes=None, dtype=torch.float32, 
                                                out.data_ptr(), cpad, int(dtype == torch.bfloat16),
                                                None if out_m is None else out_m.data_ptr(), square_ok,
                                                torch.cuda.current_stream().cuda_stream), "prepare_batch_u8")
+    mark_padded_input(out)
     return out.permute(0, 3, 1, 2)[:, :3], out_m
 
 

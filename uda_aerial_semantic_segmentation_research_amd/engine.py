@@ -10,6 +10,7 @@ Design (MI355X-first):
 """
 import math
 import os
+import weakref
 
 import torch
 import torch.nn as nn
@@ -23,12 +24,52 @@ ALIGN = 64  # floats; every arena entry starts on a 256-byte boundary
 SIDE_STREAM_WGRAD = os.environ.get("UDASEG_SERIAL", "0") != "1"
 
 
+_ARENA_OWNERS = {}   # parameter-arena storage pointer -> weakref of the ArenaModule that owns it
+
+
+def arena_owner(storage_ptr):
+    """The live network whose parameter arena starts at ``storage_ptr`` (optim.FusedAdam asks before it updates a whole
+    storage in one pass), or None."""
+    ref = _ARENA_OWNERS.get(storage_ptr)
+    net = ref() if ref is not None else None
+    if net is None or net._arena is None or net._arena.untyped_storage().data_ptr() != storage_ptr:
+        _ARENA_OWNERS.pop(storage_ptr, None)
+        return None
+    return net
+
+
+_PADDED_INPUTS = {}   # data pointer -> weakref of a channel-padded NHWC input buffer made by data.prepare_batch
+
+
+def mark_padded_input(buf):
+    """data.prepare_batch registers the buffer whose [N,3,H,W]-shaped view it returns: only such buffers are read in place
+    by the stem convolution (their padding lanes are zeros by construction; an arbitrary 4-channel channels_last tensor
+    sliced [:, :3] is NOT one of them and takes the copy path)."""
+    for k in [k for k, r in _PADDED_INPUTS.items() if r() is None]:
+        del _PADDED_INPUTS[k]
+    _PADDED_INPUTS[buf.data_ptr()] = weakref.ref(buf)
+
+
+def is_padded_input(ptr):
+    r = _PADDED_INPUTS.get(ptr)
+    t = r() if r is not None else None
+    return t is not None and t.data_ptr() == ptr
+
+
 def ceil4(c):
     return (c + 3) // 4 * 4
 
 
 def ceil_to(c, a):
     return (c + a - 1) // a * a
+
+
+class UpCat:
+    """A convolution input that is never materialised: cat([nearest_x2(a), skip], channels); ``skip`` may be None."""
+    __slots__ = ("a", "skip")
+
+    def __init__(self, a, skip):
+        self.a, self.skip = a, skip
 
 
 class ConvP(nn.Module):
@@ -138,6 +179,7 @@ class ArenaModule(nn.Module):
                 self._entries.append((p, o, n, shp, mod, name))
                 self._param_list.append(p)
         self._arena = arena
+        _ARENA_OWNERS[arena.untyped_storage().data_ptr()] = weakref.ref(self)
         # BN running statistics
         bns = [m for m in self.modules() if isinstance(m, BNP)]
         boff, blay = 0, []
@@ -223,21 +265,28 @@ class ArenaModule(nn.Module):
     def deliver_grads(self, garena):
         """Hand a finished gradient arena to the parameters' ``.grad`` (what autograd's AccumulateGrad would do, minus its
         clone of non-dense views): first backward since zero_grad -> ``.grad`` become views of ``garena``; later ones add
-        onto the arena those views live in with one axpy."""
-        ps = self._param_list
+        onto the arena those views live in with one axpy.  Parameters with ``requires_grad=False`` get no ``.grad`` (a frozen
+        encoder stays frozen under any optimizer)."""
+        ps = [p for p in self._param_list if p.requires_grad]
+        views = [g for p, g in zip(self._param_list, self.grad_views(garena)) if p.requires_grad]
         if all(p.grad is None for p in ps):
-            for p, g in zip(ps, self.grad_views(garena)):
+            for p, g in zip(ps, views):
                 p.grad = g
             self._grad_arena = garena
             return
+        if getattr(self, "grad_ready_hook", None) is not None:
+            # the buckets of the previous backward's arena are being averaged in place on the all-reduce stream, and that
+            # arena has already been divided by the world size: adding a second backward onto it would be wrong twice over
+            raise RuntimeError("gradient accumulation over several backward passes is not supported while a GradAllReducer is "
+                               "attached: call optimizer.zero_grad() (or detach the reducer) between backward passes")
         ga = getattr(self, "_grad_arena", None)
-        if (ga is not None and ga.numel() == garena.numel() and all(p.grad is not None for p in ps)
-                and ps[0].grad.data_ptr() == ga.data_ptr() + 4 * self._entries[0][1]
-                and ps[-1].grad.data_ptr() == ga.data_ptr() + 4 * self._entries[-1][1]):
+        if (ga is not None and ga.numel() == garena.numel() and all(p.grad is not None for p in ps) and ps
+                and ps[0].grad.data_ptr() == views[0].data_ptr() - garena.data_ptr() + ga.data_ptr()
+                and ps[-1].grad.data_ptr() == views[-1].data_ptr() - garena.data_ptr() + ga.data_ptr()):
             K.axpy(ga, garena, 1.0)
             return
         with torch.no_grad():
-            for p, g in zip(ps, self.grad_views(garena)):
+            for p, g in zip(ps, views):
                 if p.grad is None:
                     p.grad = g.clone()
                 else:
@@ -341,17 +390,29 @@ class Plan:
 
     def conv_bn_act(self, conv, bn, x, act=ACT_LEAKY, slope=0.0, residual=None):
         """z = act(bn(conv(x)) (+ residual)); returns (z, record for backward).  In training the conv's epilogue also
-        accumulates the BN statistics of its output (no separate pass over y)."""
+        accumulates the BN statistics of its output (no separate pass over y).
+
+        ``x`` may be an ``UpCat(a, skip)``: the convolution then runs on cat([nearest_x2(a), skip], channels) without that
+        tensor ever being written (fused gather; smp's decoder block input)."""
+        up = isinstance(x, UpCat)
+        if up:
+            n, h, w = x.a.shape[0], 2 * x.a.shape[1], 2 * x.a.shape[2]
+            ci, dev = x.a.shape[3] + (0 if x.skip is None else x.skip.shape[3]), x.a.device
+            assert residual is None
+        else:
+            (n, h, w, ci), dev = x.shape, x.device
+        bias = self.b(conv) if conv.bias is not None else None
         if self.training:
-            n, h, w, ci = x.shape
             d = K.conv_desc(n, h, w, ci, conv.cout_p, conv.k, conv.stride, conv.pad)
-            y = torch.empty((n, d.ho, d.wo, conv.cout_p), device=x.device, dtype=self.adt)
+            y = torch.empty((n, d.ho, d.wo, conv.cout_p), device=dev, dtype=self.adt)
             sums = self._next_stats(ceil4(bn.c))
-            K.conv2d_fwd_bnstats(d, x, self.w(conv), self.b(conv) if conv.bias is not None else None, y, sums[0], self.st)
+            if up:
+                K.conv2d_fwd_upcat(d, x.a, x.skip, self.w(conv), bias, y, ACT_NONE, 0.0, sums[0], self.st)
+            else:
+                K.conv2d_fwd_bnstats(d, x, self.w(conv), bias, y, sums[0], self.st)
             z, ms = self.bn(bn, y, act, slope, residual, sums)
         else:
             # eval mode: ONE kernel per conv+BN(+add)+activation block
-            n, h, w, ci = x.shape
             d = K.conv_desc(n, h, w, ci, conv.cout_p, conv.k, conv.stride, conv.pad)
             o, nel, shp = self.idx[(id(conv), "weight")]
             wf = self.fold_w[o:o + nel].view(shp)
@@ -359,12 +420,15 @@ class Plan:
             bf = self.fold_b[self._fold_off:self._fold_off + c]
             self._fold_off += c
             w32 = self.net._arena[o:o + nel].view(shp)
-            K.bn_fold(w32, self.b(conv) if conv.bias is not None else None, self.pvec(bn, "weight"),
+            K.bn_fold(w32, bias, self.pvec(bn, "weight"),
                       self.pvec(bn, "bias"), bn.running_mean, bn.running_var, bn.eps, wf, bf, self.st)
             if self.bf16:
                 wf = K.cast_to_bf16(wf, st=self.st)
-            z = torch.empty((n, d.ho, d.wo, conv.cout_p), device=x.device, dtype=self.adt)
-            K.conv2d_fwd_fused(d, x, wf, bf, residual, z, act, slope, self.st)
+            z = torch.empty((n, d.ho, d.wo, conv.cout_p), device=dev, dtype=self.adt)
+            if up:
+                K.conv2d_fwd_upcat(d, x.a, x.skip, wf, bf, z, act, slope, None, self.st)
+            else:
+                K.conv2d_fwd_fused(d, x, wf, bf, residual, z, act, slope, self.st)
             return z, None
         # has_res tells the backward whether the activation's argument can be re-evaluated from y alone
         rec = (conv, bn, d, x, y, z, ms, act, slope, residual is not None) if self.save else None
@@ -393,7 +457,10 @@ class Plan:
         return self.net._wt_arena[o:o + n]
 
     def conv_bwd(self, conv, d, x, dy, dx=None, dx_acc=False, dbias=None):
-        """dW (+ dbias) into the grad arena; dx (+)= dgrad when dx is given.  dbias: already-computed channel sums of dy."""
+        """dW (+ dbias) into the grad arena; dx (+)= dgrad when dx is given.  dbias: already-computed channel sums of dy.
+
+        ``x`` an ``UpCat(a, skip)`` (fused decoder input): the weight gradient is one launch per source, ``dx`` is the pair
+        (gradient of the UP-SAMPLED a [n,2h,2w,ca], gradient of skip) and both are overwritten."""
         side = self.side_stream
         if side is not None:
             ev = torch.cuda.Event()
@@ -403,6 +470,18 @@ class Plan:
             dy.record_stream(side)                              # the caching allocator must not recycle dy under the side stream
         else:
             wst = self.st
+        if isinstance(x, UpCat):
+            gw = self.gw(conv)
+            K.conv2d_wgrad_part(d, x.a, 0, True, dy, gw, True, wst)
+            if x.skip is not None:
+                K.conv2d_wgrad_part(d, x.skip, x.a.shape[-1], False, dy, gw, True, wst)
+            d_up, d_skip = dx
+            assert not dx_acc and conv.bias is None
+            if x.skip is None:
+                K.conv2d_dgrad(d, dy, self.packed_wt(conv), d_up, False, self.st)
+            else:
+                K.conv2d_dgrad_split(d, dy, self.packed_wt(conv), d_up, d_skip, self.st)
+            return
         K.conv2d_wgrad(d, x, dy, self.gw(conv), True, wst)
         if conv.bias is not None:
             if dbias is not None:

@@ -24,7 +24,8 @@ def ensure_workspace(device, nbytes=16 << 20):
     key = str(device)
     if key not in _WORKSPACE:
         buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        check(_lib.load().udaseg_set_workspace(buf.data_ptr(), nbytes), "set_workspace")
+        with torch.cuda.device(device):          # the library binds the buffer to the CURRENT device
+            check(_lib.load().udaseg_set_workspace(buf.data_ptr(), nbytes), "set_workspace")
         _WORKSPACE[key] = buf
     return _WORKSPACE[key]
 
@@ -103,6 +104,37 @@ def conv2d_wgrad(d, x, dy, dw, accumulate=False, st=None):
         return conv2d_wgrad_bf16(d, x, dy, dw, accumulate, st)
     check(_lib.load().udaseg_conv2d_wgrad(_byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), int(accumulate),
                                            st if st is not None else stream()), "conv2d_wgrad")
+
+
+def conv2d_fwd_upcat(d, a, skip, w, bias, y, act=ACT_NONE, slope=0.0, stats=None, st=None):
+    """y = act(conv(cat([nearest_x2(a), skip], C), w) + bias) without materialising the concatenation (+ BN statistics of y)."""
+    fn = _lib.load().udaseg_conv2d_fwd_upcat_bf16 if a.dtype == torch.bfloat16 else _lib.load().udaseg_conv2d_fwd_upcat
+    check(fn(_byref(d), a.data_ptr(), _ptr(skip), a.shape[-1], w.data_ptr(), _ptr(bias), y.data_ptr(), act, slope, _ptr(stats),
+             st if st is not None else stream()), "conv2d_fwd_upcat")
+
+
+def conv2d_dgrad_split(d, dy, w_t, dx_a, dx_b, st=None):
+    fn = _lib.load().udaseg_conv2d_dgrad_split_bf16 if dy.dtype == torch.bfloat16 else _lib.load().udaseg_conv2d_dgrad_split
+    check(fn(_byref(d), dy.data_ptr(), w_t.data_ptr(), dx_a.data_ptr(), dx_b.data_ptr(), dx_a.shape[-1],
+             st if st is not None else stream()), "conv2d_dgrad_split")
+
+
+def conv2d_wgrad_part(d, src, c_off, up, dy, dw, accumulate=True, st=None):
+    fn = _lib.load().udaseg_conv2d_wgrad_part_bf16 if src.dtype == torch.bfloat16 else _lib.load().udaseg_conv2d_wgrad_part
+    check(fn(_byref(d), src.data_ptr(), src.shape[-1], c_off, int(up), dy.data_ptr(), dw.data_ptr(), int(accumulate),
+             st if st is not None else stream()), "conv2d_wgrad_part")
+
+
+def upcat_fusable(ca, cb, co, dtype):
+    """Can the convolution over cat([up(a), skip]) take the fused gather?  Channel counts that are multiples of the K-tile
+    for the implicit-GEMM kernels (32 fp32 / 64 bf16) plus a 64-channel boundary for the data gradient's two outputs, or the
+    fp32 small-channel kernel (<= 32 channels in all, no skip)."""
+    if dtype == torch.bfloat16:
+        return ca % 64 == 0 and cb % 64 == 0
+    g_in, g_out = (ca + cb + 15) // 16, (co + 15) // 16
+    if cb == 0 and g_in * g_out <= 2:
+        return True
+    return ca % 32 == 0 and cb % 32 == 0 and (cb == 0 or ca % 64 == 0)
 
 
 def pack_dgrad_weights(d, w, w_t, st=None):
@@ -282,6 +314,25 @@ def upsample2x_concat_bwd(dout, da, dskip, ca, cb, accumulate_da=False, accumula
     check(_lib.load().udaseg_upsample2x_concat_bwd(dout.data_ptr(), _ptr(da), _ptr(dskip), n, h2 // 2, w2 // 2, ca, cb,
                                                     int(accumulate_da), int(accumulate_dskip),
                                                     st if st is not None else stream()), "upsample2x_concat_bwd")
+
+
+def upsample2x_bilinear_concat_fwd(a, skip, st=None):
+    """cat(interpolate(a, scale_factor=2, mode='bilinear', align_corners=False), skip) on NHWC tensors (fp32 or bf16)."""
+    n, h, w, ca = a.shape
+    cb = 0 if skip is None else skip.shape[-1]
+    out = torch.empty((n, 2 * h, 2 * w, ca + cb), device=a.device, dtype=a.dtype)
+    check(_lib.load().udaseg_upsample2x_bilinear_concat_fwd(a.data_ptr(), _ptr(skip), out.data_ptr(), n, h, w, ca, cb,
+                                                             int(a.dtype == torch.bfloat16), st if st is not None else stream()),
+          "upsample2x_bilinear_concat_fwd")
+    return out
+
+
+def upsample2x_bilinear_concat_bwd(dout, da, dskip, ca, cb, accumulate_da=False, accumulate_dskip=False, st=None):
+    n, h2, w2, _ = dout.shape
+    check(_lib.load().udaseg_upsample2x_bilinear_concat_bwd(dout.data_ptr(), _ptr(da), _ptr(dskip), n, h2 // 2, w2 // 2, ca, cb,
+                                                             int(accumulate_da), int(accumulate_dskip),
+                                                             int(dout.dtype == torch.bfloat16), st if st is not None else stream()),
+          "upsample2x_bilinear_concat_bwd")
 
 
 def ce_fwd(logits_base, target, pixels, classes, ldc, lse, partials, loss, st=None):

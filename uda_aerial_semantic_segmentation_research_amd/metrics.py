@@ -1,6 +1,7 @@
 """``DomainAdaptationMetrics`` -- mirror of reference ``src/models/metrics.py:5-73`` (running domain accuracy and the
 entropy of ``sigmoid(pred)``; the reference re-applies the sigmoid to probabilities), plus the per-batch
-segmentation metrics of ``SegmentationTrainer.calculate_metrics`` (reference ``src/models/train.py:225-243``).
+segmentation metrics of ``SegmentationTrainer.calculate_metrics`` (reference ``src/models/train.py:225-243``) and
+``SegmentationMetrics`` -- mirror of reference ``src/analysis/metrics.py:5-67`` on the device-side confusion matrix.
 
 These are logging side-cars, not the hot path: plain torch ops with ONE device->host transfer per call (the reference
 issues >= 25 ``.item()`` syncs per step).
@@ -94,3 +95,56 @@ def segmentation_metrics(outputs, masks, num_classes):
     for c in range(num_classes):
         out[f"iou_class_{c}"] = float(iou_c[c])
     return out
+
+
+class SegmentationMetrics:
+    """Mirror of reference ``src/analysis/metrics.py::SegmentationMetrics`` (same constructor, same methods and return
+    shapes).  ``predictions`` may be what the reference passes -- an integer class map -- or the ``[N,C,H,W]`` logits
+    themselves: then the argmax and the histogram are ONE HIP kernel (``udaseg_argmax_confusion``) and nothing but the
+    C x C matrix leaves the device."""
+
+    def __init__(self, num_classes, ignore_index=None):
+        self.num_classes = num_classes
+        self.ignore_index = ignore_index
+
+    def _fast_hist(self, pred, true):
+        """Confusion matrix (numpy int64, rows = target, columns = prediction); targets outside [0, num_classes) and
+        ``ignore_index`` are left out (reference :17-29)."""
+        k = self.num_classes
+        if pred.is_floating_point():
+            if pred.dim() != 4 or pred.shape[1] != k:
+                raise ValueError(f"logits must be [N,{k},H,W], got {tuple(pred.shape)}")
+            hist = confusion_matrix(pred, true, k)
+        else:
+            if pred.device.type != "cuda":
+                raise RuntimeError("SegmentationMetrics: tensors must live on the GPU (no CPU path in this build)")
+            t, p = true.reshape(-1).long(), pred.reshape(-1).long()
+            m = (t >= 0) & (t < k)
+            hist = torch.bincount(k * t[m] + p[m], minlength=k * k).reshape(k, k)
+        hist = hist.cpu().numpy().astype("int64")
+        if self.ignore_index is not None and 0 <= self.ignore_index < k:
+            hist[self.ignore_index, :] = 0
+        return hist
+
+    def batch_iou(self, predictions, targets):
+        import numpy as np
+        hist = self._fast_hist(predictions, targets)
+        d = np.diag(hist)
+        iu = d / (hist.sum(axis=1) + hist.sum(axis=0) - d + 1e-7)
+        return {"mean_iou": np.nanmean(iu), "class_iou": {i: v for i, v in enumerate(iu)}}
+
+    def pixel_accuracy(self, predictions, targets):
+        """Reference :47-52 (out-of-range targets stay in the denominator, as upstream)."""
+        if predictions.is_floating_point():
+            predictions = predictions.argmax(dim=1)
+        mask = targets != self.ignore_index if self.ignore_index is not None else torch.ones_like(targets, dtype=torch.bool)
+        both = torch.stack([((predictions == targets) & mask).sum(), mask.sum()]).cpu()
+        return int(both[0]) / (int(both[1]) + 1e-7)
+
+    def f1_score(self, predictions, targets, class_index=None):
+        import numpy as np
+        hist = self._fast_hist(predictions, targets)
+        tp = np.diag(hist)
+        fp, fn = hist.sum(axis=0) - tp, hist.sum(axis=1) - tp
+        f1 = 2 * tp / (2 * tp + fp + fn + 1e-7)
+        return f1[class_index] if class_index is not None else f1.tolist()

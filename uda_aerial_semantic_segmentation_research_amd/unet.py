@@ -12,6 +12,7 @@ Architecture (pinned by the reference's traced-graph fixture, SURVEY F4 / Append
 ``forward`` returns logits shaped ``[N, classes, H, W]`` like the reference; physically they are NHWC with the class
 dimension padded to a multiple of 4 (a strided view), which ``losses.CrossEntropyLoss`` consumes without a copy.
 """
+import os
 import warnings
 
 import torch
@@ -19,7 +20,7 @@ import torch.nn as nn
 
 from . import kernels as K
 from ._lib import ACT_LEAKY, ACT_NONE, require_gpu
-from .engine import ArenaModule, BNP, ConvP, GradSlots, Plan, ceil4
+from .engine import ArenaModule, BNP, ConvP, GradSlots, Plan, UpCat, ceil4, is_padded_input
 
 ENCODERS = {
     "resnet18": ("basic", (2, 2, 2, 2), (64, 64, 128, 256, 512)),
@@ -28,6 +29,9 @@ ENCODERS = {
 }
 DECODER_CHANNELS = (256, 128, 64, 32, 16)
 RELU = (ACT_LEAKY, 0.0)
+# UDASEG_MATERIALIZE_UPCAT=1: write cat([up(x), skip]) with the stand-alone kernel instead of gathering it inside conv1
+# (cross-check of the fused gather; tests flip this switch)
+FUSE_UPCAT = os.environ.get("UDASEG_MATERIALIZE_UPCAT", "0") != "1"
 
 
 class BasicBlock(nn.Module):
@@ -133,40 +137,61 @@ class ResNetEncoder(nn.Module):
 
 
 class DecoderBlock(nn.Module):
-    def __init__(self, in_ch, skip_ch, out_ch):
+    def __init__(self, in_ch, skip_ch, out_ch, upsample="nearest"):
         super().__init__()
-        self.in_ch, self.skip_ch, self.out_ch = in_ch, skip_ch, out_ch
+        self.in_ch, self.skip_ch, self.out_ch, self.upsample = in_ch, skip_ch, out_ch, upsample
         self.conv1 = nn.Sequential(ConvP(in_ch + skip_ch, out_ch, 3, 1, 1), BNP(out_ch))
         self.conv2 = nn.Sequential(ConvP(out_ch, out_ch, 3, 1, 1), BNP(out_ch))
 
     def fwd(self, P, x, skip):
-        cat = K.upsample2x_concat_fwd(x, skip, P.st)
+        ca, cb = x.shape[-1], 0 if skip is None else skip.shape[-1]
+        if self.upsample == "bilinear":      # north_star's alternate mode: a stand-alone HBM-bound pass (csrc/bilinear.hip)
+            cat = K.upsample2x_bilinear_concat_fwd(x, skip, P.st)
+        elif FUSE_UPCAT and K.upcat_fusable(ca, cb, self.conv1[0].cout_p, x.dtype):
+            cat = UpCat(x, skip)              # conv1 gathers straight from x (at (iy >> 1, ix >> 1)) and skip
+        else:
+            cat = K.upsample2x_concat_fwd(x, skip, P.st)
         a1, r1 = P.conv_bn_act(self.conv1[0], self.conv1[1], cat, *RELU)
         out, r2 = P.conv_bn_act(self.conv2[0], self.conv2[1], a1, *RELU)
         return out, (x, skip, cat, a1, r1, r2)
+
+    @staticmethod
+    def relu_outputs(rec):
+        """The block's intermediate ReLU outputs held on the tape (tests compare them with the oracle's)."""
+        return [rec[3]]
 
     def bwd(self, P, G, rec, out):
         x, skip, cat, a1, r1, r2 = rec
         d_out = G.pop(out)
         d_a1 = torch.empty_like(a1)
         P.conv_bn_act_bwd(r2, d_out, dx=d_a1)
-        d_cat = torch.empty_like(cat)
-        P.conv_bn_act_bwd(r1, d_a1, dx=d_cat)
         dx, dx_acc = G.slot(x)
         if skip is not None:
             ds, ds_acc = G.slot(skip)
         else:
             ds, ds_acc = None, False
-        K.upsample2x_concat_bwd(d_cat, dx, ds, x.shape[-1], 0 if skip is None else skip.shape[-1], dx_acc, ds_acc, P.st)
+        if isinstance(cat, UpCat):
+            n, h, w, ca = x.shape
+            d_up = torch.empty((n, 2 * h, 2 * w, ca), device=x.device, dtype=x.dtype)   # gradient of the up-sampled x
+            d_skip = torch.empty_like(skip) if ds_acc else ds       # the skip's other consumer comes later in backward
+            P.conv_bn_act_bwd(r1, d_a1, dx=(d_up, d_skip))
+            if ds_acc:
+                ds.add_(d_skip)
+            K.upsample2x_concat_bwd(d_up, dx, None, ca, 0, dx_acc, False, P.st)
+            return
+        d_cat = torch.empty_like(cat)
+        P.conv_bn_act_bwd(r1, d_a1, dx=d_cat)
+        bwd = K.upsample2x_bilinear_concat_bwd if self.upsample == "bilinear" else K.upsample2x_concat_bwd
+        bwd(d_cat, dx, ds, x.shape[-1], 0 if skip is None else skip.shape[-1], dx_acc, ds_acc, P.st)
 
 
 class UnetDecoder(nn.Module):
-    def __init__(self, encoder_channels, decoder_channels=DECODER_CHANNELS):
+    def __init__(self, encoder_channels, decoder_channels=DECODER_CHANNELS, upsample="nearest"):
         super().__init__()
         enc = list(encoder_channels[1:])[::-1]
         in_ch = [enc[0]] + list(decoder_channels[:-1])
         skip_ch = enc[1:] + [0]
-        self.blocks = nn.ModuleList(DecoderBlock(i, s, o) for i, s, o in zip(in_ch, skip_ch, decoder_channels))
+        self.blocks = nn.ModuleList(DecoderBlock(i, s, o, upsample) for i, s, o in zip(in_ch, skip_ch, decoder_channels))
         for m in self.modules():                  # smp initialize_decoder
             if isinstance(m, ConvP):
                 nn.init.kaiming_uniform_(m.weight, mode="fan_in", nonlinearity="relu")
@@ -197,8 +222,15 @@ class Unet(ArenaModule):
 
     def __init__(self, encoder_name="resnet34", encoder_depth=5, encoder_weights=None, decoder_use_batchnorm=True,
                  decoder_channels=DECODER_CHANNELS, in_channels=3, classes=1, activation=None,
-                 compute_dtype=torch.float32, **unused):
+                 compute_dtype=torch.float32, upsample="nearest", decoder_interpolation=None, **unused):
+        """``upsample`` (alias ``decoder_interpolation``, the keyword newer smp releases use): "nearest" -- what the
+        reference's traced model does, fused into the decoder convolutions -- or "bilinear" (align_corners=False),
+        the mode north_star names."""
         super().__init__()
+        upsample = decoder_interpolation or upsample
+        if upsample not in ("nearest", "bilinear"):
+            raise ValueError(f"upsample must be 'nearest' or 'bilinear', got {upsample!r}")
+        self.upsample = upsample
         if encoder_name not in ENCODERS:
             raise ValueError(f"unsupported encoder {encoder_name!r}; available: {sorted(ENCODERS)}")
         if encoder_depth != 5 or tuple(decoder_channels) != DECODER_CHANNELS or not decoder_use_batchnorm or activation:
@@ -208,7 +240,7 @@ class Unet(ArenaModule):
         self.classes = classes
         self.in_channels = in_channels
         self.encoder = ResNetEncoder(encoder_name, in_channels)
-        self.decoder = UnetDecoder(self.encoder.out_channels, DECODER_CHANNELS)
+        self.decoder = UnetDecoder(self.encoder.out_channels, DECODER_CHANNELS, upsample)
         head = ConvP(DECODER_CHANNELS[-1], classes, 3, 1, 1, bias=True)
         nn.init.xavier_uniform_(head.weight)      # smp initialize_head
         nn.init.constant_(head.bias, 0)
@@ -259,11 +291,12 @@ class Unet(ArenaModule):
 
     def _padded_input_view(self, x):
         """``data.prepare_batch`` hands the images over as an [N,3,H,W]-shaped view of the channel-padded NHWC buffer the
-        stem convolution reads: recognise it (layout + dtype) and return that buffer, else None."""
+        stem convolution reads: recognise it (registered by prepare_batch + layout + dtype) and return that buffer, else
+        None (any other tensor, e.g. an RGBA batch sliced [:, :3], is converted by udaseg_nchw_to_nhwc)."""
         cp = self.encoder.conv1.cin_p
         n, c, h, w = x.shape
         es = x.element_size()
-        if (x.dtype == self.compute_dtype and x.stride() == (h * w * cp, 1, w * cp, cp)
+        if (is_padded_input(x.data_ptr()) and x.dtype == self.compute_dtype and x.stride() == (h * w * cp, 1, w * cp, cp)
                 and x.untyped_storage().nbytes() - es * x.storage_offset() >= es * n * h * w * cp
                 and (x.data_ptr() % 16) == 0):
             return x.as_strided((n, h, w, cp), (h * w * cp, w * cp, cp, 1), x.storage_offset())
