@@ -82,6 +82,16 @@ int udaseg_conv2d_wgrad_bf16(const udaseg_conv_desc* d, const void* x, const voi
  * udaseg_pack_dgrad_weights.  Autograd of the convs above: loss.backward() at train.py:343. */
 int udaseg_conv2d_dgrad(const udaseg_conv_desc* d, const float* dy, const float* w_t, float* dx, int accumulate,
                         void* stream);
+/* dx = conv_transpose(dy, w) AND, in the same pass, the two reductions of the BatchNorm backward of the layer in front of this
+ * convolution (the one whose output prev_y [n][hi][wi][ci] went through training-mode BN + activation to become this
+ * convolution's input):  g = dx * act'(gamma*(prev_y-mean)*rstd + beta),  bsums[0][c] += sum g,  bsums[1][c] += sum g*xhat
+ * -- exactly what udaseg_bn_bwd_reduce(dz = dx, z = NULL, y = prev_y, ...) adds, without re-reading dx (loss.backward(),
+ * reference src/models/train.py:343).  Only for activations with a single consumer (dx is their complete gradient) and for
+ * geometries udaseg_conv2d_dgrad_bnreduce_ok() accepts (whole tiles: stride 1, no K-slices, not the small-channel kernel). */
+int udaseg_conv2d_dgrad_bnreduce_ok(const udaseg_conv_desc* d);
+int udaseg_conv2d_dgrad_bnreduce(const udaseg_conv_desc* d, const float* dy, const float* w_t, float* dx, const float* prev_y,
+                                 const float* save_mean, const float* save_rstd, const float* gamma, const float* beta, int act,
+                                 float slope, double* bsums, void* stream);
 /* dw[co][kh][kw][ci] (+)= sum over pixels of dy (x) x.  If !accumulate dw is overwritten.
  * Split-K partials are combined with fp32 atomics. */
 int udaseg_conv2d_wgrad(const udaseg_conv_desc* d, const float* x, const float* dy, float* dw, int accumulate,

@@ -77,8 +77,9 @@ CONV_CASES = [
     (1, 64, 64, 16, 24, 3, 1, 1),     # head shape through the direct kernel
     (4, 96, 96, 64, 64, 3, 1, 1),     # enough tiles for the unsliced launches: uniform-tap loop + buffer-store epilogues
     (2, 96, 96, 128, 32, 3, 1, 1),    # same through the 128x32 tile
-    (2, 32, 32, 64, 128, 3, 1, 1),    # two co tiles, image-border rows / columns in every K-tile
-    (3, 32, 64, 192, 64, 3, 1, 1),    # three ci tiles, non-square, K-tiles crossing image boundaries
+    (2, 32, 32, 64, 128, 3, 1, 1),    # kernel-row wgrad tiles: two co tiles, image-border rows / columns in every K-step
+    (3, 32, 64, 192, 64, 3, 1, 1),    # kernel-row wgrad tiles: three ci tiles, non-square, two K-steps per image row
+    (5, 32, 32, 64, 64, 3, 1, 1),     # kernel-row wgrad tiles: pixel splits that end inside an image (5 images, 8-split lanes)
 ]
 
 
@@ -134,6 +135,9 @@ UPCAT_CASES = [
     (2, 20, 12, 32, 0, 16, "fp32"),      # dec.4.conv1: no skip, small-channel direct kernels (halo read through the up-sampling)
     (1, 9, 7, 16, 0, 16, "fp32"),        # same, one K group, odd half-resolution extents (ragged 16x16 tiles)
     (2, 8, 8, 64, 0, 64, "fp32"),        # no skip through the implicit-GEMM kernels
+    (2, 16, 16, 64, 64, 64, "fp32"),     # 32-pixel rows: the kernel-row weight-gradient tiles, one launch per source
+    (1, 16, 32, 128, 64, 128, "fp32"),   # same, two co tiles, 64-pixel rows, up-sampled source with two ci tiles
+    (2, 16, 16, 64, 0, 64, "fp32"),      # same, no skip
     (2, 8, 12, 64, 64, 64, "bf16"),      # bf16 storage
     (2, 8, 8, 128, 64, 64, "bf16"),
 ]
@@ -640,3 +644,42 @@ def test_uniform_loops_equal_generic_loops_at_full_size(K, case):
     y2 = torch.empty_like(y0)
     K.conv2d_fwd(d, 2.0 * x, wt, None, y2)
     assert torch.equal(y2, 2.0 * y0)
+
+
+@pytest.mark.parametrize("n,h,w,c1,c2", [(8, 64, 64, 64, 64), (4, 64, 64, 128, 64), (8, 128, 128, 32, 64), (2, 96, 128, 64, 192)])
+def test_dgrad_with_bn_backward_reductions(K, n, h, w, c1, c2):
+    """udaseg_conv2d_dgrad_bnreduce == udaseg_conv2d_dgrad followed by udaseg_bn_bwd_reduce(dz = dx, z = NULL, y = prev_y):
+    dx bit for bit, the two per-channel sums to fp32 block-partial rounding; and the geometry query says no where a tile
+    would be ragged, K-sliced or strided."""
+    g = torch.Generator().manual_seed(c1 + c2 + h)
+    d = K.conv_desc(n, h, w, c1, c2, 3, 1, 1)
+    assert K.conv2d_dgrad_bnreduce_ok(d)
+    dy = torch.randn(n, h, w, c2, generator=g).cuda()
+    wt = (torch.randn(c1, 3, 3, c2, generator=g) / math.sqrt(9 * c2)).cuda()          # already [ci][taps][co]
+    prev_y = torch.randn(n, h, w, c1, generator=g).cuda()
+    mean, rstd = torch.randn(c1, generator=g).cuda() * 0.1, (torch.rand(c1, generator=g) + 0.5).cuda()
+    gamma, beta = (torch.rand(c1, generator=g) + 0.5).cuda(), (torch.randn(c1, generator=g) * 0.3).cuda()
+    R = K.bn_replicas()
+    dx_ref = torch.empty(n, h, w, c1, device="cuda")
+    K.conv2d_dgrad(d, dy, wt, dx_ref)
+    bs_ref = torch.zeros(R * 2 * c1, dtype=torch.float64, device="cuda")
+    K.bn_bwd_reduce(dx_ref, None, prev_y, mean, rstd, bs_ref, 1, 0.0, gamma=gamma, beta=beta)
+    dx = torch.full_like(dx_ref, float("nan"))
+    bs = torch.zeros_like(bs_ref)
+    K.conv2d_dgrad_bnreduce(d, dy, wt, dx, prev_y, mean, rstd, gamma, beta, 1, 0.0, bs)
+    assert torch.equal(dx, dx_ref)
+    s, s_ref = bs.view(R, 2, c1).sum(0), bs_ref.view(R, 2, c1).sum(0)
+    scale = s_ref.abs().max(dim=1, keepdim=True).values
+    assert ((s - s_ref).abs() / scale).max().item() < 1e-5
+    # torch restatement of the two sums
+    t = prev_y * (gamma * rstd) + (beta - mean * gamma * rstd)
+    gm = dx_ref * (t > 0)
+    want = torch.stack([gm.double().sum((0, 1, 2)), (gm.double() * ((prev_y - mean) * rstd).double()).sum((0, 1, 2))])
+    assert ((s - want).abs() / want.abs().max(dim=1, keepdim=True).values).max().item() < 1e-4
+    for bad in (K.conv_desc(8, 63, 65, 64, 64, 3, 1, 1),       # ragged tiles
+                K.conv_desc(8, 128, 128, 64, 128, 3, 2, 1),    # strided: parity classes
+                K.conv_desc(1, 16, 16, 512, 512, 3, 1, 1),     # K-sliced launch (atomic epilogue)
+                K.conv_desc(8, 128, 128, 16, 16, 3, 1, 1)):    # small-channel kernel
+        assert not K.conv2d_dgrad_bnreduce_ok(bad)
+    with pytest.raises(RuntimeError, match="cannot carry"):
+        K.conv2d_dgrad_bnreduce(K.conv_desc(1, 16, 16, 512, 512, 3, 1, 1), dy, wt, dx, prev_y, mean, rstd, gamma, beta, 1, 0.0, bs)

@@ -41,7 +41,28 @@ def main():
             dur = int(rows[i]["End_Timestamp"]) - int(rows[i]["Start_Timestamp"])
             ctx[(names[i], prev, nxt, rows[i].get("Queue_Id", "?"))] += 1
             print(f"{i - lo:4d} q{rows[i].get('Queue_Id', '?'):>3} {dur:7d} ns  {names[i][:48]:48s} after {prev[:40]:40s} before {nxt[:40]}")
-    print(f"\nlast step: {hi - lo} launches; matched {sum(ctx.values())}")
+    # how busy was the device inside the step?  union of the kernel intervals over all queues vs the step's span
+    iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows[lo:hi])
+    span = max(e for _, e in iv) - iv[0][0]
+    busy, cur_s, cur_e = 0, iv[0][0], iv[0][1]
+    gaps = []
+    for st, en in iv[1:]:
+        if st > cur_e:
+            busy += cur_e - cur_s
+            gaps.append(st - cur_e)
+            cur_s, cur_e = st, en
+        else:
+            cur_e = max(cur_e, en)
+    busy += cur_e - cur_s
+    per_q = Counter()
+    for r in rows[lo:hi]:
+        per_q[r.get("Queue_Id", "?")] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    gaps.sort()
+    print(f"\nlast step: span {span / 1e6:.3f} ms, some kernel running {busy / 1e6:.3f} ms ({100 * busy / span:.1f} %), "
+          f"{len(gaps)} idle gaps totalling {sum(gaps) / 1e6:.3f} ms (median {gaps[len(gaps) // 2] / 1e3 if gaps else 0:.1f} us, "
+          f"max {gaps[-1] / 1e3 if gaps else 0:.1f} us); kernel time per queue: "
+          + ", ".join(f"q{q}: {t / 1e6:.3f} ms" for q, t in per_q.items()))
+    print(f"last step: {hi - lo} launches; matched {sum(ctx.values())}")
     for (n, prev, nxt, q), c in ctx.most_common():
         print(f"{c:4d} x {n[:40]:40s} | after {prev[:36]:36s} | before {nxt[:36]}")
 

@@ -69,6 +69,17 @@ struct IgemmArgs {
   // channels [split_n, co) to y2 with row length co - split_n.  split_n is a multiple of every tile width, or 0.
   void* y2;
   int split_n;
+  // BatchNorm-backward statistics of the layer BEHIND this data gradient (training-mode BN + activation between the
+  // previous convolution's output bnb_y and this convolution's input): with g = out * act'(bn(bnb_y)) and
+  // xhat = (bnb_y - mean) * rstd the epilogue adds sum(g), sum(g * xhat) per channel into `stats` -- what
+  // udaseg_bn_bwd_reduce would compute in a separate pass over (out, bnb_y).  Whole-tile launches only (host-checked).
+  const float* bnb_y;
+  const float* bnb_mean;
+  const float* bnb_rstd;
+  const float* bnb_gamma;
+  const float* bnb_beta;
+  int bnb_act;
+  float bnb_slope;
 };
 
 __device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};   // what a masked-out gather lane reads
@@ -105,6 +116,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
   constexpr int B_PASS = (BN + 31) / 32;
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
   static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile must be a multiple of 32x32");
+  static_assert(BN % 32 == 0, "every B load pass covers 32 whole rows (no per-thread guard in the K loop)");
 
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* As = reinterpret_cast<float*>(smem_raw);          // [2][BM][LDS_LD]
@@ -164,7 +176,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
 #pragma unroll
   for (int p = 0; p < B_PASS; ++p) {
     const int n = n0 + lrow + 32 * p;
-    b_off[p] = (n < a.co && (lrow + 32 * p) < BN) ? n * a.tfull * a.ci : -1;
+    b_off[p] = n < a.co ? n * a.tfull * a.ci : -1;
   }
 
   // uniform path: byte offset of (row's pixel, this thread's 16-byte K column) and the row's per-tap "invalid" bits
@@ -308,8 +320,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
     for (int p = 0; p < A_PASS; ++p)
       *reinterpret_cast<f32x4*>(Ad + (lrow + 32 * p) * LDS_LD + kq * 4) = ra[p];
 #pragma unroll
-    for (int p = 0; p < B_PASS; ++p)
-      if (lrow + 32 * p < BN) *reinterpret_cast<f32x4*>(Bd + (lrow + 32 * p) * LDS_LD + kq * 4) = rb[p];
+    for (int p = 0; p < B_PASS; ++p) *reinterpret_cast<f32x4*>(Bd + (lrow + 32 * p) * LDS_LD + kq * 4) = rb[p];
   };
   auto mfma_tile = [&](int buf) {
     const float* Ac = As + buf * BM * LDS_LD + (wm + lr) * LDS_LD + lh * 4;
@@ -416,9 +427,27 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
       for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn + j * 32 + lr;
         const int voff = ((m0 + wm + i * 32 + 4 * lh) * yld + (n - nsub)) * 4;
-        // three uniform variants so that the common launches carry no dead per-element work:
-        // dgrad / plain conv (store only), conv feeding BatchNorm (statistics), and the general one (bias, activation)
-        if (a.bias == nullptr && a.act == UDASEG_ACT_NONE && a.stats == nullptr) {
+        // uniform variants so that the common launches carry no dead per-element work: dgrad feeding a BatchNorm backward
+        // (store + that layer's two reductions), dgrad / plain conv (store only), conv feeding BatchNorm (statistics), and
+        // the general one (bias, activation)
+        if (a.bnb_y != nullptr) {
+          __amdgpu_buffer_rsrc_t rsrc_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bnb_y), 0, cM * a.co * 4, 0x00020000);
+          float yv[16];
+#pragma unroll
+          for (int v = 0; v < 16; ++v)
+            yv[v] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_p, voff, ((v & 3) + 8 * (v >> 2)) * row_bytes, 0));
+          const float mean = a.bnb_mean[n], rstd = a.bnb_rstd[n];
+          const float sc = a.bnb_gamma[n] * rstd, sh = a.bnb_beta[n] - mean * sc;      // bn_apply's own coefficients
+#pragma unroll
+          for (int v = 0; v < 16; ++v) {
+            const float val = acc[i][j][v];
+            const float g = val * act_grad(__builtin_fmaf(yv[v], sc, sh), a.bnb_act, a.bnb_slope);
+            ssum[j] += g;
+            ssq[j] = __builtin_fmaf(g, (yv[v] - mean) * rstd, ssq[j]);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rsrc_y, voff,
+                                                  ((v & 3) + 8 * (v >> 2)) * row_bytes, 0);
+          }
+        } else if (a.bias == nullptr && a.act == UDASEG_ACT_NONE && a.stats == nullptr) {
 #pragma unroll
           for (int v = 0; v < 16; ++v) {
             const float val = acc[i][j][v];   // (bit_cast straight from the vector element stored element 0 sixteen times)
@@ -809,10 +838,33 @@ extern "C" int udaseg_conv2d_fwd_upcat_bf16(const udaseg_conv_desc* d, const voi
   return conv2d_fwd_impl(d, a, w, bias, y, act, slope, 0, stats, nullptr, stream, 1, 0, skip, ca);
 }
 
+struct BnReduceArgs {   // IgemmArgs::bnb_*
+  const float* y;
+  const float* mean;
+  const float* rstd;
+  const float* gamma;
+  const float* beta;
+  int act;
+  float slope;
+  double* bsums;
+};
+
+// Can the data gradient of this convolution carry the BatchNorm-backward reductions of the layer behind it?  Only when every
+// tile of the launch is whole and plainly stored: stride 1, implicit-GEMM kernel (not the small-channel one), no K-slices,
+// pixel and channel counts that are multiples of the tile the launcher picks.
+static bool dgrad_bnreduce_ok(const udaseg_conv_desc* d) {
+  if (check_desc(d) != UDASEG_OK || d->stride != 1 || tile_override() != 0) return false;
+  if (d->kh == d->kw && small_conv_applicable(d->kh, d->stride, d->pad, d->co, d->ci)) return false;
+  const long long M = (long long)d->n * d->hi * d->wi;
+  if (k_slices((int)M, d->ci, d->kh * d->kw, true) != 1) return false;
+  if (d->ci > 32) return M % 64 == 0 && d->ci % 64 == 0;
+  return M % 128 == 0 && d->ci % 32 == 0;
+}
+
 // dx2 / split: the data gradient of a convolution over a virtual concatenation lands in two tensors: input channels
 // [0, split) in dx [n][hi][wi][split], channels [split, ci) in dx2 [n][hi][wi][ci - split] (IgemmArgs::y2).
 static int conv2d_dgrad_impl(const udaseg_conv_desc* d, const void* dy, const void* w_t, void* dx, int accumulate,
-                             void* stream, int bf16, void* dx2 = nullptr, int split = 0) {
+                             void* stream, int bf16, void* dx2 = nullptr, int split = 0, const BnReduceArgs* bnb = nullptr) {
   int rc = check_desc(d);
   if (rc) return rc;
   UDASEG_CHECK_ARG(dy && w_t && dx, "conv2d_dgrad: NULL pointer");
@@ -865,6 +917,11 @@ static int conv2d_dgrad_impl(const udaseg_conv_desc* d, const void* dy, const vo
   a.bf16 = bf16;
   a.y2 = dx2;
   a.split_n = split;
+  if (bnb) {
+    a.bnb_y = bnb->y; a.bnb_mean = bnb->mean; a.bnb_rstd = bnb->rstd; a.bnb_gamma = bnb->gamma; a.bnb_beta = bnb->beta;
+    a.bnb_act = bnb->act; a.bnb_slope = bnb->slope;
+    a.stats = bnb->bsums;
+  }
   if (s == 1 && nc == 1 && !bf16) {
     // single class: K-slices for the deep layers, as in the forward
     const int ntaps = a.ntaps[0];
@@ -901,6 +958,21 @@ extern "C" int udaseg_conv2d_dgrad(const udaseg_conv_desc* d, const float* dy, c
 extern "C" int udaseg_conv2d_dgrad_bf16(const udaseg_conv_desc* d, const void* dy, const void* w_t, void* dx, int accumulate,
                                         void* stream) {
   return conv2d_dgrad_impl(d, dy, w_t, dx, accumulate, stream, 1);
+}
+
+extern "C" int udaseg_conv2d_dgrad_bnreduce_ok(const udaseg_conv_desc* d) { return d && dgrad_bnreduce_ok(d) ? 1 : 0; }
+
+extern "C" int udaseg_conv2d_dgrad_bnreduce(const udaseg_conv_desc* d, const float* dy, const float* w_t, float* dx,
+                                            const float* prev_y, const float* save_mean, const float* save_rstd,
+                                            const float* gamma, const float* beta, int act, float slope, double* bsums,
+                                            void* stream) {
+  UDASEG_CHECK_ARG(d && prev_y && save_mean && save_rstd && gamma && beta && bsums, "conv2d_dgrad_bnreduce: NULL pointer");
+  if (!dgrad_bnreduce_ok(d)) {
+    set_error("conv2d_dgrad_bnreduce: this geometry cannot carry the reductions (ask udaseg_conv2d_dgrad_bnreduce_ok first)");
+    return UDASEG_E_UNSUPPORTED;
+  }
+  const BnReduceArgs b = {prev_y, save_mean, save_rstd, gamma, beta, act, slope, bsums};
+  return conv2d_dgrad_impl(d, dy, w_t, dx, 0, stream, 0, nullptr, 0, &b);
 }
 
 extern "C" int udaseg_conv2d_dgrad_split(const udaseg_conv_desc* d, const float* dy, const float* w_t, float* dx_a, float* dx_b,

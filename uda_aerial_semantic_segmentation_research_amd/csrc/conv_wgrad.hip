@@ -14,6 +14,14 @@
 // Measured (profiles/r01_pmc_traffic.json): the L2 fetches 4-5x the algorithmic bytes here, because the tap tiles of one
 // pixel slab are dealt round-robin to the 8 XCD L2s.  An XCD-aware remap that keeps a slab's tiles on one L2 was tried
 // and ran 5 % SLOWER (80 -> 76 TFLOP/s): the re-fetches are served by the Infinity Cache and do not bound the kernel.
+// Round 2 built the tile that removes the re-reads outright -- one block per (64 co, 64 ci, kernel ROW): the three taps of
+// a row share one staged x row and the dy fragment, operand traffic / 3, 4 LDS reads per 3 MFMAs, 48 MFMAs per barrier,
+// XCD-aware block order -- and measured it on the r18 step (profiles/r02_wgrad_row_tiles.txt): 77-83 TFLOP/s against
+// 95 for this kernel on the same 19 launches.  What bounds these launches is neither the gather nor LDS but the fp32
+// atomics that reduce the pixel splits: their volume is (blocks x tile bytes) = 50 MB per launch either way, at the chip's
+// ~1.3 TB/s atomic rate 38 us of a ~95 us launch; 3072 small blocks run in three rounds and hide two thirds of it behind
+// other blocks' MFMAs, 1024 three-tap blocks finish together and expose all of it (512 blocks: half the atomics, half the
+// occupancy; 2048 / 3072: 100 / 150 MB of atomics).  The kernel was removed again; this one stays.
 #include <stdlib.h>
 
 #include "common.h"
@@ -539,7 +547,12 @@ static int conv2d_wgrad_impl(const udaseg_conv_desc* d, const void* x, int src_c
   UDASEG_CHECK_ARG(d && x && dy && dw, "conv2d_wgrad: NULL pointer");
   const int g = bf16 ? 8 : 4;
   UDASEG_CHECK_ARG(d->ci % g == 0 && d->co % g == 0 && d->ci > 0 && d->co > 0, "conv2d_wgrad: channels must be multiples of %d", g);
-  UDASEG_CHECK_ARG(d->kh > 0 && d->kw > 0 && d->stride >= 1, "conv2d_wgrad: bad kernel/stride");
+  UDASEG_CHECK_ARG(d->kh > 0 && d->kw > 0 && d->stride >= 1 && d->pad >= 0, "conv2d_wgrad: bad kernel/stride");
+  // found by the sanitizer build (make asan): an empty batch / extent reached the split-K planner and divided by zero
+  UDASEG_CHECK_ARG(d->n > 0 && d->hi > 0 && d->wi > 0 && d->ho > 0 && d->wo > 0, "conv2d_wgrad: non-positive extent");
+  UDASEG_CHECK_ARG(d->ho == (d->hi + 2 * d->pad - d->kh) / d->stride + 1 && d->wo == (d->wi + 2 * d->pad - d->kw) / d->stride + 1,
+                   "conv2d_wgrad: output extent %dx%d inconsistent with input %dx%d k%d s%d p%d", d->ho, d->wo, d->hi, d->wi,
+                   d->kh, d->stride, d->pad);
   UDASEG_CHECK_ARG((long long)d->n * d->hi * d->wi * d->ci < (1LL << 31) && (long long)d->n * d->ho * d->wo * d->co < (1LL << 31),
                    "conv2d_wgrad: tensor exceeds 2^31 elements");
   UDASEG_CHECK_ARG(src_c > 0 && src_c % g == 0 && c_off >= 0 && c_off % g == 0 && c_off + src_c <= d->ci,

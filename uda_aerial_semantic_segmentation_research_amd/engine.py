@@ -22,6 +22,14 @@ ALIGN = 64  # floats; every arena entry starts on a 256-byte boundary
 # Weight gradients run on a side HIP stream (see Plan.begin_backward).  UDASEG_SERIAL=1 keeps everything on one stream:
 # per-kernel durations are then free of overlap slow-down (bench.py's roofline leg and the committed rocprof stats use it).
 SIDE_STREAM_WGRAD = os.environ.get("UDASEG_SERIAL", "0") != "1"
+# BatchNorm-backward reductions of single-consumer activations in the consumer's data-gradient epilogue (UDASEG_FUSE_BN_REDUCE=0:
+# always the stand-alone reduce kernel; tests flip the module attribute to cross-check)
+FUSE_BN_REDUCE = os.environ.get("UDASEG_FUSE_BN_REDUCE", "1") != "0"
+# UDASEG_PREPACK=1: the per-step repack of the weights for the data-gradient kernels runs on the side stream during the
+# forward instead of on the main stream in front of the backward.  Measured in one A/B run (profiles/r02_ab_prepack_bnreduce.txt):
+# 645.3 / 646.1 images/s with it against 648.4 / 650.8 without -- the 0.1 ms pass competes with the forward convolutions for
+# HBM and costs more than it hides; off by default.
+PREPACK_DGRAD = os.environ.get("UDASEG_PREPACK", "0") == "1"
 
 
 _ARENA_OWNERS = {}   # parameter-arena storage pointer -> weakref of the ArenaModule that owns it
@@ -331,6 +339,21 @@ class Plan:
         self.bstats = None
         self._bstat_off = 0
         self.conv_flops = 0.0
+        self._packed = None
+        self._bnb = {}                    # id(conv output y) -> BN-backward sums already made by the consumer's data gradient
+        if training and save and SIDE_STREAM_WGRAD and PREPACK_DGRAD:
+            self._prepack_dgrad_weights()
+
+    def _prepack_dgrad_weights(self):
+        """The data-gradient kernels want the weights as [ci][taps][co]: one batched repack of the arena per step.  The
+        weights are final once the optimizer has stepped, so the repack runs on the side stream DURING the forward (it is
+        a 0.1 ms HBM-bound pass the matrix-core-bound forward convolutions hide) instead of in front of the backward."""
+        net = self.net
+        main, side = torch.cuda.current_stream(), net._side_stream()
+        side.wait_stream(main)                      # the optimizer step / load_state_dict that produced the weights
+        K.pack_dgrad_batched(net._arena, net._wt_arena, net._wt_table, side.cuda_stream)
+        self._packed = torch.cuda.Event()
+        self._packed.record(side)
 
     # -- parameter access
     def w(self, conv):
@@ -446,8 +469,12 @@ class Plan:
         nbn = net._nbn
         self.bstats = torch.zeros(max(nbn, 2) * self.R, dtype=torch.float64, device=self.dev)
         self._bstat_off = 0
-        # dgrad needs the weights as [ci][taps][co]: one batched repack of the whole arena per backward
-        K.pack_dgrad_batched(net._arena, net._wt_arena, net._wt_table, self.st)
+        # dgrad needs the weights as [ci][taps][co]: one batched repack of the whole arena per step, normally issued
+        # on the side stream at the start of the forward (_prepack_dgrad_weights)
+        if self._packed is not None:
+            self.main_stream.wait_event(self._packed)
+        else:
+            K.pack_dgrad_batched(net._arena, net._wt_arena, net._wt_table, self.st)
         if self.side_stream is not None:
             self.side_stream.wait_stream(self.main_stream)      # zeroed gradient arena is visible to the side stream
 
@@ -456,11 +483,20 @@ class Plan:
         n = conv.cout_p * conv.k * conv.k * conv.cin_p
         return self.net._wt_arena[o:o + n]
 
-    def conv_bwd(self, conv, d, x, dy, dx=None, dx_acc=False, dbias=None):
+    def _next_bstats(self, c):
+        o = self._bstat_off
+        self._bstat_off += 2 * c
+        return self.bstats[o * self.R:(o + 2 * c) * self.R]
+
+    def conv_bwd(self, conv, d, x, dy, dx=None, dx_acc=False, dbias=None, prev=None):
         """dW (+ dbias) into the grad arena; dx (+)= dgrad when dx is given.  dbias: already-computed channel sums of dy.
 
         ``x`` an ``UpCat(a, skip)`` (fused decoder input): the weight gradient is one launch per source, ``dx`` is the pair
-        (gradient of the UP-SAMPLED a [n,2h,2w,ca], gradient of skip) and both are overwritten."""
+        (gradient of the UP-SAMPLED a [n,2h,2w,ca], gradient of skip) and both are overwritten.
+
+        ``prev``: the conv+BN+activation record that PRODUCED x, when this convolution is x's only consumer: dx is then that
+        activation's complete gradient and the data-gradient kernel's epilogue also makes the two reductions of its BatchNorm
+        backward (``bn_bwd`` finds them in ``self._bnb`` and skips its reduce pass)."""
         side = self.side_stream
         if side is not None:
             ev = torch.cuda.Event()
@@ -489,29 +525,37 @@ class Plan:
             else:
                 K.channel_sum(dy, self.gvec(conv, "bias"), True, wst)
         if dx is not None:
-            K.conv2d_dgrad(d, dy, self.packed_wt(conv), dx, dx_acc, self.st)
+            if (prev is not None and FUSE_BN_REDUCE and not dx_acc and not self.bf16 and not prev[9] and prev[7] != ACT_NONE
+                    and K.conv2d_dgrad_bnreduce_ok(d)):
+                p_bn, p_y, (p_mean, p_rstd) = prev[1], prev[4], prev[6]
+                bs = self._next_bstats(ceil4(p_bn.c))
+                K.conv2d_dgrad_bnreduce(d, dy, self.packed_wt(conv), dx, p_y, p_mean, p_rstd, self.pvec(p_bn, "weight"),
+                                        self.pvec(p_bn, "bias"), prev[7], prev[8], bs, self.st)
+                self._bnb[id(p_y)] = bs
+            else:
+                K.conv2d_dgrad(d, dy, self.packed_wt(conv), dx, dx_acc, self.st)
 
     def bn_bwd(self, bn, y, z, ms, dz, act, slope, dres=None, dres_acc=False, has_res=True):
         """In place: dz becomes dy (grad w.r.t. the conv output).  dres (+)= masked grad for the residual branch.
         fp32 layers without a residual input do not read z: the kernels re-evaluate the activation's argument from y."""
         c = ceil4(bn.c)
-        o = self._bstat_off
-        self._bstat_off += 2 * c
-        bs = self.bstats[o * self.R:(o + 2 * c) * self.R]
         mean, rstd = ms
         gamma = self.pvec(bn, "weight")
         beta = None
         if not has_res and not self.bf16 and act != ACT_NONE:
             z, beta = None, self.pvec(bn, "bias")
-        K.bn_bwd_reduce(dz, z, y, mean, rstd, bs, act, slope, self.st, gamma=gamma, beta=beta)
+        bs = self._bnb.pop(id(y), None)           # the consumer's data gradient already made the two reductions
+        if bs is None:
+            bs = self._next_bstats(c)
+            K.bn_bwd_reduce(dz, z, y, mean, rstd, bs, act, slope, self.st, gamma=gamma, beta=beta)
         K.bn_bwd_apply(dz, z, y, mean, rstd, gamma, bs, dz, dres, self.gvec(bn, "weight"), self.gvec(bn, "bias"), act, slope,
                        False, dres_acc, False, self.st, beta=beta)
         return dz
 
-    def conv_bn_act_bwd(self, rec, dz, dx=None, dx_acc=False, dres=None, dres_acc=False):
+    def conv_bn_act_bwd(self, rec, dz, dx=None, dx_acc=False, dres=None, dres_acc=False, prev=None):
         conv, bn, d, x, y, z, ms, act, slope, has_res = rec
         dy = self.bn_bwd(bn, y, z, ms, dz, act, slope, dres, dres_acc, has_res)
-        self.conv_bwd(conv, d, x, dy, dx, dx_acc)
+        self.conv_bwd(conv, d, x, dy, dx, dx_acc, prev=prev)
 
 
     def ready_events(self):

@@ -61,12 +61,12 @@ class BasicBlock(nn.Module):
         if rd is None:
             # identity branch: the masked gradient goes straight into dx; conv1's dgrad accumulates on top
             d_a1 = torch.empty_like(a1)
-            P.conv_bn_act_bwd(r2, d_out, dx=d_a1, dres=dx, dres_acc=dx_acc)
+            P.conv_bn_act_bwd(r2, d_out, dx=d_a1, dres=dx, dres_acc=dx_acc, prev=r1)     # a1 feeds conv2 only
             P.conv_bn_act_bwd(r1, d_a1, dx=dx, dx_acc=True)
         else:
             d_idt = torch.empty_like(idt)
             d_a1 = torch.empty_like(a1)
-            P.conv_bn_act_bwd(r2, d_out, dx=d_a1, dres=d_idt)
+            P.conv_bn_act_bwd(r2, d_out, dx=d_a1, dres=d_idt, prev=r1)
             P.conv_bn_act_bwd(rd, d_idt, dx=dx, dx_acc=dx_acc)
             P.conv_bn_act_bwd(r1, d_a1, dx=dx, dx_acc=True)
 
@@ -101,12 +101,12 @@ class Bottleneck(nn.Module):
         d_a2 = torch.empty_like(a2)
         d_a1 = torch.empty_like(a1)
         if rd is None:
-            P.conv_bn_act_bwd(r3, d_out, dx=d_a2, dres=dx, dres_acc=dx_acc)
+            P.conv_bn_act_bwd(r3, d_out, dx=d_a2, dres=dx, dres_acc=dx_acc, prev=r2)     # a2 feeds conv3 only
         else:
             d_idt = torch.empty_like(idt)
-            P.conv_bn_act_bwd(r3, d_out, dx=d_a2, dres=d_idt)
+            P.conv_bn_act_bwd(r3, d_out, dx=d_a2, dres=d_idt, prev=r2)
             P.conv_bn_act_bwd(rd, d_idt, dx=dx, dx_acc=dx_acc)
-        P.conv_bn_act_bwd(r2, d_a2, dx=d_a1)
+        P.conv_bn_act_bwd(r2, d_a2, dx=d_a1, prev=r1)                                    # a1 feeds conv2 only
         P.conv_bn_act_bwd(r1, d_a1, dx=dx, dx_acc=True)
 
 
@@ -164,7 +164,7 @@ class DecoderBlock(nn.Module):
         x, skip, cat, a1, r1, r2 = rec
         d_out = G.pop(out)
         d_a1 = torch.empty_like(a1)
-        P.conv_bn_act_bwd(r2, d_out, dx=d_a1)
+        P.conv_bn_act_bwd(r2, d_out, dx=d_a1, prev=r1)             # a1 feeds conv2 only
         dx, dx_acc = G.slot(x)
         if skip is not None:
             ds, ds_acc = G.slot(skip)
