@@ -205,14 +205,22 @@ def roofline_leg(step, model, trainer, dtype, psteps=3, layer_table=False):
     torch.cuda.synchronize()
     K.prof_enable(False)
     _engine.SIDE_STREAM_WGRAD = was_side
+    # HBM-side view of the same launches: algorithmic bytes (gathered tensor + output + weights, each once) over the summed
+    # launch time -- at bf16 rates most of these convolutions are bound by HBM, not by the matrix cores
+    es = 2 if dtype == "bf16" else 4
+    conv_bytes, conv_ms_api = 0.0, 0.0
+    agg = {}
+    for fam in (0, 1):
+        for ms, fl, kind, d in K.prof_records(fam):
+            n_, hi_, wi_, ci_, ho_, wo_, co_, kh_, kw_ = d[:9]
+            x_b, y_b, w_b = n_ * hi_ * wi_ * ci_ * es, n_ * ho_ * wo_ * co_ * es, co_ * kh_ * kw_ * ci_ * (4 if kind == 2 else es)
+            conv_bytes += x_b + y_b + w_b
+            conv_ms_api += ms
+            a = agg.setdefault((kind, d), [0.0, 0.0, 0])
+            a[0] += ms
+            a[1] += fl
+            a[2] += 1
     if layer_table:
-        agg = {}
-        for fam in (0, 1):
-            for ms, fl, kind, d in K.prof_records(fam):
-                a = agg.setdefault((kind, d), [0.0, 0.0, 0])
-                a[0] += ms
-                a[1] += fl
-                a[2] += 1
         print("kind  n  hi  wi   ci   co k s |  calls/step  ms/call   GFLOP   TFLOP/s", file=sys.stderr)
         for (kind, d), (ms, fl, cnt) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
             print(f"{('fwd', 'dgrad', 'wgrad')[kind]:5s} {d[0]:2d} {d[1]:3d} {d[2]:3d} {d[3]:4d} {d[6]:4d} {d[7]} {d[9]} | "
@@ -232,6 +240,10 @@ def roofline_leg(step, model, trainer, dtype, psteps=3, layer_table=False):
             "launches_per_step": dom[3] // psteps, "avg_launch_us": round(1e3 * dom[1] / dom[3], 2),
             "gflop_per_launch": round(dom[2] / dom[3] / 1e9, 3),
             "ms_per_step": round(dom[1] / psteps, 3),
+            "hbm_view": {"algorithmic_GB_per_step": round(conv_bytes / psteps / 1e9, 3),
+                         "achieved_TB_per_s": round(conv_bytes / (conv_ms_api * 1e-3) / 1e12, 3) if conv_ms_api else None,
+                         "frac_of_8TBps": round(conv_bytes / (conv_ms_api * 1e-3) / 8e12, 4) if conv_ms_api else None,
+                         "note": "all conv launches: (gathered tensor + output + weights, each counted once) / summed launch time"},
             "all_conv_kernels": {"ms_per_step": round(conv_ms, 3),
                                  "achieved": round(sum(k[2] for k in kern) / psteps / (conv_ms * 1e-3) / 1e12, 2),
                                  "flops_note": "per-kernel GEMM FLOPs count PHYSICAL channels (image 3->4, logits 23->24): the "
@@ -242,7 +254,7 @@ def roofline_leg(step, model, trainer, dtype, psteps=3, layer_table=False):
                                                       "launches_per_step": k[3] // psteps} for k in kern}}}
 
 
-def also_leg(name, workload, encoder, dtype, batch, size, classes, dev, steps=8, warmup=3):
+def also_leg(name, workload, encoder, dtype, batch, size, classes, dev, steps=10, warmup=6):
     """A short informational leg of another BASELINE config in the same process (N=1 only)."""
     step, model, trainer = build_leg(workload, encoder, dtype, batch, size, classes, dev, 0, 1, False)
     dt, ev_ms, loss = timed_region(step, steps, warmup, 1, dev, False)
@@ -256,7 +268,7 @@ def also_leg(name, workload, encoder, dtype, batch, size, classes, dev, steps=8,
            "final_loss": round(float(loss.item()), 5),
            "conv_mfma_util": round(value * gf / 1e3 / peak, 4) if gf else None,
            "roofline": {k: roof[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launches_per_step",
-                                             "avg_launch_us", "ms_per_step")},
+                                             "avg_launch_us", "ms_per_step", "hbm_view")},
            "all_conv_kernels_ms_per_step": roof["all_conv_kernels"]["ms_per_step"]}
     del step, model, trainer
     torch.cuda.empty_cache()

@@ -1,0 +1,33 @@
+#!/bin/bash
+# Collect the round's committed evidence on a GPU box (run through gpurun from the repo root):
+#   bash tools/collect_profiles.sh r02
+# Writes gpurun_out/<tag>_*: bench JSON, rocprofv3 kernel stats (single-stream and overlapped), PMC traffic / MFMA-busy reductions.
+# PMC passes run alone (--pmc with --kernel-trace only), the program itself after `--`.
+set -o pipefail
+TAG=${1:-r02}
+ROOT=${GRAFT_REPO_ROOT:-$PWD}
+OUT=$ROOT/gpurun_out
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+BENCH="python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-also --no-sustain"
+python3 $ROOT/bench.py --steps 30 --warmup 10 > $OUT/${TAG}_bench_n1.json 2> $OUT/${TAG}_bench_n1.err || exit 1
+echo "bench done"
+UDASEG_SERIAL=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_serial -- $BENCH > $OUT/${TAG}_prof_serial.log 2>&1 || exit 1
+cp $(find $OUT/${TAG}_prof_serial -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats_serial.csv
+echo "serial stats done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_ovl -- $BENCH > $OUT/${TAG}_prof_ovl.log 2>&1 || exit 1
+cp $(find $OUT/${TAG}_prof_ovl -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats_overlapped.csv
+python3 $ROOT/tools/trace_neighbors.py $OUT/${TAG}_prof_ovl > $OUT/${TAG}_step_gaps.txt 2>&1
+echo "overlapped stats done"
+UDASEG_SERIAL=1 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_fetch -- $BENCH > $OUT/${TAG}_pmc_fetch.log 2>&1 || exit 1
+echo "pmc fetch done"
+UDASEG_SERIAL=1 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_write -- $BENCH > $OUT/${TAG}_pmc_write.log 2>&1 || exit 1
+echo "pmc write done"
+python3 $ROOT/tools/pmc_traffic.py $(find $OUT/${TAG}_pmc_fetch -name "*counter_collection.csv" | head -1) \
+        $(find $OUT/${TAG}_pmc_write -name "*counter_collection.csv" | head -1) $OUT/${TAG}_pmc_traffic.json || exit 1
+UDASEG_SERIAL=1 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA --kernel-trace --output-format csv \
+        -d $OUT/${TAG}_pmc_mfma -- $BENCH > $OUT/${TAG}_pmc_mfma.log 2>&1 || exit 1
+python3 $ROOT/tools/pmc_mfma.py $(find $OUT/${TAG}_pmc_mfma -name "*counter_collection.csv" | head -1) $OUT/${TAG}_pmc_mfma_util.json || exit 1
+echo "pmc mfma done"
+rm -rf $OUT/${TAG}_prof_serial $OUT/${TAG}_prof_ovl $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write $OUT/${TAG}_pmc_mfma
+ls -la $OUT/${TAG}_*

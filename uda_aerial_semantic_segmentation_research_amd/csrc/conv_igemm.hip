@@ -54,6 +54,12 @@ struct IgemmArgs {
   signed char dy[64];
   signed char dx[64];
   unsigned char wt[64];
+  // The taps of a class are a contiguous run [g_t0, g_t0 + ntaps) of a row-major g_ny x g_nx GRID of offsets
+  // (dy, dx) = (g_dy0 + g_sy * a, g_dx0 + g_sx * b), unit steps of either sign: the whole k x k window (forward), a parity
+  // class of it (strided dgrad), a K-slice of either.  The uniform-tap loop builds each row's tap-validity mask from that
+  // description with a handful of ALU operations; reading dy[] / dx[] in a loop costs one vector memory round trip per tap
+  // (byte-sized kernarg reads are global loads): ~2 us per row, a fifth of a K = 576 tile's life (round 2, ISA + trace).
+  int g_dy0[NCLS], g_dx0[NCLS], g_sy[NCLS], g_sx[NCLS], g_ny[NCLS], g_nx[NCLS], g_t0[NCLS];
   // uniform-tap fast path (ci a multiple of the K-tile: every thread of a block is in the same tap during a K-step)
   int uniform;                 // host-side selector
   unsigned x_bytes, w_bytes;   // operand sizes for the buffer descriptors (range-checked loads: out of range reads 0)
@@ -146,10 +152,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
   const int cM = a.M[cls], cJX = a.JX[cls], cJY = a.JY[cls], cK = a.K[cls], cnt = a.ntaps[cls], toff = a.tap_off[cls];
   const float cinv_jx = a.inv_jx[cls], cinv_jy = a.inv_jy[cls];
 
-  if (tid < 64) {
-    taps[tid] = a.dy[tid];
-    taps[64 + tid] = a.dx[tid];
-    taps[128 + tid] = a.wt[tid];
+  if constexpr (!UNI) {       // the generic loop looks its taps up in LDS; the uniform loop never reads the table
+    if (tid < 64) {
+      taps[tid] = a.dy[tid];
+      taps[64 + tid] = a.dx[tid];
+      taps[128 + tid] = a.wt[tid];
+    }
   }
 
   // ---- per-thread load slots: float4 column kq of rows lrow + 32*p
@@ -183,16 +191,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
   unsigned u_aoff[A_PASS], u_ainv[A_PASS], u_boff[B_PASS];
   unsigned u_acur[A_PASS];   // gather offset of each row for the tap (and source) the loop is in: recomputed when the tap changes
   if constexpr (UNI) {
+    const int gy0 = a.g_dy0[cls], gsy = a.g_sy[cls], gny = a.g_ny[cls];
+    const int gx0 = a.g_dx0[cls], gsx = a.g_sx[cls], gnx = a.g_nx[cls], gt0 = a.g_t0[cls];
 #pragma unroll
     for (int p = 0; p < A_PASS; ++p) {
       unsigned inv = 0xffffffffu;
       if (a_iy[p] > -(1 << 19)) {
-        inv = 0u;
-        for (int t = 0; t < cnt; ++t) {
-          const int iy = a_iy[p] + a.dy[toff + t], ix = a_ix[p] + a.dx[toff + t];
-          const bool ok = (unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi;
-          inv |= (ok ? 0u : 1u) << t;
+        // which grid rows / columns fall inside the image for this output row, then their outer product
+        unsigned yb = 0u, xb = 0u;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          if (q < gny) yb |= ((unsigned)(a_iy[p] + gy0 + gsy * q) < (unsigned)a.hi ? 1u : 0u) << q;
+          if (q < gnx) xb |= ((unsigned)(a_ix[p] + gx0 + gsx * q) < (unsigned)a.wi ? 1u : 0u) << q;
         }
+        unsigned long long valid = 0ull;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (q < gny) valid |= (unsigned long long)((yb >> q) & 1u ? xb : 0u) << (q * gnx);
+        inv = ~(unsigned)(valid >> gt0);        // bit tl = tap tl of this class is outside the image (bits >= ntaps unused)
       }
       u_ainv[p] = inv;
       // rows past the end of the class keep offset 0: with every tap marked invalid their address is 2^31 + (a small tap
@@ -234,7 +250,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
   uint64_t zp = reinterpret_cast<uint64_t>(&g_zero16[0]);
   asm volatile("" : "+s"(zp));
 
-  __syncthreads();  // tap table visible
+  if constexpr (!UNI) __syncthreads();  // tap table visible
 
   __amdgpu_buffer_rsrc_t rsrc_x, rsrc_w, rsrc_x2;
   if constexpr (UNI) {
@@ -243,6 +259,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
     if constexpr (UP) rsrc_x2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x2), 0, (int)a.x2_bytes, 0x00020000);
   }
   int u_tl = 0, u_c0 = 0;                     // uniform path: local tap / byte offset inside the tap of the NEXT tile to load
+  int u_ga = 0, u_gb = 0;                     // ... and that tap's (row, column) in the class's tap grid (fused input only)
+  if constexpr (UP) {
+    u_ga = a.g_t0[cls] / a.g_nx[cls];
+    u_gb = a.g_t0[cls] - u_ga * a.g_nx[cls];
+  }
   const int u_cend = a.ci * ES;
   const int u_ca = UP ? a.up_ca * ES : 0;     // bytes of a virtual pixel that come from the up-sampled source
   auto load_tile = [&](int kt, f32x4* ra, f32x4* rb) {
@@ -251,21 +272,28 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
       // offset only changes with the tap (and, fused input, with the source): it is recomputed then (a uniform branch) and
       // the position inside the tap travels in the load's SCALAR offset -- no vector ALU work per K-step at all.
       const int tl = u_tl, c0 = u_c0;
+      // (dy, dx) of this tap from the grid description: a byte read of a.dy[] / a.dx[] would be a vector memory round trip
+      const int dyt = UP ? a.g_dy0[cls] + a.g_sy[cls] * u_ga : 0, dxt = UP ? a.g_dx0[cls] + a.g_sx[cls] * u_gb : 0;
       u_c0 += BKE * ES;
       if (u_c0 == u_cend) {
         u_c0 = 0;
         ++u_tl;
+        if constexpr (UP) {
+          if (++u_gb == a.g_nx[cls]) {
+            u_gb = 0;
+            ++u_ga;
+          }
+        }
       }
       if constexpr (UP) {
         if (c0 == 0) {                        // new tap, channels [0, up_ca): nearest-x2 source, pixel (iy >> 1, ix >> 1)
-          const int dyt = a.dy[toff + tl], dxt = a.dx[toff + tl], w2 = a.wi >> 1;
+          const int w2 = a.wi >> 1;
 #pragma unroll
           for (int p = 0; p < A_PASS; ++p) {
             const int pix = (a_base[p] >> 2) + ((a_iy[p] + dyt) >> 1) * w2 + ((a_ix[p] + dxt) >> 1);
             u_acur[p] = ((unsigned)pix * (unsigned)u_ca + (unsigned)(kq * 16)) | ((u_ainv[p] >> tl) << 31);
           }
         } else if (c0 == u_ca) {              // same tap, channels [up_ca, ci): the skip tensor at full resolution
-          const int dyt = a.dy[toff + tl], dxt = a.dx[toff + tl];
 #pragma unroll
           for (int p = 0; p < A_PASS; ++p) {
             const int pix = a_base[p] + (a_iy[p] + dyt) * a.wi + (a_ix[p] + dxt);
@@ -637,8 +665,16 @@ static void finish_args(IgemmArgs& a, long long x_elems, long long w_elems) {
   if ((uniform_off() && a.up_ca == 0) || a.ci % bke != 0 || a.up_ca % bke != 0 || total > 32 || x_elems * es > (1LL << 30) ||
       w_elems * es > (1LL << 30))
     return;
-  for (int c = 0; c < a.nclass; ++c)
+  for (int c = 0; c < a.nclass; ++c) {
     if (a.ntaps[c] > 32 || a.K[c] != a.ntaps[c] * a.ci) return;
+    // the class's taps must be the grid run its description claims (they are, for every launch the library builds)
+    if (a.g_nx[c] < 1 || a.g_ny[c] < 1 || a.g_nx[c] > 8 || a.g_ny[c] > 8 || a.g_t0[c] < 0 || a.g_t0[c] + a.ntaps[c] > a.g_nx[c] * a.g_ny[c])
+      return;
+    for (int tl = 0; tl < a.ntaps[c]; ++tl) {
+      const int gi = a.g_t0[c] + tl, ga = gi / a.g_nx[c], gb = gi % a.g_nx[c], t = a.tap_off[c] + tl;
+      if (a.dy[t] != a.g_dy0[c] + a.g_sy[c] * ga || a.dx[t] != a.g_dx0[c] + a.g_sx[c] * gb) return;
+    }
+  }
   for (int t = 0; t < total; ++t) {
     a.tap_xoff[t] = (a.dy[t] * a.wi + a.dx[t]) * a.ci * es;
     a.tap_woff[t] = a.wt[t] * a.ci * es;
@@ -781,6 +817,7 @@ static int conv2d_fwd_impl(const udaseg_conv_desc* d, const void* x, const void*
     a.JY[c] = d->ho; a.JX[c] = d->wo; a.M[c] = M; a.cy[c] = 0; a.cx[c] = 0;
     a.ntaps[c] = t1 - t0; a.K[c] = (t1 - t0) * d->ci; a.tap_off[c] = t0;
     a.inv_jx[c] = 1.0f / d->wo; a.inv_jy[c] = 1.0f / d->ho;
+    a.g_dy0[c] = -d->pad; a.g_dx0[c] = -d->pad; a.g_sy[c] = 1; a.g_sx[c] = 1; a.g_ny[c] = d->kh; a.g_nx[c] = d->kw; a.g_t0[c] = t0;
   }
   prof_begin(0, st);
   if (ns > 1) {
@@ -896,10 +933,14 @@ static int conv2d_dgrad_impl(const udaseg_conv_desc* d, const void* dy, const vo
       const int JY = (d->hi - ph + s - 1) / s, JX = (d->wi - pw + s - 1) / s;
       if (JY <= 0 || JX <= 0) continue;
       const int t0 = ntot;
+      int gny = 0, gnx = 0;      // the class's taps form a gny x gnx grid, dy and dx falling by one per step
       for (int r = 0; r < d->kh; ++r) {
         if ((ph + d->pad - r) % s != 0) continue;
+        ++gny;
+        gnx = 0;
         for (int q = 0; q < d->kw; ++q) {
           if ((pw + d->pad - q) % s != 0) continue;
+          ++gnx;
           a.dy[ntot] = (signed char)((ph + d->pad - r) / s);
           a.dx[ntot] = (signed char)((pw + d->pad - q) / s);
           a.wt[ntot] = (unsigned char)(r * d->kw + q);
@@ -911,6 +952,8 @@ static int conv2d_dgrad_impl(const udaseg_conv_desc* d, const void* dy, const vo
       a.JY[nc] = JY; a.JX[nc] = JX; a.M[nc] = d->n * JY * JX; a.cy[nc] = ph; a.cx[nc] = pw;
       a.ntaps[nc] = nt; a.K[nc] = nt * d->co; a.tap_off[nc] = t0;
       a.inv_jx[nc] = 1.0f / JX; a.inv_jy[nc] = 1.0f / JY;
+      a.g_ny[nc] = nt ? gny : 1; a.g_nx[nc] = nt ? gnx : 1; a.g_t0[nc] = 0;
+      a.g_dy0[nc] = nt ? a.dy[t0] : 0; a.g_dx0[nc] = nt ? a.dx[t0] : 0; a.g_sy[nc] = -1; a.g_sx[nc] = -1;
       ++nc;
     }
   a.nclass = nc;
@@ -931,6 +974,8 @@ static int conv2d_dgrad_impl(const udaseg_conv_desc* d, const void* dy, const vo
         const int t0 = (int)((long long)ntaps * c / ns), t1 = (int)((long long)ntaps * (c + 1) / ns);
         a.JY[c] = a.JY[0]; a.JX[c] = a.JX[0]; a.M[c] = a.M[0]; a.cy[c] = 0; a.cx[c] = 0;
         a.inv_jx[c] = a.inv_jx[0]; a.inv_jy[c] = a.inv_jy[0];
+        a.g_ny[c] = a.g_ny[0]; a.g_nx[c] = a.g_nx[0]; a.g_dy0[c] = a.g_dy0[0]; a.g_dx0[c] = a.g_dx0[0];
+        a.g_sy[c] = -1; a.g_sx[c] = -1; a.g_t0[c] = t0;
         a.ntaps[c] = t1 - t0; a.K[c] = (t1 - t0) * d->co; a.tap_off[c] = t0;
       }
       a.nclass = ns;
