@@ -31,6 +31,7 @@ def bucket_ranges(total, bucket_elems, tail_elems=0):
 
 
 FORCE = False   # tests / 1-GPU rehearsal: issue the collectives even when world == 1
+_COMM_STREAMS = {}
 
 
 def average_(flat, world, group=None):
@@ -71,7 +72,8 @@ class GradAllReducer:
         self._pending = bucket_ranges(P.garena.numel(), self.bucket_elems, self.tail_elems)
         self.launched = []
         if P.garena.is_cuda and self.comm_stream is None:
-            self.comm_stream = torch.cuda.Stream(device=P.garena.device)
+            dev = P.garena.device          # one all-reduce stream per device (see engine._SIDE_STREAMS for why not one per reducer)
+            self.comm_stream = _COMM_STREAMS.get(dev) or _COMM_STREAMS.setdefault(dev, torch.cuda.Stream(device=dev))
 
     def _launch(self, a, b):
         g = self._garena[a:b]

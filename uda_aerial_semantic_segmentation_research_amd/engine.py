@@ -32,6 +32,7 @@ FUSE_BN_REDUCE = os.environ.get("UDASEG_FUSE_BN_REDUCE", "1") != "0"
 PREPACK_DGRAD = os.environ.get("UDASEG_PREPACK", "0") == "1"
 
 
+_SIDE_STREAMS = {}   # device -> the one side HIP stream the weight gradients of every network on that device run on
 _ARENA_OWNERS = {}   # parameter-arena storage pointer -> weakref of the ArenaModule that owns it
 
 
@@ -241,10 +242,14 @@ class ArenaModule(nn.Module):
             self.build_arena()
 
     def _side_stream(self):
-        st = getattr(self, "_side", None)
-        if st is None or st.device != self._arena.device:
-            st = torch.cuda.Stream(device=self._arena.device)
-            self._side = st
+        """The weight-gradient side stream: ONE per device, shared by every network.  HIP multiplexes streams onto a few
+        hardware queues; a fresh stream per network meant that the fourth network of a process (bench.py's cfg 5 leg) got a
+        side stream aliased with the compute stream's queue, where every cross-stream event wait then blocked the
+        compute stream itself: 240 instead of 320 images/s (round 2)."""
+        dev = self._arena.device
+        st = _SIDE_STREAMS.get(dev)
+        if st is None:
+            st = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
         return st
 
     def tick_batchnorm_counters(self):
