@@ -14,14 +14,16 @@
 // Measured (profiles/r01_pmc_traffic.json): the L2 fetches 4-5x the algorithmic bytes here, because the tap tiles of one
 // pixel slab are dealt round-robin to the 8 XCD L2s.  An XCD-aware remap that keeps a slab's tiles on one L2 was tried
 // and ran 5 % SLOWER (80 -> 76 TFLOP/s): the re-fetches are served by the Infinity Cache and do not bound the kernel.
-// Round 2 built the tile that removes the re-reads outright -- one block per (64 co, 64 ci, kernel ROW): the three taps of
-// a row share one staged x row and the dy fragment, operand traffic / 3, 4 LDS reads per 3 MFMAs, 48 MFMAs per barrier,
-// XCD-aware block order -- and measured it on the r18 step (profiles/r02_wgrad_row_tiles.txt): 77-83 TFLOP/s against
-// 95 for this kernel on the same 19 launches.  What bounds these launches is neither the gather nor LDS but the fp32
-// atomics that reduce the pixel splits: their volume is (blocks x tile bytes) = 50 MB per launch either way, at the chip's
-// ~1.3 TB/s atomic rate 38 us of a ~95 us launch; 3072 small blocks run in three rounds and hide two thirds of it behind
-// other blocks' MFMAs, 1024 three-tap blocks finish together and expose all of it (512 blocks: half the atomics, half the
-// occupancy; 2048 / 3072: 100 / 150 MB of atomics).  The kernel was removed again; this one stays.
+// Round 2 built and measured three alternatives on the r18 step (profiles/r02_wgrad_row_tiles.txt), all removed again:
+//  * kernel-row tiles (one block per 64 co x 64 ci x three taps sharing one staged x row and the dy fragment: operand
+//    traffic / 3, 4 LDS reads per 3 MFMAs, 48 MFMAs per barrier, XCD-aware order): 77-83 TFLOP/s against 95 here.  The
+//    partial tiles of the pixel splits are reduced with fp32 atomics, 50 MB per launch for either tiling (38 us at the
+//    chip's ~1.3 TB/s atomic rate): this kernel's 3072 small blocks run in three rounds and hide them (a timing-only build
+//    with plain stores instead: 99.9 vs 95.0 TFLOP/s, the atomics cost 5 %), 1024 three-tap blocks finish together and
+//    expose them;
+//  * transposed staging (pixel-contiguous swizzled LDS rows through a register transpose, 16-byte fragment reads feeding
+//    four MFMAs each): 95.4-95.6 vs 95.6 TFLOP/s -- the fragment-read width is not the bound;
+//  * the same with loads two K-tiles ahead: 89.
 #include <stdlib.h>
 
 #include "common.h"
