@@ -317,6 +317,11 @@ int udaseg_gap_bwd_param(const float* dp, const float* p, const float* pooled, f
                          int accumulate_param, void* stream);
 int udaseg_pack_dgrad_batched_bf16(const float* arena, void* packed, const int* table, int entries, void* stream);
 
+/* ---- diagnosis: while a device buffer of 6 * blocks u64 is registered, every implicit-GEMM launch of at most `blocks` blocks
+ *      writes per block {entry, first tile load, end of K loop, exit} (100 MHz wall-clock ticks), HW_ID and XCC_ID into it
+ *      (tools/igemm_timeline.py).  NULL switches it off.  Not for timed runs. ---- */
+int udaseg_debug_set_timeline(void* buffer, int blocks);
+
 /* ---- small utilities ---- */
 int udaseg_fill_f32(float* p, int64_t count, float value, void* stream);
 int udaseg_axpy_f32(float* y, const float* x, int64_t count, float alpha, void* stream); /* y += alpha*x */

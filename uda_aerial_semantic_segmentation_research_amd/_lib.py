@@ -105,6 +105,7 @@ SIGNATURES = {
     "udaseg_pack_dgrad_batched_bf16": (_I, [_P, _P, _P, _I, _P]),
     "udaseg_set_workspace": (_I, [_P, C.c_size_t]),
     "udaseg_workspace_bytes": (C.c_size_t, [_P]),
+    "udaseg_debug_set_timeline": (_I, [_P, _I]),
     "udaseg_fill_f32": (_I, [_P, _L, _F, _P]),
     "udaseg_axpy_f32": (_I, [_P, _P, _L, _F, _P]),
     "udaseg_prof_enable": (_I, [_I]),

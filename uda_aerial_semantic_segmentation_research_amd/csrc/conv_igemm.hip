@@ -75,6 +75,8 @@ struct IgemmArgs {
   // channels [split_n, co) to y2 with row length co - split_n.  split_n is a multiple of every tile width, or 0.
   void* y2;
   int split_n;
+  // diagnosis (udaseg_debug_set_timeline): per block {entry, first load, end of K loop, exit} in 100 MHz ticks + HW_ID + XCC_ID
+  unsigned long long* timeline;
   // BatchNorm-backward statistics of the layer BEHIND this data gradient (training-mode BN + activation between the
   // previous convolution's output bnb_y and this convolution's input): with g = out * act'(bn(bnb_y)) and
   // xhat = (bnb_y - mean) * rstd the epilogue adds sum(g), sum(g * xhat) per channel into `stats` -- what
@@ -133,6 +135,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
   const int lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
   const int wm = (wave / WAVES_N) * WM, wn = (wave % WAVES_N) * WN;
+  unsigned long long tl0 = 0, tl1 = 0, tl2 = 0;
+  if (a.timeline) tl0 = wall_clock64();
 
   // ---- block -> (class, tile).  Within a class the tile order is XCD-aware: blocks that share blockIdx%8 (one XCD's
   // L2) take a contiguous run of tiles, N-tiles innermost, so an XCD re-reads its own A rows / halos from its own L2.
@@ -379,6 +383,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
     }
   };
 
+  if (a.timeline) tl1 = wall_clock64();
   // invariant at the top of a pair: tile kt sits in LDS buffer 0, tile kt+1 (if any) is in flight in stage S1
   int kt = 0;
   if (nkt > 0) {
@@ -420,6 +425,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
     mfma_tile(0);
   }
   __syncthreads();   // every wave is done with the LDS tiles (the statistics epilogue reuses them)
+  if (a.timeline) tl2 = wall_clock64();
 
   // ---- epilogue: D[i][j] reg v of lane (lr, lh) = C[row = (v&3) + 8*(v>>2) + 4*lh][col = lr]
   const int ccy = a.cy[cls], ccx = a.cx[cls];
@@ -589,9 +595,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
       atomicAdd(rep + a.co + n0 + tid, (double)s2);
     }
   }
+  if (a.timeline && tid == 0) {
+    unsigned long long* t = a.timeline + (size_t)blockIdx.x * 6;
+    t[0] = tl0; t[1] = tl1; t[2] = tl2; t[3] = wall_clock64();
+    t[4] = __builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (0 << 6) | (31 << 11));
+    t[5] = __builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | (31 << 11));
+  }
 }
 
 // ------------------------------------------------------------------------------------------------- host side
+
+static unsigned long long* g_timeline = nullptr;
+static int g_timeline_blocks = 0;
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool BF, bool UNI, bool UP>
 static int launch_cfg_t(const IgemmArgs& a, hipStream_t s) {
@@ -617,6 +632,7 @@ static int launch_cfg_t(const IgemmArgs& a, hipStream_t s) {
     set_error("conv_igemm: split output at channel %d is not a multiple of the %d-wide tile", a.split_n, BN);
     return UDASEG_E_UNSUPPORTED;
   }
+  b.timeline = (g_timeline && b.tile_begin[a.nclass] <= g_timeline_blocks) ? g_timeline : nullptr;
   dim3 grid((unsigned)b.tile_begin[a.nclass]), block(256);
   constexpr int tile_id = (BM == 128 && BN == 128) ? 0 : (BM == 128 && BN == 64) ? 1 : (BM == 64) ? 2 : 3;
   constexpr int kid = BF ? 12 : (UP ? 20 + tile_id : (UNI ? 14 + tile_id : tile_id));
@@ -755,6 +771,12 @@ static int check_desc(const udaseg_conv_desc* d) {
 }  // namespace udaseg
 
 using namespace udaseg;
+
+extern "C" int udaseg_debug_set_timeline(void* buffer, int blocks) {
+  udaseg::g_timeline = static_cast<unsigned long long*>(buffer);
+  udaseg::g_timeline_blocks = buffer ? blocks : 0;
+  return UDASEG_OK;
+}
 
 extern "C" double udaseg_conv_flops(const udaseg_conv_desc* d) {
   if (!d) return 0.0;
