@@ -54,6 +54,10 @@ def main():
             assert rc in ok_codes, (rc, [getattr(d, f) for f, _ in d._fields_])
             calls += 1
         assert lib.udaseg_conv_flops(r) >= 0 and lib.udaseg_workspace_bytes(r) >= 0
+        ok = lib.udaseg_conv2d_dgrad_bnreduce_ok(r)
+        rc = lib.udaseg_conv2d_dgrad_bnreduce(r, P, P, P, P, P, P, P, P, 1, 0.0, P, None)
+        assert ok in (0, 1) and rc in ok_codes and (ok == 1 or rc == -2 or rc == -1), (ok, rc)
+        calls += 2
         # fused decoder input / split output / gradient slices: every split of the input channels
         if d.stride == 1 and d.kh == 3:
             for ca in sorted({d.ci, d.ci // 2, d.ci // 4 * 3, 64, 32, 8, 0, -4}):
@@ -85,6 +89,10 @@ def main():
                 assert rc in ok_codes or rc == 0, rc        # zero-size launches may legitimately return OK
                 calls += 1
     assert lib.udaseg_set_workspace(P, 1 << 20) in ok_codes          # no current device on this box
+    assert lib.udaseg_debug_set_timeline(None, 0) == 0 and lib.udaseg_debug_set_timeline(P, 16) == 0
+    d = desc(8, 128, 128, 64, 64, 3, 1, 1)
+    assert lib.udaseg_conv2d_fwd(C.byref(d), P, P, None, P, 0, 0.0, 0, None) in ok_codes      # with the timeline hook armed
+    assert lib.udaseg_debug_set_timeline(None, 0) == 0
     assert lib.udaseg_last_error() is not None
     print(f"asan host check ok: {calls} calls")
 
