@@ -408,6 +408,29 @@ def test_act_bwd_and_channel_sum(K):
     assert_close(out.cpu(), 2 * dz.sum(dim=(0, 1, 2)), "channel_sum acc", 1e-5)
 
 
+@pytest.mark.parametrize("shape,dtype", [((8, 256, 256, 64), torch.bfloat16), ((8, 64, 64, 256), torch.bfloat16),
+                                         ((4, 128, 128, 128), torch.float32), ((2, 96, 96, 24), torch.float32),
+                                         ((2, 32, 32, 1024), torch.float32)])
+def test_channel_sum_replica_path(K, shape, dtype):
+    """Bias gradients of the discriminator's strided convs (adversarial_trainer.py:85-114 backward): tensors large enough for
+    the replica + fold path (csrc/common.h CHSUM_*), both storage types, overwrite and accumulate, non-zero mean so a lost
+    replica would show."""
+    g = torch.Generator().manual_seed(11)
+    dz = (torch.randn(*shape, generator=g) + 0.25).to(dtype).cuda()
+    ref = dz.double().sum(dim=(0, 1, 2)).float().cpu()
+    out = torch.full((shape[-1],), 7.0, device="cuda")
+    K.channel_sum(dz, out, accumulate=False)
+    assert_close(out.cpu(), ref, "channel_sum", 2e-5)
+    K.channel_sum(dz, out, accumulate=True)
+    assert_close(out.cpu(), 2 * ref, "channel_sum acc", 2e-5)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        K.channel_sum(dz, out, accumulate=False, st=side.cuda_stream)
+    side.synchronize()
+    assert_close(out.cpu(), ref, "channel_sum on a side stream", 2e-5)
+
+
 @pytest.mark.parametrize("shape", [(2, 64, 16, 16), (1, 8, 7, 9), (2, 16, 2, 2)])
 def test_maxpool(K, shape):
     g = torch.Generator().manual_seed(1)

@@ -213,7 +213,8 @@ __global__ void act_bwd_bf16_kernel(const f32x4* __restrict__ dz, const f32x4* _
   }
 }
 
-__global__ void channel_sum_bf16_kernel(const f32x4* __restrict__ x, int64_t n8, int c8, float* __restrict__ out) {
+__global__ void channel_sum_bf16_kernel(const f32x4* __restrict__ x, int64_t n8, int c8, float* __restrict__ out, int replicas) {
+  out += (size_t)(blockIdx.x % replicas) * c8 * 8;
   __shared__ float red[256][8];
   const int64_t T = (int64_t)gridDim.x * blockDim.x;
   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -538,14 +539,34 @@ extern "C" int udaseg_channel_sum_bf16(const void* x, int64_t pixels, int c, flo
   if (rc) return rc;
   UDASEG_CHECK_ARG(x && out, "channel_sum_bf16: NULL pointer");
   hipStream_t st = as_stream(stream);
-  if (!accumulate) {
-    hipError_t e = hipMemsetAsync(out, 0, (size_t)c * sizeof(float), st);
-    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(channel_sum_bf16)");
-  }
   const int64_t n8 = pixels * (c / 8);
-  const StreamShape s = stream_shape(n8, c / 8);
-  hipLaunchKernelGGL(channel_sum_bf16_kernel, dim3(s.grid), dim3(s.bs), 0, st, (const f32x4*)x, n8, s.c4, out);
-  UDASEG_LAUNCH_CHECK("channel_sum_bf16 launch");
+  StreamShape s = stream_shape(n8, c / 8, REDUCE_MAX_BLOCKS);
+  if (s.grid <= CHSUM_DIRECT_BLOCKS) {
+    if (!accumulate) {
+      hipError_t e = hipMemsetAsync(out, 0, (size_t)c * sizeof(float), st);
+      if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(channel_sum_bf16)");
+    }
+    hipLaunchKernelGGL(channel_sum_bf16_kernel, dim3(s.grid), dim3(s.bs), 0, st, (const f32x4*)x, n8, s.c4, out, 1);
+    UDASEG_LAUNCH_CHECK("channel_sum_bf16 launch");
+    return UDASEG_OK;
+  }
+  float* rep = nullptr;
+  const size_t rep_bytes = (size_t)CHSUM_REPLICAS * c * sizeof(float);
+  hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&rep), rep_bytes, st);
+  if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(channel_sum_bf16)");
+  e = hipMemsetAsync(rep, 0, rep_bytes, st);
+  if (e != hipSuccess) {
+    (void)hipFreeAsync(rep, st);
+    return hip_fail(e, "hipMemsetAsync(channel_sum_bf16)");
+  }
+  hipLaunchKernelGGL(channel_sum_bf16_kernel, dim3(s.grid), dim3(s.bs), 0, st, (const f32x4*)x, n8, s.c4, rep, CHSUM_REPLICAS);
+  hipError_t e1 = hipGetLastError();
+  hipLaunchKernelGGL(fold_replicas_kernel, dim3((c + 255) / 256), dim3(256), 0, st, rep, c, out, accumulate);
+  hipError_t e2 = hipGetLastError();
+  e = hipFreeAsync(rep, st);
+  if (e1 != hipSuccess) return hip_fail(e1, "channel_sum_bf16 launch");
+  if (e2 != hipSuccess) return hip_fail(e2, "channel_sum_bf16 fold launch");
+  if (e != hipSuccess) return hip_fail(e, "hipFreeAsync(channel_sum_bf16)");
   return UDASEG_OK;
 }
 

@@ -304,7 +304,8 @@ __global__ void act_bwd_kernel(const f32x4* __restrict__ dz, const f32x4* __rest
   }
 }
 
-__global__ void channel_sum_kernel(const f32x4* __restrict__ x, int64_t n4, int c4, float* __restrict__ out) {
+__global__ void channel_sum_kernel(const f32x4* __restrict__ x, int64_t n4, int c4, float* __restrict__ out, int replicas) {
+  out += (size_t)(blockIdx.x % replicas) * c4 * 4;
   __shared__ float4 red[256];
   const int64_t T = (int64_t)gridDim.x * blockDim.x;
   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -461,13 +462,33 @@ extern "C" int udaseg_channel_sum(const float* x, int64_t pixels, int c, float* 
   if (rc) return rc;
   UDASEG_CHECK_ARG(x && out, "channel_sum: NULL pointer");
   hipStream_t st = as_stream(stream);
-  if (!accumulate) {
-    hipError_t e = hipMemsetAsync(out, 0, (size_t)c * sizeof(float), st);
-    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(channel_sum)");
-  }
   const int64_t n4 = pixels * (c / 4);
-  const StreamShape s = stream_shape(n4, c / 4);
-  hipLaunchKernelGGL(channel_sum_kernel, dim3(s.grid), dim3(s.bs), 0, st, (const f32x4*)x, n4, s.c4, out);
-  UDASEG_LAUNCH_CHECK("channel_sum launch");
+  StreamShape s = stream_shape(n4, c / 4, REDUCE_MAX_BLOCKS);
+  if (s.grid <= CHSUM_DIRECT_BLOCKS) {
+    if (!accumulate) {
+      hipError_t e = hipMemsetAsync(out, 0, (size_t)c * sizeof(float), st);
+      if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(channel_sum)");
+    }
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(s.grid), dim3(s.bs), 0, st, (const f32x4*)x, n4, s.c4, out, 1);
+    UDASEG_LAUNCH_CHECK("channel_sum launch");
+    return UDASEG_OK;
+  }
+  float* rep = nullptr;
+  const size_t rep_bytes = (size_t)CHSUM_REPLICAS * c * sizeof(float);
+  hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&rep), rep_bytes, st);
+  if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(channel_sum)");
+  e = hipMemsetAsync(rep, 0, rep_bytes, st);
+  if (e != hipSuccess) {
+    (void)hipFreeAsync(rep, st);
+    return hip_fail(e, "hipMemsetAsync(channel_sum)");
+  }
+  hipLaunchKernelGGL(channel_sum_kernel, dim3(s.grid), dim3(s.bs), 0, st, (const f32x4*)x, n4, s.c4, rep, CHSUM_REPLICAS);
+  hipError_t e1 = hipGetLastError();
+  hipLaunchKernelGGL(fold_replicas_kernel, dim3((c + 255) / 256), dim3(256), 0, st, rep, c, out, accumulate);
+  hipError_t e2 = hipGetLastError();
+  e = hipFreeAsync(rep, st);
+  if (e1 != hipSuccess) return hip_fail(e1, "channel_sum launch");
+  if (e2 != hipSuccess) return hip_fail(e2, "channel_sum fold launch");
+  if (e != hipSuccess) return hip_fail(e, "hipFreeAsync(channel_sum)");
   return UDASEG_OK;
 }
