@@ -29,9 +29,10 @@ def main():
     buf = torch.zeros(cap * 6, dtype=torch.int64, device="cuda")
     for (n, h, w, ci, co, k, s, p) in shapes:
         d = K.conv_desc(n, h, w, ci, co, k, s, p)
-        x = torch.randn(n, h, w, ci, device="cuda")
-        wt = torch.randn(co, k, k, ci, device="cuda") * 0.05
-        y = torch.empty(n, d.ho, d.wo, co, device="cuda")
+        dt = torch.bfloat16 if os.environ.get("TL_DTYPE") == "bf16" else torch.float32     # TL_DTYPE=bf16: the bf16 instantiation
+        x = torch.randn(n, h, w, ci, device="cuda").to(dt)
+        wt = (torch.randn(co, k, k, ci, device="cuda") * 0.05).to(dt)
+        y = torch.empty(n, d.ho, d.wo, co, device="cuda", dtype=dt)
         for _ in range(5):
             K.conv2d_fwd(d, x, wt, None, y)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

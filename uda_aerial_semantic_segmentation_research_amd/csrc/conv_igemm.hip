@@ -452,6 +452,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
     fast_epi = a.dense_out && !a.atomic_out && !a.accumulate && a.residual == nullptr && m0 + BM <= cM && n0 + BN <= a.co &&
                (long long)cM * a.co * 4 < (1LL << 31);
   }
+  bool lds_epi = false;
+  if constexpr (BF) {
+    lds_epi = !a.atomic_out && !a.accumulate && a.residual == nullptr && !a.out_f32 && (a.co & 7) == 0 && (yld & 7) == 0 &&
+              (nsub & 7) == 0 && (reinterpret_cast<uintptr_t>(yb) & 15) == 0;
+  }
   if (fast_epi) {
     __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(yb, 0, cM * yld * 4, 0x00020000);
     const int row_bytes = yld * 4;
@@ -510,6 +515,67 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
           }
         }
       }
+  } else if (lds_epi) {
+    // bf16 output through LDS: the accumulator layout gives a lane ONE column, so direct stores are 2-byte scalars with
+    // per-element index arithmetic -- at bf16 MFMA rates that epilogue was 85 % of a K = 576 layer (35 of 41 us, r02 probe).
+    // Here: bias / statistics / activation on the fp32 accumulators, neighbouring lanes swap one value (DPP) so that every
+    // lane owns a (column pair, row) dword, the tile is staged row-major in the free K-loop LDS and leaves as 16-byte
+    // row-contiguous stores; the output pixel of a row (strided data-gradient classes) is computed once per row.
+    if constexpr (BF) {
+      constexpr int TS = BN / 2 + 4;                 // dwords per staged row: rows r, r+1, r+4, r+5 of one store spread over the banks
+      static_assert(BM * TS <= 2 * (BM + BN) * LDS_LD, "staged output tile fits the K-loop buffers");
+      unsigned* T = reinterpret_cast<unsigned*>(As);
+      const bool inside = m0 + BM <= cM;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int n = n0 + wn + j * 32 + lr;
+          const float bv = (a.bias != nullptr && n < a.co) ? a.bias[n] : 0.f;
+          const int tr0 = wm + i * 32 + 4 * lh;
+          const int cd = (wn + j * 32 + lr) >> 1;
+#pragma unroll
+          for (int v = 0; v < 16; v += 2) {
+            const int tr = tr0 + (v & 3) + 8 * (v >> 2);
+            float w0 = acc[i][j][v] + bv, w1 = acc[i][j][v + 1] + bv;
+            if (a.stats != nullptr) {                // from the fp32 accumulator, before rounding; rows past the class are no outputs
+              const float q0 = (inside || m0 + tr < cM) ? w0 : 0.f, q1 = (inside || m0 + tr + 1 < cM) ? w1 : 0.f;
+              ssum[j] += q0 + q1;
+              ssq[j] = __builtin_fmaf(q0, q0, __builtin_fmaf(q1, q1, ssq[j]));
+            }
+            w0 = act_apply(w0, a.act, a.slope);
+            w1 = act_apply(w1, a.act, a.slope);
+            const float send = (lr & 1) ? w0 : w1;
+            const float recv = __shfl_xor(send, 1, 64);
+            const float lo = (lr & 1) ? recv : w0, hi = (lr & 1) ? w1 : recv;
+            const unsigned d = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)lo) |
+                               ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)hi) << 16);
+            T[(tr + (lr & 1)) * TS + cd] = d;
+          }
+        }
+      __syncthreads();
+      constexpr int CH = BN / 8, RPP = 256 / CH;     // 16-byte chunks per row, rows per pass
+      const int ch = tid % CH;
+      const int n = n0 + ch * 8;
+      if (n < a.co) {
+#pragma unroll
+        for (int r = tid / CH; r < BM; r += RPP) {
+          const int m = m0 + r;
+          if (m < cM) {
+            size_t pix = (size_t)m;
+            if (!a.dense_out) {
+              const int t1 = fast_div(m, cJX, cinv_jx);
+              const int jx = m - t1 * cJX;
+              const int ni = fast_div(t1, cJY, cinv_jy);
+              const int jy = t1 - ni * cJY;
+              pix = ((size_t)ni * a.ho + (size_t)(ccy + a.sy_o * jy)) * a.wo + (size_t)(ccx + a.sx_o * jx);
+            }
+            const f32x4 d = *reinterpret_cast<const f32x4*>(T + r * TS + ch * 4);
+            *reinterpret_cast<f32x4*>(static_cast<__bf16*>(yb) + pix * (size_t)yld + (size_t)(n - nsub)) = d;
+          }
+        }
+      }
+    }
   } else
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
