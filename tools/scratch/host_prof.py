@@ -7,6 +7,7 @@ wl, enc, dt, size = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
 step, model, trainer = bench.build_leg(wl, enc, dt, 8, size, 23, dev, 0, 1, False)
 for _ in range(5): step()
 torch.cuda.synchronize()
+torch.autograd.set_multithreading_enabled(False)
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(10):

@@ -485,7 +485,10 @@ static int launch_wgrad(WgradArgs a, int accumulate, hipStream_t s, bool bf16 = 
     target = e ? atoi(e) : 3072;  // measured sweep 512..8192: 68.7 / 79.4 / 80.3 / 85.9 / 87.0 / 89.1 / 88.8 / 88.1 TFLOP/s
     if (target < 64) target = 3072;
   }
-  int splits = cdiv(target, tiles);
+  // bf16: the MFMA phase of a split is 16x shorter, so the fp32 atomics of the partial tiles (blocks x 16 KB at ~1.3 TB/s)
+  // are the launch: 512 blocks measured best (r18 8x512^2 step: 256 / 512 / 768 / 1024 / 2048 / 3072 blocks ->
+  // 1285 / 1398 / 1366 / 1353 / 1326 / 1285 images/s; r50 768^2: 337 / 344 / 338 / 335 / 336 / 332)
+  int splits = cdiv(bf16 && getenv("UDASEG_WGRAD_BLOCKS") == nullptr ? 512 : target, tiles);
   const int max_splits = cdiv(a.M, 256);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
