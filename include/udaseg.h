@@ -168,6 +168,11 @@ int udaseg_act_bwd(const float* dz, const float* z, float* dy, int64_t count, in
 /* out[c] (+)= sum over pixels of x[p][c]  (bias gradients) */
 int udaseg_channel_sum(const float* x, int64_t pixels, int c, float* out,
                        int accumulate, void* stream);
+/* same, with the caller's scratch for the partial sums of large inputs (udaseg_channel_sum_scratch_bytes(c) bytes, owned by
+   `stream` until the call's work has run); the plain form takes a stream-ordered allocation instead */
+int udaseg_channel_sum_ws(const float* x, int64_t pixels, int c, float* out, int accumulate, float* scratch,
+                          size_t scratch_bytes, void* stream);
+size_t udaseg_channel_sum_scratch_bytes(int c);
 
 /* ---- pooling / resize glue inside smp.Unet ---- */
 /* max_pool2d(3, 2, 1): y[n,ho,wo,c], idx = argmax tap (0..8, first max in scan order) */
@@ -302,6 +307,8 @@ int udaseg_bn_bwd_apply_bf16(const void* dz, const void* z, const void* y, const
                              int accumulate_param, void* stream);
 int udaseg_act_bwd_bf16(const void* dz, const void* z, void* dy, int64_t count, int act, float slope, void* stream);
 int udaseg_channel_sum_bf16(const void* x, int64_t pixels, int c, float* out, int accumulate, void* stream);
+int udaseg_channel_sum_bf16_ws(const void* x, int64_t pixels, int c, float* out, int accumulate, float* scratch,
+                               size_t scratch_bytes, void* stream);
 int udaseg_nchw_to_nhwc_bf16(const float* x, void* y, int n, int c, int h, int w, int cpad, void* stream);
 int udaseg_cast_f32_to_bf16(const float* x, void* y, int64_t count, void* stream);
 int udaseg_maxpool3x3s2_fwd_bf16(const void* x, void* y, uint8_t* idx, int n, int h, int w, int c, void* stream);

@@ -15,4 +15,4 @@ for _ in range(10):
     torch.cuda.synchronize()     # so that queue back-pressure does not show up as host time
 pr.disable()
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(35)
+st.sort_stats("cumtime").print_stats(60)

@@ -58,6 +58,8 @@ SIGNATURES = {
     "udaseg_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _I, _I, _I, _P]),
     "udaseg_act_bwd": (_I, [_P, _P, _P, _L, _I, _F, _P]),
     "udaseg_channel_sum": (_I, [_P, _L, _I, _P, _I, _P]),
+    "udaseg_channel_sum_ws": (_I, [_P, _L, _I, _P, _I, _P, C.c_size_t, _P]),
+    "udaseg_channel_sum_scratch_bytes": (C.c_size_t, [_I]),
     "udaseg_maxpool3x3s2_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "udaseg_maxpool3x3s2_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "udaseg_upsample2x_concat_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
@@ -93,6 +95,7 @@ SIGNATURES = {
     "udaseg_bn_bwd_apply_bf16": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _I, _I, _I, _P]),
     "udaseg_act_bwd_bf16": (_I, [_P, _P, _P, _L, _I, _F, _P]),
     "udaseg_channel_sum_bf16": (_I, [_P, _L, _I, _P, _I, _P]),
+    "udaseg_channel_sum_bf16_ws": (_I, [_P, _L, _I, _P, _I, _P, C.c_size_t, _P]),
     "udaseg_nchw_to_nhwc_bf16": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "udaseg_cast_f32_to_bf16": (_I, [_P, _P, _L, _P]),
     "udaseg_maxpool3x3s2_fwd_bf16": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),

@@ -534,7 +534,8 @@ extern "C" int udaseg_act_bwd_bf16(const void* dz, const void* z, void* dy, int6
   return UDASEG_OK;
 }
 
-extern "C" int udaseg_channel_sum_bf16(const void* x, int64_t pixels, int c, float* out, int accumulate, void* stream) {
+static int channel_sum_bf16_impl(const void* x, int64_t pixels, int c, float* out, int accumulate, float* scratch, size_t scratch_bytes,
+                            void* stream) {
   int rc = check_pc8(pixels, c, "channel_sum_bf16");
   if (rc) return rc;
   UDASEG_CHECK_ARG(x && out, "channel_sum_bf16: NULL pointer");
@@ -550,24 +551,39 @@ extern "C" int udaseg_channel_sum_bf16(const void* x, int64_t pixels, int c, flo
     UDASEG_LAUNCH_CHECK("channel_sum_bf16 launch");
     return UDASEG_OK;
   }
-  float* rep = nullptr;
+  // replicas of the output in the caller's scratch (stream-ordered ownership is the caller's), or in a stream-ordered allocation
   const size_t rep_bytes = (size_t)CHSUM_REPLICAS * c * sizeof(float);
-  hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&rep), rep_bytes, st);
-  if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(channel_sum_bf16)");
-  e = hipMemsetAsync(rep, 0, rep_bytes, st);
-  if (e != hipSuccess) {
-    (void)hipFreeAsync(rep, st);
-    return hip_fail(e, "hipMemsetAsync(channel_sum_bf16)");
+  float* rep = scratch;
+  if (rep != nullptr) {
+    UDASEG_CHECK_ARG(scratch_bytes >= rep_bytes, "channel_sum_bf16: scratch of %zu bytes, need %zu", scratch_bytes, rep_bytes);
+  } else {
+    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&rep), rep_bytes, st);
+    if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(channel_sum_bf16)");
   }
-  hipLaunchKernelGGL(channel_sum_bf16_kernel, dim3(s.grid), dim3(s.bs), 0, st, (const f32x4*)x, n8, s.c4, rep, CHSUM_REPLICAS);
-  hipError_t e1 = hipGetLastError();
-  hipLaunchKernelGGL(fold_replicas_kernel, dim3((c + 255) / 256), dim3(256), 0, st, rep, c, out, accumulate);
-  hipError_t e2 = hipGetLastError();
-  e = hipFreeAsync(rep, st);
+  hipError_t e = hipMemsetAsync(rep, 0, rep_bytes, st);
+  hipError_t e1 = hipSuccess, e2 = hipSuccess;
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(channel_sum_bf16_kernel, dim3(s.grid), dim3(s.bs), 0, st, (const f32x4*)x, n8, s.c4, rep, CHSUM_REPLICAS);
+    e1 = hipGetLastError();
+    hipLaunchKernelGGL(fold_replicas_kernel, dim3((c + 255) / 256), dim3(256), 0, st, rep, c, out, accumulate);
+    e2 = hipGetLastError();
+  }
+  hipError_t e3 = scratch == nullptr ? hipFreeAsync(rep, st) : hipSuccess;
+  if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(channel_sum_bf16)");
   if (e1 != hipSuccess) return hip_fail(e1, "channel_sum_bf16 launch");
   if (e2 != hipSuccess) return hip_fail(e2, "channel_sum_bf16 fold launch");
-  if (e != hipSuccess) return hip_fail(e, "hipFreeAsync(channel_sum_bf16)");
+  if (e3 != hipSuccess) return hip_fail(e3, "hipFreeAsync(channel_sum_bf16)");
   return UDASEG_OK;
+}
+
+extern "C" int udaseg_channel_sum_bf16(const void* x, int64_t pixels, int c, float* out, int accumulate, void* stream) {
+  return channel_sum_bf16_impl(x, pixels, c, out, accumulate, nullptr, 0, stream);
+}
+
+extern "C" int udaseg_channel_sum_bf16_ws(const void* x, int64_t pixels, int c, float* out, int accumulate, float* scratch,
+                                size_t scratch_bytes, void* stream) {
+  UDASEG_CHECK_ARG(scratch != nullptr, "channel_sum_bf16_ws: NULL scratch");
+  return channel_sum_bf16_impl(x, pixels, c, out, accumulate, scratch, scratch_bytes, stream);
 }
 
 extern "C" int udaseg_nchw_to_nhwc_bf16(const float* x, void* y, int n, int c, int h, int w, int cpad, void* stream) {

@@ -457,7 +457,8 @@ extern "C" int udaseg_act_bwd(const float* dz, const float* z, float* dy, int64_
   return UDASEG_OK;
 }
 
-extern "C" int udaseg_channel_sum(const float* x, int64_t pixels, int c, float* out, int accumulate, void* stream) {
+static int channel_sum_impl(const float* x, int64_t pixels, int c, float* out, int accumulate, float* scratch, size_t scratch_bytes,
+                            void* stream) {
   int rc = check_pc(pixels, c, "channel_sum");
   if (rc) return rc;
   UDASEG_CHECK_ARG(x && out, "channel_sum: NULL pointer");
@@ -473,22 +474,39 @@ extern "C" int udaseg_channel_sum(const float* x, int64_t pixels, int c, float* 
     UDASEG_LAUNCH_CHECK("channel_sum launch");
     return UDASEG_OK;
   }
-  float* rep = nullptr;
+  // replicas of the output in the caller's scratch (stream-ordered ownership is the caller's), or in a stream-ordered allocation
   const size_t rep_bytes = (size_t)CHSUM_REPLICAS * c * sizeof(float);
-  hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&rep), rep_bytes, st);
-  if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(channel_sum)");
-  e = hipMemsetAsync(rep, 0, rep_bytes, st);
-  if (e != hipSuccess) {
-    (void)hipFreeAsync(rep, st);
-    return hip_fail(e, "hipMemsetAsync(channel_sum)");
+  float* rep = scratch;
+  if (rep != nullptr) {
+    UDASEG_CHECK_ARG(scratch_bytes >= rep_bytes, "channel_sum: scratch of %zu bytes, need %zu", scratch_bytes, rep_bytes);
+  } else {
+    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&rep), rep_bytes, st);
+    if (e != hipSuccess) return hip_fail(e, "hipMallocAsync(channel_sum)");
   }
-  hipLaunchKernelGGL(channel_sum_kernel, dim3(s.grid), dim3(s.bs), 0, st, (const f32x4*)x, n4, s.c4, rep, CHSUM_REPLICAS);
-  hipError_t e1 = hipGetLastError();
-  hipLaunchKernelGGL(fold_replicas_kernel, dim3((c + 255) / 256), dim3(256), 0, st, rep, c, out, accumulate);
-  hipError_t e2 = hipGetLastError();
-  e = hipFreeAsync(rep, st);
+  hipError_t e = hipMemsetAsync(rep, 0, rep_bytes, st);
+  hipError_t e1 = hipSuccess, e2 = hipSuccess;
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(s.grid), dim3(s.bs), 0, st, (const f32x4*)x, n4, s.c4, rep, CHSUM_REPLICAS);
+    e1 = hipGetLastError();
+    hipLaunchKernelGGL(fold_replicas_kernel, dim3((c + 255) / 256), dim3(256), 0, st, rep, c, out, accumulate);
+    e2 = hipGetLastError();
+  }
+  hipError_t e3 = scratch == nullptr ? hipFreeAsync(rep, st) : hipSuccess;
+  if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(channel_sum)");
   if (e1 != hipSuccess) return hip_fail(e1, "channel_sum launch");
   if (e2 != hipSuccess) return hip_fail(e2, "channel_sum fold launch");
-  if (e != hipSuccess) return hip_fail(e, "hipFreeAsync(channel_sum)");
+  if (e3 != hipSuccess) return hip_fail(e3, "hipFreeAsync(channel_sum)");
   return UDASEG_OK;
+}
+
+extern "C" size_t udaseg_channel_sum_scratch_bytes(int c) { return c > 0 ? (size_t)CHSUM_REPLICAS * c * sizeof(float) : 0; }
+
+extern "C" int udaseg_channel_sum(const float* x, int64_t pixels, int c, float* out, int accumulate, void* stream) {
+  return channel_sum_impl(x, pixels, c, out, accumulate, nullptr, 0, stream);
+}
+
+extern "C" int udaseg_channel_sum_ws(const float* x, int64_t pixels, int c, float* out, int accumulate, float* scratch,
+                                size_t scratch_bytes, void* stream) {
+  UDASEG_CHECK_ARG(scratch != nullptr, "channel_sum_ws: NULL scratch");
+  return channel_sum_impl(x, pixels, c, out, accumulate, scratch, scratch_bytes, stream);
 }

@@ -271,14 +271,21 @@ def act_bwd(dz, z, dy, act, slope, st=None):
                                       st if st is not None else stream()), "act_bwd")
 
 
+_CHSUM_SCRATCH = {}          # (device index, stream handle) -> persistent fp32 scratch for channel_sum's partial sums
+
+
 def channel_sum(x, out, accumulate=False, st=None):
+    """out[c] (+)= sum over pixels.  Large inputs reduce through 16 replicas of ``out`` in a scratch that belongs to the
+    stream the call runs on (kept per stream: calls on one stream are ordered, calls on different streams never share it)."""
     c = x.shape[-1]
-    if x.dtype == torch.bfloat16:
-        check(_lib.load().udaseg_channel_sum_bf16(x.data_ptr(), x.numel() // c, c, out.data_ptr(), int(accumulate),
-                                                   st if st is not None else stream()), "channel_sum_bf16")
-        return
-    check(_lib.load().udaseg_channel_sum(x.data_ptr(), x.numel() // c, c, out.data_ptr(), int(accumulate),
-                                          st if st is not None else stream()), "channel_sum")
+    st = st if st is not None else stream()
+    key = (x.device.index, st)
+    ws = _CHSUM_SCRATCH.get(key)
+    need = 16 * c
+    if ws is None or ws.numel() < need:
+        ws = _CHSUM_SCRATCH[key] = torch.empty(max(need, 16 * 2048), dtype=torch.float32, device=x.device)
+    fn = _lib.load().udaseg_channel_sum_bf16_ws if x.dtype == torch.bfloat16 else _lib.load().udaseg_channel_sum_ws
+    check(fn(x.data_ptr(), x.numel() // c, c, out.data_ptr(), int(accumulate), ws.data_ptr(), ws.numel() * 4, st), "channel_sum")
 
 
 def maxpool_fwd(x, st=None):
