@@ -89,10 +89,10 @@ __global__ void bn_apply_bf16_kernel(const f32x4* __restrict__ y, const double* 
     sc[e] = coef[q * 8 + e];
     sh[e] = coef[C + q * 8 + e];
   }
-  for (int64_t i = g; i < n8; i += T) {
+  auto body = [&](int64_t i, const f32x4 yv, const f32x4 rv) {
     float v[8], r[8];
-    unpack8(y[i], v);
-    if (residual) unpack8(residual[i], r);
+    unpack8(yv, v);
+    if (residual) unpack8(rv, r);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float t = v[e] * sc[e] + sh[e];
@@ -100,7 +100,24 @@ __global__ void bn_apply_bf16_kernel(const f32x4* __restrict__ y, const double* 
       v[e] = act_apply(t, act, slope);
     }
     z[i] = pack8(v);
+  };
+  const f32x4 zero = {0, 0, 0, 0};
+  int64_t i = g;
+  for (; i + 3 * T < n8; i += 4 * T) {     // four independent 16-byte loads per array in flight per thread
+    f32x4 a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      a[u] = y[i + u * T];
+      b[u] = zero;
+    }
+    if (residual) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) b[u] = residual[i + u * T];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) body(i + u * T, a[u], b[u]);
   }
+  for (; i < n8; i += T) body(i, y[i], residual ? residual[i] : zero);
 }
 
 __global__ void bn_bwd_reduce_bf16_kernel(const f32x4* __restrict__ dz, const f32x4* __restrict__ z,
@@ -118,11 +135,11 @@ __global__ void bn_bwd_reduce_bf16_kernel(const f32x4* __restrict__ dz, const f3
     rstd[e] = save_rstd[q * 8 + e];
   }
   d8 sg = {{0, 0, 0, 0, 0, 0, 0, 0}}, sgx = {{0, 0, 0, 0, 0, 0, 0, 0}};
-  for (int64_t i = g; i < n8; i += T) {
+  auto body = [&](const f32x4 gv, const f32x4 yv, const f32x4 zv) {
     float gz[8], zz[8], yy[8];
-    unpack8(dz[i], gz);
-    unpack8(y[i], yy);
-    if (act != UDASEG_ACT_NONE) unpack8(z[i], zz);
+    unpack8(gv, gz);
+    unpack8(yv, yy);
+    if (act != UDASEG_ACT_NONE) unpack8(zv, zz);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float gg = gz[e];
@@ -131,7 +148,26 @@ __global__ void bn_bwd_reduce_bf16_kernel(const f32x4* __restrict__ dz, const f3
       sg.v[e] += (double)gg;
       sgx.v[e] += (double)gg * (double)xh;
     }
+  };
+  const f32x4 zero = {0, 0, 0, 0};
+  const bool need_z = act != UDASEG_ACT_NONE;
+  int64_t i = g;
+  for (; i + 3 * T < n8; i += 4 * T) {     // four independent iterations of loads in flight per thread, same summation order
+    f32x4 a[4], b[4], c[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      a[u] = dz[i + u * T];
+      b[u] = y[i + u * T];
+      c[u] = zero;
+    }
+    if (need_z) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) c[u] = z[i + u * T];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) body(a[u], b[u], c[u]);
   }
+  for (; i < n8; i += T) body(dz[i], y[i], need_z ? z[i] : zero);
   double* rep = bsums + (size_t)(blockIdx.x % BN_REPLICAS) * 2 * c8 * 8;
   block_fold_add8(sg, rep, c8, q, red);
   block_fold_add8(sgx, rep + (size_t)c8 * 8, c8, q, red);
@@ -175,12 +211,12 @@ __global__ void bn_bwd_apply_bf16_kernel(const f32x4* __restrict__ dz, const f32
     const int c = q * 8 + e;
     mean[e] = coef[c]; rstd[e] = coef[C + c]; scale[e] = coef[2 * C + c]; mg[e] = coef[3 * C + c]; mgx[e] = coef[4 * C + c];
   }
-  for (int64_t i = g; i < n8; i += T) {
+  auto body = [&](int64_t i, const f32x4 gv, const f32x4 yv, const f32x4 zv, const f32x4 ov, const f32x4 rv) {
     float gz[8], zz[8], yy[8], out[8], old[8];
-    unpack8(dz[i], gz);
-    unpack8(y[i], yy);
-    if (act != UDASEG_ACT_NONE) unpack8(z[i], zz);
-    if (acc_dy) unpack8(dy[i], old);
+    unpack8(gv, gz);
+    unpack8(yv, yy);
+    if (act != UDASEG_ACT_NONE) unpack8(zv, zz);
+    if (acc_dy) unpack8(ov, old);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       if (act != UDASEG_ACT_NONE) gz[e] *= act_grad(zz[e], act, slope);
@@ -191,13 +227,16 @@ __global__ void bn_bwd_apply_bf16_kernel(const f32x4* __restrict__ dz, const f32
     dy[i] = pack8(out);
     if (dres) {
       if (acc_dres) {
-        unpack8(dres[i], old);
+        unpack8(rv, old);
 #pragma unroll
         for (int e = 0; e < 8; ++e) gz[e] += old[e];
       }
       dres[i] = pack8(gz);
     }
-  }
+  };
+  const f32x4 zero = {0, 0, 0, 0};       // plain loop: see bn_bwd_apply_kernel (the four-deep unroll lost here)
+  const bool need_z = act != UDASEG_ACT_NONE, need_res = dres != nullptr && acc_dres;
+  for (int64_t i = g; i < n8; i += T) body(i, dz[i], y[i], need_z ? z[i] : zero, acc_dy ? dy[i] : zero, need_res ? dres[i] : zero);
 }
 
 __global__ void act_bwd_bf16_kernel(const f32x4* __restrict__ dz, const f32x4* __restrict__ z, f32x4* __restrict__ dy,

@@ -69,25 +69,24 @@ __global__ void bn_apply_kernel(const f32x4* __restrict__ y, const double* __res
                                 float* save_mean, float* save_rstd, int act, float slope) {
   extern __shared__ __attribute__((aligned(16))) float4 coef[];  // [2][c4]: scale, shift
   const double inv = 1.0 / (double)pixels;
-  for (int q = threadIdx.x; q < c4; q += blockDim.x) {
-    float4 sc, sh;
-    float* scp = reinterpret_cast<float*>(&sc);
-    float* shp = reinterpret_cast<float*>(&sh);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int c = q * 4 + e;
+  // one CHANNEL per thread (not one quad: four times the threads share the replica sums, 32 independent loads each)
+  {
+    float* cf = reinterpret_cast<float*>(coef);
+    const int C = c4 * 4;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
       double s1 = 0.0, s2 = 0.0;
 #pragma unroll
       for (int r = 0; r < BN_REPLICAS; ++r) {
-        s1 += sums[(size_t)r * 2 * c4 * 4 + c];
-        s2 += sums[(size_t)r * 2 * c4 * 4 + (size_t)c4 * 4 + c];
+        s1 += sums[(size_t)r * 2 * C + c];
+        s2 += sums[(size_t)r * 2 * C + C + c];
       }
       const double m = s1 * inv;
       double var = s2 * inv - m * m;
       var = var > 0.0 ? var : 0.0;
       const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-      scp[e] = gamma[c] * rstd;
-      shp[e] = beta[c] - (float)m * scp[e];
+      const float sc = gamma[c] * rstd;
+      cf[c] = sc;
+      cf[C + c] = beta[c] - (float)m * sc;
       if (blockIdx.x == 0) {  // one owner per channel
         if (save_mean) save_mean[c] = (float)m;
         if (save_rstd) save_rstd[c] = rstd;
@@ -99,8 +98,6 @@ __global__ void bn_apply_kernel(const f32x4* __restrict__ y, const double* __res
         }
       }
     }
-    coef[q] = sc;
-    coef[c4 + q] = sh;
   }
   __syncthreads();
   const int64_t T = (int64_t)gridDim.x * blockDim.x;
@@ -188,14 +185,10 @@ __global__ void bn_bwd_reduce_kernel(const f32x4* __restrict__ dz, const f32x4* 
     }
   }
   d4 sg = {{0, 0, 0, 0}}, sgx = {{0, 0, 0, 0}};
-  for (int64_t i = g; i < n4; i += T) {
-    f32x4 gz = dz[i];
-    const f32x4 yy = y[i];
+  auto body = [&](f32x4 gz, const f32x4 yy, const f32x4 zin) {
     if (act != UDASEG_ACT_NONE) {
-      f32x4 zz;
-      if (z) {
-        zz = z[i];
-      } else {
+      f32x4 zz = zin;
+      if (!z) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) zz[e] = __builtin_fmaf(yy[e], sc[e], sh[e]);
       }
@@ -208,7 +201,28 @@ __global__ void bn_bwd_reduce_kernel(const f32x4* __restrict__ dz, const f32x4* 
       sg.v[e] += (double)gz[e];
       sgx.v[e] += (double)gz[e] * (double)xh[e];
     }
+  };
+  // four independent iterations of loads in flight per thread (same summation order as the plain loop)
+  const bool need_z = z != nullptr && act != UDASEG_ACT_NONE;
+  int64_t i = g;
+  for (; i + 3 * T < n4; i += 4 * T) {
+    f32x4 a[4], b[4], c[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      a[u] = dz[i + u * T];
+      b[u] = y[i + u * T];
+    }
+    if (need_z) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) c[u] = z[i + u * T];
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) c[u] = f32x4{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) body(a[u], b[u], c[u]);
   }
+  for (; i < n4; i += T) body(dz[i], y[i], need_z ? z[i] : f32x4{0, 0, 0, 0});
   double* rep = bsums + (size_t)(blockIdx.x % BN_REPLICAS) * 2 * c4 * 4;
   block_fold_add(sg, rep, c4, q, red);
   block_fold_add(sgx, rep + (size_t)c4 * 4, c4, q, red);
@@ -224,32 +238,29 @@ __global__ void bn_bwd_apply_kernel(const f32x4* __restrict__ dz, const f32x4* _
   extern __shared__ __attribute__((aligned(16))) float4 coef[];  // [6][c4]: mean, rstd, scale, mean(g), mean(g*xhat), shift
   const double inv = 1.0 / (double)pixels;
   const bool recompute = !z && act != UDASEG_ACT_NONE;
-  for (int q = threadIdx.x; q < c4; q += blockDim.x) {
-    float4 v[6];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int c = q * 4 + e;
+  {
+    float* cf = reinterpret_cast<float*>(coef);
+    const int C = c4 * 4;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {     // one channel per thread, see bn_apply_kernel
       double s1 = 0.0, s2 = 0.0;
 #pragma unroll
       for (int r = 0; r < BN_REPLICAS; ++r) {
-        s1 += bsums[(size_t)r * 2 * c4 * 4 + c];
-        s2 += bsums[(size_t)r * 2 * c4 * 4 + (size_t)c4 * 4 + c];
+        s1 += bsums[(size_t)r * 2 * C + c];
+        s2 += bsums[(size_t)r * 2 * C + C + c];
       }
-      const float rs = save_rstd[c];
-      reinterpret_cast<float*>(&v[0])[e] = save_mean[c];
-      reinterpret_cast<float*>(&v[1])[e] = rs;
-      reinterpret_cast<float*>(&v[2])[e] = gamma[c] * rs;
-      reinterpret_cast<float*>(&v[3])[e] = (float)(s1 * inv);
-      reinterpret_cast<float*>(&v[4])[e] = (float)(s2 * inv);
-      reinterpret_cast<float*>(&v[5])[e] = recompute ? beta[c] - save_mean[c] * (gamma[c] * rs) : 0.f;
+      const float rs = save_rstd[c], mu = save_mean[c], gs = gamma[c] * rs;
+      cf[c] = mu;
+      cf[C + c] = rs;
+      cf[2 * C + c] = gs;
+      cf[3 * C + c] = (float)(s1 * inv);
+      cf[4 * C + c] = (float)(s2 * inv);
+      cf[5 * C + c] = recompute ? beta[c] - mu * gs : 0.f;
       if (blockIdx.x == 0) {
         const float db = (float)s1, dg = (float)s2;
         if (dbeta) dbeta[c] = acc_param ? dbeta[c] + db : db;
         if (dgamma) dgamma[c] = acc_param ? dgamma[c] + dg : dg;
       }
     }
-#pragma unroll
-    for (int k = 0; k < 6; ++k) coef[k * c4 + q] = v[k];
   }
   __syncthreads();
   const int64_t T = (int64_t)gridDim.x * blockDim.x;
@@ -266,14 +277,10 @@ __global__ void bn_bwd_apply_kernel(const f32x4* __restrict__ dz, const f32x4* _
     mg = f32x4{a3.x, a3.y, a3.z, a3.w};
     mgx = f32x4{a4.x, a4.y, a4.z, a4.w};
   }
-  for (int64_t i = g; i < n4; i += T) {
-    f32x4 gz = dz[i];
-    const f32x4 yy = y[i];
+  auto body = [&](int64_t i, f32x4 gz, const f32x4 yy, const f32x4 zin, const f32x4 old_dy, const f32x4 old_res) {
     if (act != UDASEG_ACT_NONE) {
-      f32x4 zz;
-      if (z) {
-        zz = z[i];
-      } else {
+      f32x4 zz = zin;
+      if (!z) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) zz[e] = __builtin_fmaf(yy[e], scale[e], shift[e]);
       }
@@ -282,14 +289,19 @@ __global__ void bn_bwd_apply_kernel(const f32x4* __restrict__ dz, const f32x4* _
     }
     const f32x4 xh = (yy - mean) * rstd;
     f32x4 out = scale * (gz - mg - xh * mgx);
-    if (acc_dy) out += dy[i];
+    if (acc_dy) out += old_dy;
     dy[i] = out;
     if (dres) {
       f32x4 r = gz;
-      if (acc_dres) r += dres[i];
+      if (acc_dres) r += old_res;
       dres[i] = r;
     }
-  }
+  };
+  // (a four-deep unroll like bn_apply's was measured here and LOST: 82.7 -> 123 us on the 134 MB layers -- five arrays of
+  // four vectors cost the occupancy the streams need; the plain loop already has two or three loads in flight per thread)
+  const f32x4 zero = {0, 0, 0, 0};
+  const bool need_z = z != nullptr && act != UDASEG_ACT_NONE, need_res = dres != nullptr && acc_dres;
+  for (int64_t i = g; i < n4; i += T) body(i, dz[i], y[i], need_z ? z[i] : zero, acc_dy ? dy[i] : zero, need_res ? dres[i] : zero);
 }
 
 __global__ void act_bwd_kernel(const f32x4* __restrict__ dz, const f32x4* __restrict__ z, f32x4* __restrict__ dy,
