@@ -408,6 +408,28 @@ def test_act_bwd_and_channel_sum(K):
     assert_close(out.cpu(), 2 * dz.sum(dim=(0, 1, 2)), "channel_sum acc", 1e-5)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_pack_dgrad_batched_tiles(K, dtype):
+    """One launch repacks every convolution of a network for the data gradient: w[co][t][ci] -> wt[ci][t][co] as LDS tile
+    transposes.  Ragged tiles (24, 36, 4 channels), a 7x7 and a 1x1 kernel, a full 512 x 512 x 9 layer; bit-exact."""
+    g = torch.Generator().manual_seed(5)
+    shapes = [(64, 49, 4), (24, 9, 16), (16, 9, 36), (128, 1, 64), (512, 9, 512), (32, 16, 8), (64, 9, 64)]
+    ws = [torch.randn(co, t, ci, generator=g) for co, t, ci in shapes]
+    arena = torch.cat([w.reshape(-1) for w in ws]).cuda()
+    rows, off = [], 0
+    for (co, t, ci) in shapes:
+        rows.append([off, off, co, t, ci])
+        off += co * t * ci
+    table = torch.tensor(rows, dtype=torch.int32, device="cuda")
+    packed = torch.full((off,), float("nan"), device="cuda").to(dtype)
+    K.pack_dgrad_batched(arena, packed, table)
+    torch.cuda.synchronize()
+    for (o, _, co, t, ci), w in zip(rows, ws):
+        want = w.permute(2, 1, 0).contiguous().to(dtype)
+        got = packed[o:o + co * t * ci].view(ci, t, co).cpu()
+        assert torch.equal(got, want), (co, t, ci)
+
+
 @pytest.mark.parametrize("shape,dtype", [((8, 256, 256, 64), torch.bfloat16), ((8, 64, 64, 256), torch.bfloat16),
                                          ((4, 128, 128, 128), torch.float32), ((2, 96, 96, 24), torch.float32),
                                          ((2, 32, 32, 1024), torch.float32)])

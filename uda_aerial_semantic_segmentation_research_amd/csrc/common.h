@@ -70,6 +70,50 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 constexpr int BN_REPLICAS = 16;
 constexpr int REDUCE_MAX_BLOCKS = 512;
 
+// dgrad weight repack w[co][t][ci] -> wt[ci][t][co] of one table row, as 32x32 tile transposes through LDS: 128-byte row
+// reads, 128-byte (fp32) / 64-byte (bf16) row writes.  (The element-wise form read 4 bytes per lane at a stride of a whole
+// weight row: 0.93 TB/s, 97 us per step for r18's 45 MB; 408 us for r50.)  Blocks of gridDim.x stride over the row's tiles.
+template <typename OutT>
+__device__ __forceinline__ void pack_dgrad_tiles(const float* __restrict__ w, OutT* __restrict__ wt, int co, int T, int ci) {
+  __shared__ float tile[32][33];
+  const int ta = (co + 31) >> 5, tb = (ci + 31) >> 5;
+  const int ntiles = T * ta * tb;
+  const int row = threadIdx.x >> 3, q = threadIdx.x & 7;
+  for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+    const int b = tl % tb, r = tl / tb, a = r % ta, t = r / ta;
+    {
+      const int o = 32 * a + row, c = 32 * b + 4 * q;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (o < co && c < ci) v = *reinterpret_cast<const f32x4*>(w + ((size_t)o * T + t) * ci + c);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) tile[row][4 * q + k] = v[k];
+    }
+    __syncthreads();
+    {
+      const int c = 32 * b + row, o = 32 * a + 4 * q;
+      if (c < ci && o < co) {
+        OutT* dst = wt + ((size_t)c * T + t) * co + o;
+        if constexpr (sizeof(OutT) == 4) {
+          f32x4 v;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] = tile[4 * q + k][row];
+          *reinterpret_cast<f32x4*>(dst) = v;
+        } else {
+          unsigned short h[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) h[k] = __builtin_bit_cast(unsigned short, (__bf16)tile[4 * q + k][row]);
+          uint2 pk;
+          pk.x = (unsigned)h[0] | ((unsigned)h[1] << 16);
+          pk.y = (unsigned)h[2] | ((unsigned)h[3] << 16);
+          *reinterpret_cast<uint2*>(dst) = pk;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+constexpr int PACK_DGRAD_GRID_X = 256;
+
 // channel_sum (bias gradients): above CHSUM_DIRECT_BLOCKS blocks the per-block partials go into CHSUM_REPLICAS zeroed copies of
 // the output in a stream-ordered scratch allocation and a second tiny kernel folds them -- 2048 blocks adding into one
 // 64-float vector took 415 us for a 67 MB tensor (r02: 24 % of the bf16 adversarial step), 30x its HBM time.

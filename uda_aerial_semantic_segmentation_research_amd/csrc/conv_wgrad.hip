@@ -637,21 +637,25 @@ __global__ void pack_dgrad_batched_kernel(const float* __restrict__ arena, float
   const int* e = table + 5 * blockIdx.y;
   const float* w = arena + e[0];
   float* wt = packed + e[1];
-  const int co = e[2], T = e[3], ci = e[4];
-  const int total = co * T * ci;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const int o = i % co;
-    const int r = i / co;
-    const int t = r % T;
-    const int c = r / T;
-    wt[i] = w[(o * T + t) * ci + c];
+  if ((e[2] | e[4]) & 3) {       // channel counts that are not multiples of 4 (not produced by the arena layout): element-wise
+    const int co = e[2], T = e[3], ci = e[4];
+    const int total = co * T * ci;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+      const int o = i % co;
+      const int r = i / co;
+      const int t = r % T;
+      const int c = r / T;
+      wt[i] = w[(o * T + t) * ci + c];
+    }
+    return;
   }
+  pack_dgrad_tiles<float>(w, wt, e[2], e[3], e[4]);
 }
 }  // namespace udaseg
 
 extern "C" int udaseg_pack_dgrad_batched(const float* arena, float* packed, const int* table, int entries, void* stream) {
   UDASEG_CHECK_ARG(arena && packed && table && entries > 0, "pack_dgrad_batched: bad arguments");
-  hipLaunchKernelGGL(pack_dgrad_batched_kernel, dim3(64, entries), dim3(256), 0, as_stream(stream), arena, packed, table);
+  hipLaunchKernelGGL(pack_dgrad_batched_kernel, dim3(PACK_DGRAD_GRID_X, entries), dim3(256), 0, as_stream(stream), arena, packed, table);
   UDASEG_LAUNCH_CHECK("pack_dgrad_batched launch");
   return UDASEG_OK;
 }

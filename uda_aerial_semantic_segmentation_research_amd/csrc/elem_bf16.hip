@@ -488,15 +488,19 @@ __global__ void pack_dgrad_batched_bf16_kernel(const float* __restrict__ arena, 
   const int* e = table + 5 * blockIdx.y;
   const float* w = arena + e[0];
   __bf16* wt = packed + e[1];
-  const int co = e[2], T = e[3], ci = e[4];
-  const int total = co * T * ci;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const int o = i % co;
-    const int r = i / co;
-    const int t = r % T;
-    const int c = r / T;
-    wt[i] = (__bf16)w[(o * T + t) * ci + c];
+  if ((e[2] | e[4]) & 3) {
+    const int co = e[2], T = e[3], ci = e[4];
+    const int total = co * T * ci;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+      const int o = i % co;
+      const int r = i / co;
+      const int t = r % T;
+      const int c = r / T;
+      wt[i] = (__bf16)w[(o * T + t) * ci + c];
+    }
+    return;
   }
+  pack_dgrad_tiles<__bf16>(w, wt, e[2], e[3], e[4]);
 }
 
 static inline int grid_for8(int64_t items, int per_thread = 2) {
@@ -705,7 +709,7 @@ extern "C" int udaseg_gap_bwd_broadcast_bf16(const float* dp, const float* p, co
 
 extern "C" int udaseg_pack_dgrad_batched_bf16(const float* arena, void* packed, const int* table, int entries, void* stream) {
   UDASEG_CHECK_ARG(arena && packed && table && entries > 0, "pack_dgrad_batched_bf16: bad arguments");
-  hipLaunchKernelGGL(pack_dgrad_batched_bf16_kernel, dim3(64, entries), dim3(256), 0, as_stream(stream), arena, (__bf16*)packed,
+  hipLaunchKernelGGL(pack_dgrad_batched_bf16_kernel, dim3(PACK_DGRAD_GRID_X, entries), dim3(256), 0, as_stream(stream), arena, (__bf16*)packed,
                      table);
   UDASEG_LAUNCH_CHECK("pack_dgrad_batched_bf16 launch");
   return UDASEG_OK;
