@@ -29,5 +29,14 @@ UDASEG_SERIAL=1 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE
         -d $OUT/${TAG}_pmc_mfma -- $BENCH > $OUT/${TAG}_pmc_mfma.log 2>&1 || exit 1
 python3 $ROOT/tools/pmc_mfma.py $(find $OUT/${TAG}_pmc_mfma -name "*counter_collection.csv" | head -1) $OUT/${TAG}_pmc_mfma_util.json || exit 1
 echo "pmc mfma done"
+# the bf16 legs (cfg 3, cfg 5): single-stream kernel statistics
+UDASEG_SERIAL=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_bf16_cfg3 -- python3 $ROOT/bench.py --steps 5 --warmup 2 \
+        --no-cpu-baseline --no-roofline --no-also --no-sustain --workload adversarial --dtype bf16 > $OUT/${TAG}_prof_bf16_cfg3.log 2>&1 || exit 1
+cp $(find $OUT/${TAG}_prof_bf16_cfg3 -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats_bf16_cfg3.csv
+UDASEG_SERIAL=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_bf16_cfg5 -- python3 $ROOT/bench.py --steps 5 --warmup 2 \
+        --no-cpu-baseline --no-roofline --no-also --no-sustain --encoder resnet50 --size 768 --dtype bf16 > $OUT/${TAG}_prof_bf16_cfg5.log 2>&1 || exit 1
+cp $(find $OUT/${TAG}_prof_bf16_cfg5 -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats_bf16_cfg5.csv
+echo "bf16 stats done"
+rm -rf $OUT/${TAG}_prof_bf16_cfg3 $OUT/${TAG}_prof_bf16_cfg5
 rm -rf $OUT/${TAG}_prof_serial $OUT/${TAG}_prof_ovl $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write $OUT/${TAG}_pmc_mfma
 ls -la $OUT/${TAG}_*
