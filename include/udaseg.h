@@ -92,6 +92,12 @@ int udaseg_conv2d_dgrad_bnreduce_ok(const udaseg_conv_desc* d);
 int udaseg_conv2d_dgrad_bnreduce(const udaseg_conv_desc* d, const float* dy, const float* w_t, float* dx, const float* prev_y,
                                  const float* save_mean, const float* save_rstd, const float* gamma, const float* beta, int act,
                                  float slope, double* bsums, void* stream);
+/* bf16 storage: same reductions from the LDS-staged epilogue (g from the bf16-rounded gradient, as the stand-alone
+   udaseg_bn_bwd_reduce_bf16 would read it back); any stride-1 geometry */
+int udaseg_conv2d_dgrad_bnreduce_bf16_ok(const udaseg_conv_desc* d);
+int udaseg_conv2d_dgrad_bnreduce_bf16(const udaseg_conv_desc* d, const void* dy, const void* w_t, void* dx, const void* prev_y,
+                                      const float* save_mean, const float* save_rstd, const float* gamma, const float* beta,
+                                      int act, float slope, double* bsums, void* stream);
 /* dw[co][kh][kw][ci] (+)= sum over pixels of dy (x) x.  If !accumulate dw is overwritten.
  * Split-K partials are combined with fp32 atomics. */
 int udaseg_conv2d_wgrad(const udaseg_conv_desc* d, const float* x, const float* dy, float* dw, int accumulate,

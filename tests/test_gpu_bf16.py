@@ -104,6 +104,45 @@ def bf(t):  # NCHW cpu fp32 -> NHWC cuda bf16
     return t.permute(0, 2, 3, 1).contiguous().to("cuda", torch.bfloat16)
 
 
+@pytest.mark.parametrize("n,h,w,c1,c2,act,slope", [(8, 64, 64, 64, 64, 1, 0.0), (2, 32, 32, 256, 128, 1, 0.0),
+                                                    (3, 9, 7, 40, 64, 1, 0.2), (1, 16, 16, 512, 512, 1, 0.0),
+                                                    (2, 24, 24, 16, 24, 1, 0.0)])
+def test_dgrad_with_bn_backward_reductions_bf16(K, n, h, w, c1, c2, act, slope):
+    """udaseg_conv2d_dgrad_bnreduce_bf16 == udaseg_conv2d_dgrad_bf16 followed by udaseg_bn_bwd_reduce_bf16 on what it stored
+    (dz = the bf16 dx, z = the bf16 activation the forward wrote): dx bit for bit, the two per-channel sums to fp32
+    block-partial rounding.  Ragged tiles, a channel tail and the <= 32-channel generic loop included (the reductions are made
+    in the LDS-staged epilogue, which guards rows and chunks itself)."""
+    g = torch.Generator().manual_seed(c1 + c2 + h)
+    d = K.conv_desc(n, h, w, c1, c2, 3, 1, 1)
+    assert K.conv2d_dgrad_bnreduce_ok(d, torch.bfloat16)
+    assert not K.conv2d_dgrad_bnreduce_ok(K.conv_desc(n, h, w, c1, c2, 3, 2, 1), torch.bfloat16)
+    bf = torch.bfloat16
+    dy = torch.randn(n, h, w, c2, generator=g).to(bf).cuda()
+    wt = (torch.randn(c1, 3, 3, c2, generator=g) / math.sqrt(9 * c2)).to(bf).cuda()          # already [ci][taps][co]
+    prev_y = torch.randn(n, h, w, c1, generator=g).to(bf).cuda()
+    mean, rstd = torch.randn(c1, generator=g).cuda() * 0.1, (torch.rand(c1, generator=g) + 0.5).cuda()
+    gamma, beta = (torch.rand(c1, generator=g) + 0.5).cuda(), (torch.randn(c1, generator=g) * 0.3).cuda()
+    # the activation the forward stored: act(bn(y)) rounded to bf16 (what the stand-alone reduction reads as z)
+    t = prev_y.float() * (gamma * rstd) + (beta - mean * (gamma * rstd))
+    z = torch.where(t > 0, t, slope * t).to(bf)
+    R = K.bn_replicas()
+    dx_ref = torch.empty(n, h, w, c1, device="cuda", dtype=bf)
+    K.conv2d_dgrad(d, dy, wt, dx_ref)
+    bs_ref = torch.zeros(R * 2 * c1, dtype=torch.float64, device="cuda")
+    K.bn_bwd_reduce(dx_ref, z, prev_y, mean, rstd, bs_ref, act, slope)
+    dx = torch.full_like(dx_ref, float("nan"))
+    bs = torch.zeros_like(bs_ref)
+    K.conv2d_dgrad_bnreduce(d, dy, wt, dx, prev_y, mean, rstd, gamma, beta, act, slope, bs)
+    assert torch.equal(dx, dx_ref)
+    s, s_ref = bs.view(R, 2, c1).sum(0), bs_ref.view(R, 2, c1).sum(0)
+    scale = s_ref.abs().max(dim=1, keepdim=True).values
+    # a sign flip of one near-zero pre-activation (fma vs the rounded z) would show as ~1e-4 of a channel sum; none expected
+    assert ((s - s_ref).abs() / scale).max().item() < 2e-5, ((s - s_ref).abs() / scale).max().item()
+    gm = dx_ref.float() * torch.where(t > 0, 1.0, slope)
+    want = torch.stack([gm.double().sum((0, 1, 2)), (gm.double() * ((prev_y.float() - mean) * rstd).double()).sum((0, 1, 2))])
+    assert ((s - want).abs() / want.abs().max(dim=1, keepdim=True).values).max().item() < 1e-4
+
+
 @pytest.mark.parametrize("c", [16, 64, 512])
 @pytest.mark.parametrize("act,slope,with_res", [(0, 0.0, False), (1, 0.0, True), (1, 0.2, False)])
 def test_bn_bf16_fwd_bwd(K, c, act, slope, with_res):

@@ -39,6 +39,8 @@ SIGNATURES = {
     "udaseg_conv2d_wgrad": (_I, [_D, _P, _P, _P, _I, _P]),
     "udaseg_conv2d_dgrad_bnreduce_ok": (_I, [_D]),
     "udaseg_conv2d_dgrad_bnreduce": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _P, _P]),
+    "udaseg_conv2d_dgrad_bnreduce_bf16_ok": (_I, [_D]),
+    "udaseg_conv2d_dgrad_bnreduce_bf16": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _P, _P]),
     "udaseg_conv2d_fwd_upcat": (_I, [_D, _P, _P, _I, _P, _P, _P, _I, _F, _P, _P]),
     "udaseg_conv2d_fwd_upcat_bf16": (_I, [_D, _P, _P, _I, _P, _P, _P, _I, _F, _P, _P]),
     "udaseg_conv2d_dgrad_split": (_I, [_D, _P, _P, _P, _P, _I, _P]),

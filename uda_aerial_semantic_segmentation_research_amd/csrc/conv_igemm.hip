@@ -452,7 +452,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
     fast_epi = a.dense_out && !a.atomic_out && !a.accumulate && a.residual == nullptr && m0 + BM <= cM && n0 + BN <= a.co &&
                (long long)cM * a.co * 4 < (1LL << 31);
   }
-  bool lds_epi = false;
+  bool lds_epi = false, stats_done = false;
   if constexpr (BF) {
     lds_epi = !a.atomic_out && !a.accumulate && a.residual == nullptr && !a.out_f32 && (a.co & 7) == 0 && (yld & 7) == 0 &&
               (nsub & 7) == 0 && (reinterpret_cast<uintptr_t>(yb) & 15) == 0;
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
           for (int v = 0; v < 16; v += 2) {
             const int tr = tr0 + (v & 3) + 8 * (v >> 2);
             float w0 = acc[i][j][v] + bv, w1 = acc[i][j][v + 1] + bv;
-            if (a.stats != nullptr) {                // from the fp32 accumulator, before rounding; rows past the class are no outputs
+            if (a.stats != nullptr && a.bnb_y == nullptr) {   // from the fp32 accumulator, before rounding; rows past the class are no outputs
               const float q0 = (inside || m0 + tr < cM) ? w0 : 0.f, q1 = (inside || m0 + tr + 1 < cM) ? w1 : 0.f;
               ssum[j] += q0 + q1;
               ssq[j] = __builtin_fmaf(q0, q0, __builtin_fmaf(q1, q1, ssq[j]));
@@ -557,6 +557,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
       constexpr int CH = BN / 8, RPP = 256 / CH;     // 16-byte chunks per row, rows per pass
       const int ch = tid % CH;
       const int n = n0 + ch * 8;
+      // BatchNorm-backward sums of the layer behind (IgemmArgs::bnb_*): formed here, where a thread holds eight consecutive
+      // channels of a row -- g from the bf16-ROUNDED gradient, exactly what the stand-alone bn_bwd_reduce_bf16 would read back
+      const bool bnb = a.bnb_y != nullptr;
+      float b_sc[8], b_sh[8], b_mu[8], b_rs[8], s1[8], s2[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s1[e] = s2[e] = b_sc[e] = b_sh[e] = b_mu[e] = b_rs[e] = 0.f;
+      if (bnb && n < a.co) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          b_mu[e] = a.bnb_mean[n + e];
+          b_rs[e] = a.bnb_rstd[n + e];
+          b_sc[e] = a.bnb_gamma[n + e] * b_rs[e];
+          b_sh[e] = a.bnb_beta[n + e] - b_mu[e] * b_sc[e];
+        }
+      }
       if (n < a.co) {
 #pragma unroll
         for (int r = tid / CH; r < BM; r += RPP) {
@@ -572,8 +587,43 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
             }
             const f32x4 d = *reinterpret_cast<const f32x4*>(T + r * TS + ch * 4);
             *reinterpret_cast<f32x4*>(static_cast<__bf16*>(yb) + pix * (size_t)yld + (size_t)(n - nsub)) = d;
+            if (bnb) {     // host-checked: dense output, no split -- the producer's y has this tensor's geometry
+              const f32x4 yv = *reinterpret_cast<const f32x4*>(reinterpret_cast<const __bf16*>(a.bnb_y) + (size_t)m * a.co + n);
+              const bf16x8 dh = __builtin_bit_cast(bf16x8, d), yh = __builtin_bit_cast(bf16x8, yv);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const float yy = (float)yh[e];
+                const float g = (float)dh[e] * act_grad(yy * b_sc[e] + b_sh[e], a.bnb_act, a.bnb_slope);
+                s1[e] += g;
+                s2[e] = __builtin_fmaf(g, (yy - b_mu[e]) * b_rs[e], s2[e]);
+              }
+            }
           }
         }
+      }
+      if (bnb) {
+        // fold the RPP row-threads of a channel chunk through LDS (behind the staged tile), one f64 atomic per (channel, sum)
+        float* red = reinterpret_cast<float*>(T + BM * TS);       // [2][RPP][BN]
+        static_assert(BM * TS + 2 * RPP * BN <= 2 * (BM + BN) * LDS_LD, "reduction scratch fits behind the staged tile");
+        const int rr = tid / CH;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          red[rr * BN + ch * 8 + e] = s1[e];
+          red[RPP * BN + rr * BN + ch * 8 + e] = s2[e];
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < a.co) {
+          float t1 = 0.f, t2 = 0.f;
+#pragma unroll 8
+          for (int q = 0; q < RPP; ++q) {
+            t1 += red[q * BN + tid];
+            t2 += red[RPP * BN + q * BN + tid];
+          }
+          double* rep = a.stats + (size_t)(blockIdx.x % STATS_REPLICAS) * 2 * a.co;
+          atomicAdd(rep + n0 + tid, (double)t1);
+          atomicAdd(rep + a.co + n0 + tid, (double)t2);
+        }
+        stats_done = true;
       }
     }
   } else
@@ -633,7 +683,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
       }
     }
   }
-  if (a.stats) {
+  if (a.stats && !stats_done) {
     // fold the two half-waves (same column), then the WAVES_M waves that share a column through LDS (the K loop is
     // over: its tiles are free), then one f64 atomic per (column, statistic) per block into replica blockIdx % R.
     float* red = As;  // [2][4 waves][TN][32]
@@ -1094,6 +1144,27 @@ extern "C" int udaseg_conv2d_dgrad_bf16(const udaseg_conv_desc* d, const void* d
 }
 
 extern "C" int udaseg_conv2d_dgrad_bnreduce_ok(const udaseg_conv_desc* d) { return d && dgrad_bnreduce_ok(d) ? 1 : 0; }
+
+// bf16: the reductions ride on the LDS-staged epilogue, which guards rows and channel chunks itself -- any stride-1 geometry
+static bool dgrad_bnreduce_ok_bf16(const udaseg_conv_desc* d) {
+  return check_desc(d) == UDASEG_OK && d->stride == 1 && d->ci % 8 == 0 && d->co % 8 == 0;
+}
+extern "C" int udaseg_conv2d_dgrad_bnreduce_bf16_ok(const udaseg_conv_desc* d) { return d && dgrad_bnreduce_ok_bf16(d) ? 1 : 0; }
+
+extern "C" int udaseg_conv2d_dgrad_bnreduce_bf16(const udaseg_conv_desc* d, const void* dy, const void* w_t, void* dx,
+                                                 const void* prev_y, const float* save_mean, const float* save_rstd,
+                                                 const float* gamma, const float* beta, int act, float slope, double* bsums,
+                                                 void* stream) {
+  UDASEG_CHECK_ARG(d && prev_y && save_mean && save_rstd && gamma && beta && bsums, "conv2d_dgrad_bnreduce_bf16: NULL pointer");
+  UDASEG_CHECK_ARG(dx && (reinterpret_cast<uintptr_t>(dx) & 15) == 0 && (reinterpret_cast<uintptr_t>(prev_y) & 15) == 0,
+                   "conv2d_dgrad_bnreduce_bf16: dx and prev_y must be 16-byte aligned");
+  if (!dgrad_bnreduce_ok_bf16(d)) {
+    set_error("conv2d_dgrad_bnreduce_bf16: stride-1 convolutions with channel counts that are multiples of 8 only");
+    return UDASEG_E_UNSUPPORTED;
+  }
+  const BnReduceArgs b = {static_cast<const float*>(prev_y), save_mean, save_rstd, gamma, beta, act, slope, bsums};
+  return conv2d_dgrad_impl(d, dy, w_t, dx, 0, stream, 1, nullptr, 0, &b);
+}
 
 extern "C" int udaseg_conv2d_dgrad_bnreduce(const udaseg_conv_desc* d, const float* dy, const float* w_t, float* dx,
                                             const float* prev_y, const float* save_mean, const float* save_rstd,

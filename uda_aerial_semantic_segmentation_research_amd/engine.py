@@ -530,10 +530,10 @@ class Plan:
             else:
                 K.channel_sum(dy, self.gvec(conv, "bias"), True, wst)
         if dx is not None:
-            if (prev is not None and FUSE_BN_REDUCE and not dx_acc and not self.bf16 and not prev[9] and prev[7] != ACT_NONE
-                    and K.conv2d_dgrad_bnreduce_ok(d)):
+            if (prev is not None and FUSE_BN_REDUCE and not dx_acc and not prev[9] and prev[7] != ACT_NONE
+                    and K.conv2d_dgrad_bnreduce_ok(d, dy.dtype) and prev[4].shape == dx.shape):
                 p_bn, p_y, (p_mean, p_rstd) = prev[1], prev[4], prev[6]
-                bs = self._next_bstats(ceil4(p_bn.c))
+                bs = self._next_bstats(p_y.shape[-1] if self.bf16 else ceil4(p_bn.c))
                 K.conv2d_dgrad_bnreduce(d, dy, self.packed_wt(conv), dx, p_y, p_mean, p_rstd, self.pvec(p_bn, "weight"),
                                         self.pvec(p_bn, "bias"), prev[7], prev[8], bs, self.st)
                 self._bnb[id(p_y)] = bs

@@ -100,15 +100,17 @@ def conv2d_dgrad(d, dy, w_t, dx, accumulate=False, st=None):
 
 
 def conv2d_dgrad_bnreduce_ok(d, dtype=torch.float32):
+    if dtype == torch.bfloat16:
+        return bool(_lib.load().udaseg_conv2d_dgrad_bnreduce_bf16_ok(_byref(d)))
     return dtype == torch.float32 and bool(_lib.load().udaseg_conv2d_dgrad_bnreduce_ok(_byref(d)))
 
 
 def conv2d_dgrad_bnreduce(d, dy, w_t, dx, prev_y, save_mean, save_rstd, gamma, beta, act, slope, bsums, st=None):
     """dx = dgrad AND the BatchNorm-backward reductions (sum g, sum g*xhat) of the layer whose output prev_y feeds this conv."""
-    check(_lib.load().udaseg_conv2d_dgrad_bnreduce(_byref(d), dy.data_ptr(), w_t.data_ptr(), dx.data_ptr(), prev_y.data_ptr(),
-                                                    save_mean.data_ptr(), save_rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                                    act, slope, bsums.data_ptr(), st if st is not None else stream()),
-          "conv2d_dgrad_bnreduce")
+    fn = _lib.load().udaseg_conv2d_dgrad_bnreduce_bf16 if dy.dtype == torch.bfloat16 else _lib.load().udaseg_conv2d_dgrad_bnreduce
+    check(fn(_byref(d), dy.data_ptr(), w_t.data_ptr(), dx.data_ptr(), prev_y.data_ptr(), save_mean.data_ptr(),
+             save_rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), act, slope, bsums.data_ptr(),
+             st if st is not None else stream()), "conv2d_dgrad_bnreduce")
 
 
 def conv2d_wgrad(d, x, dy, dw, accumulate=False, st=None):
