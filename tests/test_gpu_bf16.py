@@ -47,6 +47,10 @@ BF_CASES = [
     (2, 16, 16, 64, 64, 3, 1, 1), (2, 16, 16, 64, 128, 3, 2, 1), (2, 16, 16, 64, 128, 1, 2, 0), (1, 8, 8, 256, 256, 3, 1, 1),
     (2, 32, 32, 8, 64, 7, 2, 3), (2, 32, 32, 8, 64, 4, 2, 1), (1, 24, 24, 32, 16, 3, 1, 1), (1, 24, 24, 16, 24, 3, 1, 1),
     (1, 12, 20, 192, 64, 3, 1, 1), (3, 9, 7, 8, 40, 3, 1, 1), (8, 64, 64, 64, 64, 3, 1, 1),
+    # pixel folding (csrc/conv_igemm.hip fold_plan): 16 / 32 gathered channels, forward and data gradient, width a multiple of
+    # the fold or not (fallback to the generic loop), the head's 24 outputs, a full-size decoder-tail shape
+    (2, 32, 32, 32, 32, 3, 1, 1), (2, 16, 64, 16, 16, 3, 1, 1), (1, 10, 14, 16, 24, 3, 1, 1), (1, 10, 14, 32, 16, 3, 1, 1),
+    (2, 20, 36, 16, 32, 3, 1, 1), (4, 128, 128, 32, 16, 3, 1, 1),
 ]
 
 
@@ -106,7 +110,8 @@ def bf(t):  # NCHW cpu fp32 -> NHWC cuda bf16
 
 @pytest.mark.parametrize("n,h,w,c1,c2,act,slope", [(8, 64, 64, 64, 64, 1, 0.0), (2, 32, 32, 256, 128, 1, 0.0),
                                                     (3, 9, 7, 40, 64, 1, 0.2), (1, 16, 16, 512, 512, 1, 0.0),
-                                                    (2, 24, 24, 16, 24, 1, 0.0)])
+                                                    (2, 24, 24, 16, 24, 1, 0.0), (2, 32, 32, 32, 16, 1, 0.0),
+                                                    (2, 16, 64, 16, 32, 1, 0.2)])
 def test_dgrad_with_bn_backward_reductions_bf16(K, n, h, w, c1, c2, act, slope):
     """udaseg_conv2d_dgrad_bnreduce_bf16 == udaseg_conv2d_dgrad_bf16 followed by udaseg_bn_bwd_reduce_bf16 on what it stored
     (dz = the bf16 dx, z = the bf16 activation the forward wrote): dx bit for bit, the two per-channel sums to fp32

@@ -78,14 +78,17 @@ void kprof_end(int kid, hipEvent_t a, hipStream_t s, double flops) {
   g_krecs[kid].push_back({a, b, flops});
 }
 
+static int g_prof_suspended = 0;
+void prof_suspend(int on) { g_prof_suspended = on; }   // a launcher that wraps another launcher keeps ONE record (its own)
+
 void prof_begin(int family, hipStream_t s) {
-  if (!g_prof_on) return;
+  if (!g_prof_on || g_prof_suspended) return;
   g_open[family] = get_event();
   if (g_open[family]) (void)hipEventRecord(g_open[family], s);
 }
 
 void prof_end(int family, hipStream_t s, double flops, int kind, const udaseg_conv_desc* d) {
-  if (!g_prof_on || !g_open[family]) return;
+  if (!g_prof_on || g_prof_suspended || !g_open[family]) return;
   hipEvent_t b = get_event();
   if (!b) return;
   (void)hipEventRecord(b, s);

@@ -114,6 +114,8 @@ __device__ __forceinline__ void pack_dgrad_tiles(const float* __restrict__ w, Ou
 }
 constexpr int PACK_DGRAD_GRID_X = 256;
 
+void* workspace_ptr(size_t* bytes);   // conv_small.hip: the scratch bound to the current device, or nullptr
+
 // channel_sum (bias gradients): above CHSUM_DIRECT_BLOCKS blocks the per-block partials go into CHSUM_REPLICAS zeroed copies of
 // the output in a stream-ordered scratch allocation and a second tiny kernel folds them -- 2048 blocks adding into one
 // 64-float vector took 415 us for a 67 MB tensor (r02: 24 % of the bf16 adversarial step), 30x its HBM time.
@@ -172,6 +174,7 @@ constexpr int PROF_NKERNELS = 24;
 hipEvent_t kprof_begin(hipStream_t s);
 void kprof_end(int kid, hipEvent_t a, hipStream_t s, double flops);
 void prof_begin(int family, hipStream_t s);
+void prof_suspend(int on);
 void prof_end(int family, hipStream_t s, double flops, int kind, const udaseg_conv_desc* d);
 
 }  // namespace udaseg

@@ -81,6 +81,10 @@ struct IgemmArgs {
   // previous convolution's output bnb_y and this convolution's input): with g = out * act'(bn(bnb_y)) and
   // xhat = (bnb_y - mean) * rstd the epilogue adds sum(g), sum(g * xhat) per channel into `stats` -- what
   // udaseg_bn_bwd_reduce would compute in a separate pass over (out, bnb_y).  Whole-tile launches only (host-checked).
+  // Pixel folding (bf16, <= 32-channel 3x3 layers; see fold_plan): F neighbouring pixels of a row are addressed as ONE pixel
+  // with F x the channels, so physical channel n stands for logical channel n % cmod in every per-channel vector (bias,
+  // BatchNorm statistics, the bnb_* coefficients).  0 = not folded.
+  int cmod;
   const float* bnb_y;
   const float* bnb_mean;
   const float* bnb_rstd;
@@ -531,7 +535,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           const int n = n0 + wn + j * 32 + lr;
-          const float bv = (a.bias != nullptr && n < a.co) ? a.bias[n] : 0.f;
+          const float bv = (a.bias != nullptr && n < a.co) ? a.bias[a.cmod ? n % a.cmod : n] : 0.f;
           const int tr0 = wm + i * 32 + 4 * lh;
           const int cd = (wn + j * 32 + lr) >> 1;
 #pragma unroll
@@ -564,12 +568,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) s1[e] = s2[e] = b_sc[e] = b_sh[e] = b_mu[e] = b_rs[e] = 0.f;
       if (bnb && n < a.co) {
+        const int nl = a.cmod ? n % a.cmod : n;      // a chunk of 8 never straddles a fold (cmod is a multiple of 8)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          b_mu[e] = a.bnb_mean[n + e];
-          b_rs[e] = a.bnb_rstd[n + e];
-          b_sc[e] = a.bnb_gamma[n + e] * b_rs[e];
-          b_sh[e] = a.bnb_beta[n + e] - b_mu[e] * b_sc[e];
+          b_mu[e] = a.bnb_mean[nl + e];
+          b_rs[e] = a.bnb_rstd[nl + e];
+          b_sc[e] = a.bnb_gamma[nl + e] * b_rs[e];
+          b_sh[e] = a.bnb_beta[nl + e] - b_mu[e] * b_sc[e];
         }
       }
       if (n < a.co) {
@@ -619,9 +624,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
             t1 += red[q * BN + tid];
             t2 += red[RPP * BN + q * BN + tid];
           }
-          double* rep = a.stats + (size_t)(blockIdx.x % STATS_REPLICAS) * 2 * a.co;
-          atomicAdd(rep + n0 + tid, (double)t1);
-          atomicAdd(rep + a.co + n0 + tid, (double)t2);
+          const int cl = a.cmod ? a.cmod : a.co, nl = (n0 + tid) % cl;
+          double* rep = a.stats + (size_t)(blockIdx.x % STATS_REPLICAS) * 2 * cl;
+          atomicAdd(rep + nl, (double)t1);
+          atomicAdd(rep + cl + nl, (double)t2);
         }
         stats_done = true;
       }
@@ -664,7 +670,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
             }
           } else {
             float val = acc[i][j][v];
-            if (a.bias) val += a.bias[n];
+            if (a.bias) val += a.bias[a.cmod ? n % a.cmod : n];
             ssum[j] += val;            // statistics from the fp32 accumulator, before rounding to bf16
             ssq[j] += val * val;
             if (a.residual) val += (float)static_cast<const __bf16*>(a.residual)[o];
@@ -706,9 +712,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
         s1 += red[(w * TN + jj) * 32 + l];
         s2 += red[4 * TN * 32 + (w * TN + jj) * 32 + l];
       }
-      double* rep = a.stats + (size_t)(blockIdx.x % STATS_REPLICAS) * 2 * a.co;
-      atomicAdd(rep + n0 + tid, (double)s1);
-      atomicAdd(rep + a.co + n0 + tid, (double)s2);
+      const int cl = a.cmod ? a.cmod : a.co, nl = (n0 + tid) % cl;
+      double* rep = a.stats + (size_t)(blockIdx.x % STATS_REPLICAS) * 2 * cl;
+      atomicAdd(rep + nl, (double)s1);
+      atomicAdd(rep + cl + nl, (double)s2);
     }
   }
   if (a.timeline && tid == 0) {
@@ -902,12 +909,88 @@ extern "C" double udaseg_conv_flops(const udaseg_conv_desc* d) {
 // skip / up_ca: the fused nearest-x2-upsample + concat input (IgemmArgs::x2): x is then the HALF-resolution tensor
 // [n][hi/2][wi/2][up_ca], skip the full-resolution [n][hi][wi][ci - up_ca] (NULL when ci == up_ca), d describes the conv on
 // the virtual concatenation.
+// ------------------------------------------------------------------------------------------------ pixel folding (bf16)
+// The <= 32-channel 3x3 / stride 1 / pad 1 layers at full resolution (decoder tail, head) do not fit the uniform-tap loop in
+// bf16: a K-tile is 64 elements = 128 bytes, a tap of 16 or 32 channels is 32 or 64.  On the generic loop they ran
+// block-overhead-bound (16 384 blocks of 1.2 MFLOP; 150-190 us per 9.66-19 GFLOP layer).  Folding: F = 64 / ci neighbouring
+// pixels of an image row ARE one pixel of F * ci = 64 channels in memory ([n][h][w][ci] == [n][h][w / F][F * ci], zero copy),
+// and the convolution is again a 3x3 / pad 1 convolution over those units with folded weights
+//     W'[(fo, o)][r][qu][(fi, c)] = W[o][r][dx][c],  dx = F * (qu - 1) + fi - fo + 1   if 0 <= dx <= 2, else 0
+// (output pixel F * xo + fo reads input pixel F * (xo + qu - 1) + fi).  F x the multiplications, all of them on the uniform
+// loop at bf16 MFMA rates, for a layer whose time is its operand traffic.  The folded weights (<= 96 x 9 x 64 bf16) are
+// rebuilt per call by a one-block-per-row kernel into the tail of the device's bound scratch; per-channel vectors are
+// addressed modulo the logical channel count (IgemmArgs::cmod).  The data gradient is the same thing on the flipped,
+// transposed weights (it IS a forward convolution of dy with V[c][r][q][o] = W[o][2 - r][2 - q][c]).
+constexpr size_t FOLD_SCRATCH_BYTES = 256 << 10;
+
+static int fold_factor(int kh, int kw, int stride, int pad, int gathered_c, int produced_c, int width, int bf16) {
+  if (!bf16 || kh != 3 || kw != 3 || stride != 1 || pad != 1) return 1;
+  if (gathered_c != 16 && gathered_c != 32) return 1;
+  static int off = -1;   // UDASEG_NO_FOLD=1: tuning aid / A-B
+  if (off < 0) off = getenv("UDASEG_NO_FOLD") != nullptr ? 1 : 0;
+  if (off) return 1;
+  const int F = 64 / gathered_c;
+  if (width % F != 0 || produced_c % 8 != 0) return 1;
+  // F x the multiplications and F x the output columns: measured per layer (r18 8x512^2 bf16, API-level events, folded vs generic
+  // loop): 32 -> 16 forward 129 vs 173 us, 16 -> 16 forward 125 vs 141 and data gradient 131 vs 192, 32 -> 32 at 256^2 58 vs 60 /
+  // 70 vs 73; but 16 -> 24 forward 215 vs 192 and the gradient that gathers 16 and produces 32 channels 157 vs 124: a fold of
+  // four only pays while the folded output still fits one 64-wide column tile
+  if (F == 4 && produced_c > 16) return 1;
+  if ((size_t)produced_c * F * 9 * 64 * 2 > FOLD_SCRATCH_BYTES) return 1;
+  size_t ws = 0;
+  if (workspace_ptr(&ws) == nullptr || ws < FOLD_SCRATCH_BYTES) return 1;
+  return F;
+}
+
+// src: forward weights [co][9][ci] (transposed == 0) or dgrad-packed weights [c_g][9][c_p] read as the flipped forward
+// convolution (transposed == 1: gathered channels are the packing's LAST axis).  dst: [F * cp][9][F * cg].
+__global__ void fold_weights_bf16_kernel(const __bf16* __restrict__ src, __bf16* __restrict__ dst, int cp, int cg, int F,
+                                         int transposed) {
+  const int row = blockIdx.x;                 // (fo, o)
+  const int fo = row / cp, o = row % cp;
+  const int KP = 9 * F * cg;
+  for (int i = threadIdx.x; i < KP; i += blockDim.x) {
+    const int c = i % cg, fi = (i / cg) % F, t = i / (cg * F);
+    const int r = t / 3, qu = t % 3;
+    const int dx = F * (qu - 1) + fi - fo + 1;
+    __bf16 v = (__bf16)0.f;
+    if (dx >= 0 && dx <= 2) {
+      if (!transposed) v = src[((size_t)o * 9 + r * 3 + dx) * cg + c];
+      else v = src[((size_t)o * 9 + (2 - r) * 3 + (2 - dx)) * cg + c];
+    }
+    dst[(size_t)row * KP + i] = v;
+  }
+}
+
+struct BnReduceArgs {   // IgemmArgs::bnb_*
+  const float* y;
+  const float* mean;
+  const float* rstd;
+  const float* gamma;
+  const float* beta;
+  int act;
+  float slope;
+  double* bsums;
+};
+
+// Run the folded problem: gathered tensor g [n][h][w][cg], produced tensor p [n][h][w][cp], weights as fold_weights expects.
+static int conv2d_folded(const udaseg_conv_desc* d, int F, const void* g, int cg, const void* wsrc, int transposed, const float* bias,
+                         void* p, int cp, int act, float slope, int accumulate, double* stats, const void* residual,
+                         hipStream_t st, int out_f32, const BnReduceArgs* bnb);
+
 static int conv2d_fwd_impl(const udaseg_conv_desc* d, const void* x, const void* w, const float* bias, void* y,
                            int act, float slope, int accumulate, double* stats, const void* residual, void* stream,
-                           int bf16 = 0, int out_f32 = 0, const void* skip = nullptr, int up_ca = 0) {
+                           int bf16 = 0, int out_f32 = 0, const void* skip = nullptr, int up_ca = 0, int cmod = 0,
+                           const BnReduceArgs* bnb = nullptr) {
   int rc = check_desc(d);
   if (rc) return rc;
   UDASEG_CHECK_ARG(x && w && y, "conv2d_fwd: NULL pointer");
+  if (cmod == 0 && up_ca == 0) {
+    const int F = fold_factor(d->kh, d->kw, d->stride, d->pad, d->ci, d->co, d->wi, bf16);
+    if (F > 1)
+      return conv2d_folded(d, F, x, d->ci, w, 0, bias, y, d->co, act, slope, accumulate, stats, residual, as_stream(stream), out_f32,
+                           nullptr);
+  }
   UDASEG_CHECK_ARG(!bf16 || (d->ci % 8 == 0 && d->co % 8 == 0), "conv2d_fwd(bf16): channels must be multiples of 8 (ci=%d co=%d)",
                    d->ci, d->co);
   if (up_ca > 0) {
@@ -944,6 +1027,12 @@ static int conv2d_fwd_impl(const udaseg_conv_desc* d, const void* x, const void*
   a.residual = residual;
   a.bf16 = bf16;
   a.out_f32 = out_f32;
+  a.cmod = cmod;
+  if (bnb) {
+    a.bnb_y = bnb->y; a.bnb_mean = bnb->mean; a.bnb_rstd = bnb->rstd; a.bnb_gamma = bnb->gamma; a.bnb_beta = bnb->beta;
+    a.bnb_act = bnb->act; a.bnb_slope = bnb->slope;
+    stats = bnb->bsums;
+  }
   a.x2 = skip;
   a.up_ca = up_ca;
   a.x2_bytes = (unsigned)((long long)d->n * d->hi * d->wi * (d->ci - up_ca) * (bf16 ? 2 : 4));
@@ -985,6 +1074,28 @@ extern "C" int udaseg_conv2d_fwd_bf16(const udaseg_conv_desc* d, const void* x, 
   return conv2d_fwd_impl(d, x, w, bias, y, act, slope, 0, stats, residual, stream, 1, out_f32);
 }
 
+static int conv2d_folded(const udaseg_conv_desc* d, int F, const void* g, int cg, const void* wsrc, int flip, const float* bias,
+                         void* p, int cp, int act, float slope, int accumulate, double* stats, const void* residual,
+                         hipStream_t st, int out_f32, const BnReduceArgs* bnb) {
+  size_t ws = 0;
+  char* base = static_cast<char*>(workspace_ptr(&ws));
+  if (base == nullptr || ws < FOLD_SCRATCH_BYTES) {
+    set_error("conv (bf16, folded pixels): no scratch bound to the current device");
+    return UDASEG_E_BADARG;
+  }
+  __bf16* wf = reinterpret_cast<__bf16*>(base + ws - FOLD_SCRATCH_BYTES);
+  hipLaunchKernelGGL(fold_weights_bf16_kernel, dim3(cp * F), dim3(256), 0, st, static_cast<const __bf16*>(wsrc), wf, cp, cg, F, flip);
+  UDASEG_LAUNCH_CHECK("fold_weights_bf16 launch");
+  udaseg_conv_desc f = *d;        // the same 3x3 / stride 1 / pad 1 convolution over units of F pixels
+  f.wi = d->wi / F; f.wo = d->wo / F; f.ci = cg * F; f.co = cp * F;
+  prof_begin(0, st);
+  prof_suspend(1);                // FLOPs of the record: the LOGICAL convolution's (the folded launch does F x the multiplies)
+  const int rc = conv2d_fwd_impl(&f, g, wf, bias, p, act, slope, accumulate, stats, residual, st, 1, out_f32, nullptr, 0, cp, bnb);
+  prof_suspend(0);
+  prof_end(0, st, udaseg_conv_flops(d), flip ? 1 : 0, d);
+  return rc;
+}
+
 extern "C" int udaseg_conv2d_fwd(const udaseg_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
                                  int act, float slope, int accumulate, void* stream) {
   return conv2d_fwd_impl(d, x, w, bias, y, act, slope, accumulate, nullptr, nullptr, stream);
@@ -1013,16 +1124,6 @@ extern "C" int udaseg_conv2d_fwd_upcat_bf16(const udaseg_conv_desc* d, const voi
   return conv2d_fwd_impl(d, a, w, bias, y, act, slope, 0, stats, nullptr, stream, 1, 0, skip, ca);
 }
 
-struct BnReduceArgs {   // IgemmArgs::bnb_*
-  const float* y;
-  const float* mean;
-  const float* rstd;
-  const float* gamma;
-  const float* beta;
-  int act;
-  float slope;
-  double* bsums;
-};
 
 // Can the data gradient of this convolution carry the BatchNorm-backward reductions of the layer behind it?  Only when every
 // tile of the launch is whole and plainly stored: stride 1, implicit-GEMM kernel (not the small-channel one), no K-slices,
@@ -1047,6 +1148,12 @@ static int conv2d_dgrad_impl(const udaseg_conv_desc* d, const void* dy, const vo
                    "conv2d_dgrad_split: needs dx2, 0 < split < ci, stride 1, no accumulation");
   UDASEG_CHECK_ARG(!bf16 || (d->ci % 8 == 0 && d->co % 8 == 0), "conv2d_dgrad(bf16): channels must be multiples of 8");
   hipStream_t st = as_stream(stream);
+  if (split == 0) {
+    // pixel folding: the data gradient as the flipped forward convolution of dy (gathered: co channels, produced: ci)
+    const int F = fold_factor(d->kh, d->kw, d->stride, d->pad, d->co, d->ci, d->wi, bf16);
+    if (F > 1)
+      return conv2d_folded(d, F, dy, d->co, w_t, 1, nullptr, dx, d->ci, UDASEG_ACT_NONE, 0.f, accumulate, nullptr, nullptr, st, 0, bnb);
+  }
   const int s = d->stride;
   prof_begin(0, st);
   if (!bf16 && d->kh == d->kw && small_conv_applicable(d->kh, d->stride, d->pad, d->co, d->ci)) {

@@ -523,6 +523,19 @@ int launch_small_wgrad(const float* x, const float* dy, float* dw, int n, int h,
 
 }  // namespace udaseg
 
+namespace udaseg {
+// the device's bound scratch (udaseg_set_workspace), for the other translation units
+void* workspace_ptr(size_t* bytes) {
+  const int dev = current_device();
+  if (dev < 0 || g_workspace[dev] == nullptr) {
+    if (bytes) *bytes = 0;
+    return nullptr;
+  }
+  if (bytes) *bytes = g_workspace_bytes[dev];
+  return g_workspace[dev];
+}
+}  // namespace udaseg
+
 extern "C" size_t udaseg_workspace_bytes(const udaseg_conv_desc* d) {
   // what udaseg_conv2d_wgrad wants to find in the workspace for this convolution (0: it needs none)
   if (!d || d->kh != d->kw || !udaseg::small_conv_applicable(d->kh, d->stride, d->pad, d->ci, d->co)) return 0;
