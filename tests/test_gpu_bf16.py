@@ -51,6 +51,8 @@ BF_CASES = [
     # the fold or not (fallback to the generic loop), the head's 24 outputs, a full-size decoder-tail shape
     (2, 32, 32, 32, 32, 3, 1, 1), (2, 16, 64, 16, 16, 3, 1, 1), (1, 10, 14, 16, 24, 3, 1, 1), (1, 10, 14, 32, 16, 3, 1, 1),
     (2, 20, 36, 16, 32, 3, 1, 1), (4, 128, 128, 32, 16, 3, 1, 1),
+    # 1x1 / stride 1: the weight gradient treats the batch as one row of M pixels (row-uniform gather at any image width)
+    (2, 24, 24, 64, 256, 1, 1, 0), (1, 7, 9, 64, 128, 1, 1, 0), (3, 48, 48, 256, 64, 1, 1, 0),
 ]
 
 

@@ -70,6 +70,7 @@ CONV_CASES = [
     (3, 9, 7, 8, 36, 3, 1, 1),        # ragged everything: M, N, K tails
     (1, 5, 5, 8, 8, 3, 2, 1),         # odd extent with stride 2
     (2, 16, 16, 64, 256, 1, 1, 0),    # bottleneck 1x1
+    (2, 24, 24, 128, 64, 1, 1, 0), (1, 7, 9, 64, 128, 1, 1, 0),   # 1x1 at widths that are not multiples of the load pass / ragged M
     (1, 64, 64, 64, 64, 3, 1, 1),     # 128x64 tile path? (M = 4096 -> small) keep for coverage
     (2, 40, 20, 16, 16, 3, 1, 1),     # small-channel direct kernel, ragged 16x16 tiles
     (1, 33, 47, 32, 16, 3, 1, 1),     # direct kernel, two K groups, odd extents

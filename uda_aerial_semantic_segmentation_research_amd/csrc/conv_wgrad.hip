@@ -573,6 +573,13 @@ static int conv2d_wgrad_impl(const udaseg_conv_desc* d, const void* x, int src_c
   a.J = d->kh * d->kw * src_c;
   a.ci_full = d->ci; a.c_off = c_off; a.J_ld = d->kh * d->kw * d->ci; a.up = up;
   a.inv_ci = 1.0f / src_c; a.inv_kw = 1.0f / d->kw; a.inv_wo = 1.0f / d->wo; a.inv_ho = 1.0f / d->ho;
+  if (d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0 && !up) {
+    // a 1x1 / stride 1 convolution gathers pixel m from pixel m: the batch is ONE image row of M pixels as far as the gather is
+    // concerned, so the row-uniform loop applies whatever the image width (r50's 48- and 24-pixel-wide stages took the generic
+    // loop -- two divisions per gathered row -- only because their width is not a multiple of the 32-pixel load pass)
+    a.hi = 1; a.wi = a.M; a.ho = 1; a.wo = a.M;
+    a.inv_wo = 1.0f / (float)a.M; a.inv_ho = 1.0f;
+  }
   hipStream_t st = as_stream(stream);
   prof_begin(1, st);
   int rc;
