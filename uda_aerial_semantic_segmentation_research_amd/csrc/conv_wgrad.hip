@@ -585,8 +585,8 @@ static int conv2d_wgrad_impl(const udaseg_conv_desc* d, const void* x, int src_c
   int rc;
   udaseg_conv_desc dp = *d;     // FLOPs of this launch: the slice's share
   dp.ci = src_c;
-  if (bf16)
-    rc = launch_wgrad<64, 64, 2, 2>(a, accumulate, st, true);
+  if (bf16)   // co <= 32: the 32 x 128 tile, as in fp32 (three J-tiles instead of five re-reading dy, no half-empty co tile)
+    rc = d->co > 32 ? launch_wgrad<64, 64, 2, 2>(a, accumulate, st, true) : launch_wgrad<32, 128, 1, 4>(a, accumulate, st, true);
   else if (whole && d->kh == d->kw &&
            small_wgrad_applicable(d->kh, d->stride, d->pad, d->ci, d->co, d->n * cdiv(d->hi, 16) * cdiv(d->wi, 16)))
     rc = launch_small_wgrad(static_cast<const float*>(x), static_cast<const float*>(dy), dw, d->n, d->hi, d->wi, d->ci, d->co,
