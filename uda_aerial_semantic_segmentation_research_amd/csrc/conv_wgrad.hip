@@ -488,7 +488,10 @@ static int launch_wgrad(WgradArgs a, int accumulate, hipStream_t s, bool bf16 = 
   // bf16: the MFMA phase of a split is 16x shorter, so the fp32 atomics of the partial tiles (blocks x 16 KB at ~1.3 TB/s)
   // are the launch: 512 blocks measured best (r18 8x512^2 step: 256 / 512 / 768 / 1024 / 2048 / 3072 blocks ->
   // 1285 / 1398 / 1366 / 1353 / 1326 / 1285 images/s; r50 768^2: 337 / 344 / 338 / 335 / 336 / 332)
-  int splits = cdiv(bf16 && getenv("UDASEG_WGRAD_BLOCKS") == nullptr ? 512 : target, tiles);
+  // (the <= 32-output-channel full-resolution layers -- 32 x 128 tile, 16 KB of partials per block, >= 1 M pixels -- are the
+  // exception: latency-bound at two blocks per CU, 2048 blocks: 185 -> 152, 138 -> 120, 128 -> 109 us at 512^2)
+  const int bf16_target = (BMW == 32 && a.M >= (1 << 20)) ? 2048 : 512;
+  int splits = cdiv(bf16 && getenv("UDASEG_WGRAD_BLOCKS") == nullptr ? bf16_target : target, tiles);
   const int max_splits = cdiv(a.M, 256);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
