@@ -63,13 +63,8 @@ struct IgemmArgs {
   // uniform-tap fast path (ci a multiple of the K-tile: every thread of a block is in the same tap during a K-step)
   int uniform;                 // host-side selector
   unsigned x_bytes, w_bytes;   // operand sizes for the buffer descriptors (range-checked loads: out of range reads 0)
-  int tap_xoff[32];            // ((dy*wi + dx) * ci) * element_size     (host-side check of the affine forms below)
+  int tap_xoff[32];            // ((dy*wi + dx) * ci) * element_size
   int tap_woff[32];            // wt * ci * element_size
-  // The same two offsets as AFFINE functions of a tap's grid coordinates (a, b): off = o0 + oa * a + ob * b, per class.
-  // The K loop forms them with four scalar multiply-adds when the tap changes; reading tap_xoff[] / tap_woff[] there was a
-  // scalar MEMORY load per K-tile followed by s_waitcnt lgkmcnt(0) -- which also drains every LDS fragment read in flight
-  // (scalar loads return out of order, so the counter cannot be waited on partially) in the middle of the MFMA run.
-  int xo0[NCLS], xoa[NCLS], xob[NCLS], wo0[NCLS], woa[NCLS], wob[NCLS];
   // fused nearest-x2-upsample + concat input (decoder blocks of smp.Unet: cat([up(a), skip], 1) is never materialised):
   // the gathered tensor is VIRTUAL, channels [0, up_ca) come from x = a [n][hi/2][wi/2][up_ca] read at (iy >> 1, ix >> 1),
   // channels [up_ca, ci) from x2 = skip [n][hi][wi][ci - up_ca].  Uniform-tap loop only (up_ca, ci multiples of the K-tile).
@@ -272,14 +267,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
     if constexpr (UP) rsrc_x2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x2), 0, (int)a.x2_bytes, 0x00020000);
   }
   int u_tl = 0, u_c0 = 0;                     // uniform path: local tap / byte offset inside the tap of the NEXT tile to load
-  int u_ga = 0, u_gb = 0;                     // ... and that tap's (row, column) in the class's tap grid
-  int u_wcur = 0;                             // ... and the weight offset of the tap the loop is in
-  if constexpr (UNI) {
+  int u_ga = 0, u_gb = 0;                     // ... and that tap's (row, column) in the class's tap grid (fused input only)
+  if constexpr (UP) {
     u_ga = a.g_t0[cls] / a.g_nx[cls];
     u_gb = a.g_t0[cls] - u_ga * a.g_nx[cls];
   }
-  const int c_xo0 = a.xo0[cls], c_xoa = a.xoa[cls], c_xob = a.xob[cls];
-  const int c_wo0 = a.wo0[cls], c_woa = a.woa[cls], c_wob = a.wob[cls], c_gnx = a.g_nx[cls];
   const int u_cend = a.ci * ES;
   const int u_ca = UP ? a.up_ca * ES : 0;     // bytes of a virtual pixel that come from the up-sampled source
   auto load_tile = [&](int kt, f32x4* ra, f32x4* rb) {
@@ -290,17 +282,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
       const int tl = u_tl, c0 = u_c0;
       // (dy, dx) of this tap from the grid description: a byte read of a.dy[] / a.dx[] would be a vector memory round trip
       const int dyt = UP ? a.g_dy0[cls] + a.g_sy[cls] * u_ga : 0, dxt = UP ? a.g_dx0[cls] + a.g_sx[cls] * u_gb : 0;
-      const int ga = u_ga, gb = u_gb;
       u_c0 += BKE * ES;
       if (u_c0 == u_cend) {
         u_c0 = 0;
         ++u_tl;
-        if (++u_gb == c_gnx) {
-          u_gb = 0;
-          ++u_ga;
+        if constexpr (UP) {
+          if (++u_gb == a.g_nx[cls]) {
+            u_gb = 0;
+            ++u_ga;
+          }
         }
       }
-      if (c0 == 0) u_wcur = c_wo0 + c_woa * ga + c_wob * gb;      // scalar ALU only
       if constexpr (UP) {
         if (c0 == 0) {                        // new tap, channels [0, up_ca): nearest-x2 source, pixel (iy >> 1, ix >> 1)
           const int w2 = a.wi >> 1;
@@ -318,7 +310,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
         }
       } else {
         if (c0 == 0) {
-          const unsigned s_x = (unsigned)(c_xo0 + c_xoa * ga + c_xob * gb);
+          const unsigned s_x = (unsigned)a.tap_xoff[toff + tl];
 #pragma unroll
           for (int p = 0; p < A_PASS; ++p) u_acur[p] = (u_aoff[p] + s_x) + ((u_ainv[p] >> tl) << 31);
         }
@@ -330,7 +322,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
 #pragma unroll
       for (int p = 0; p < A_PASS; ++p)
         ra[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)u_acur[p], s_a, 0));
-      const int s_w = u_wcur + c0;
+      const int s_w = a.tap_woff[toff + tl] + c0;
 #pragma unroll
       for (int p = 0; p < B_PASS; ++p)
         rb[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (int)u_boff[p], s_w, 0));
@@ -825,40 +817,6 @@ static void finish_args(IgemmArgs& a, long long x_elems, long long w_elems) {
   for (int t = 0; t < total; ++t) {
     a.tap_xoff[t] = (a.dy[t] * a.wi + a.dx[t]) * a.ci * es;
     a.tap_woff[t] = a.wt[t] * a.ci * es;
-  }
-  // the affine forms the kernel evaluates; the weight-tap index is fitted from the table (forward: a * kw + b; a strided data
-  // gradient's parity class: (r0 + s a) kw + q0 + s b) and every tap of every class is checked against the tables
-  for (int c = 0; c < a.nclass; ++c) {
-    const int nx = a.g_nx[c], nt = a.ntaps[c], t0 = a.tap_off[c];
-    a.xo0[c] = (a.g_dy0[c] * a.wi + a.g_dx0[c]) * a.ci * es;
-    a.xoa[c] = a.g_sy[c] * a.wi * a.ci * es;
-    a.xob[c] = a.g_sx[c] * a.ci * es;
-    int P = 0, Q = 0, R = 0;
-    bool haveR = false, haveQ = false;
-    for (int i = 0; i + 1 < nt && !haveR; ++i) {
-      const int g0 = a.g_t0[c] + i, g1 = g0 + 1;
-      if (g0 / nx == g1 / nx) {
-        R = (int)a.wt[t0 + i + 1] - (int)a.wt[t0 + i];
-        haveR = true;
-      }
-    }
-    for (int i = 0; i < nt && !haveQ; ++i)
-      for (int j = i + 1; j < nt && !haveQ; ++j) {
-        const int gi = a.g_t0[c] + i, gj = a.g_t0[c] + j;
-        if (gi / nx != gj / nx && (haveR || gi % nx == gj % nx)) {
-          const int num = (int)a.wt[t0 + j] - (int)a.wt[t0 + i] - R * (gj % nx - gi % nx), den = gj / nx - gi / nx;
-          if (num % den != 0) return;
-          Q = num / den;
-          haveQ = true;
-        }
-      }
-    if (nt > 0) P = (int)a.wt[t0] - Q * (a.g_t0[c] / nx) - R * (a.g_t0[c] % nx);
-    a.wo0[c] = P * a.ci * es; a.woa[c] = Q * a.ci * es; a.wob[c] = R * a.ci * es;
-    for (int tl = 0; tl < nt; ++tl) {
-      const int gi = a.g_t0[c] + tl, ga = gi / nx, gb = gi % nx;
-      if (a.xo0[c] + a.xoa[c] * ga + a.xob[c] * gb != a.tap_xoff[t0 + tl]) return;
-      if (a.wo0[c] + a.woa[c] * ga + a.wob[c] * gb != a.tap_woff[t0 + tl]) return;     // not affine: the generic loop serves it
-    }
   }
   a.x_bytes = (unsigned)(x_elems * es);
   a.w_bytes = (unsigned)(w_elems * es);
