@@ -71,30 +71,73 @@ def pmc_traffic(kernel):
     return None, None
 
 
-def cpu_baseline(encoder, classes, hw, budget_s=25.0):
-    """The CPU oracle (pure-torch restatement of the reference path) on this box's host cores: same step, bounded sample."""
+def host_cores():
+    """The cores this process may actually use: os.cpu_count() clipped by the affinity mask and by the cgroup's CPU quota (the
+    GPU box is a slice of a large host: more threads than granted cores only adds contention)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
+def cpu_baseline(encoder, classes, hw, workload="segmentation", batch=8, warmups=2, timed=5, budget_s=30.0):
+    """The CPU oracle (pure-torch restatement of the reference path) on this box's host cores, as BASELINE.md section 3 plans
+    it: the SAME batch as the GPU leg, fp32, torch.set_num_threads(os.cpu_count()), 2 warm-ups, median of >= 5 timed steps
+    (time.perf_counter).  The sample is bounded: if the warm-ups show that the plan would exceed `budget_s`, fewer steps are
+    timed (never fewer than 3) and `sample` says so."""
     from oracle.unet_ref import UnetRef
-    from oracle.adversarial_ref import segmentation_step
-    cores = min(os.cpu_count() or 1, 16)          # the GPU box grants ~16 host cores per GPU
+    from oracle.adversarial_ref import (AdversarialLossRef, DomainDiscriminatorRef, adversarial_step, segmentation_step,
+                                        synthetic_batch)
+    cores = host_cores()
     torch.set_num_threads(cores)
     torch.manual_seed(1234)
     model = UnetRef(encoder, classes=classes).train()
     opt = torch.optim.Adam(model.parameters(), lr=1e-4)
-    n = 2
-    g = torch.Generator().manual_seed(0)
-    x = torch.randn(n, 3, hw, hw, generator=g)
-    y = torch.randint(0, classes, (n, hw, hw), generator=torch.Generator().manual_seed(1), dtype=torch.int64)
+    x, y, xt = synthetic_batch(batch, hw, hw, classes=classes, seed=0)
+    if workload == "adversarial":
+        D = DomainDiscriminatorRef(3).train()
+        d_opt = torch.optim.Adam(D.parameters(), lr=1e-4)
+        adv = AdversarialLossRef(0.001)
+
+        def one():
+            adversarial_step(model, D, adv, opt, d_opt, x, y, xt)
+        what = "oracle/adversarial_ref.py adversarial_step (D step + segmenter step)"
+    else:
+        def one():
+            segmentation_step(model, opt, x, y)
+        what = "oracle/adversarial_ref.py segmentation_step"
     t0 = time.perf_counter()
-    segmentation_step(model, opt, x, y)            # warm-up (oneDNN primitive creation)
-    warm = time.perf_counter() - t0
-    steps, t0 = 0, time.perf_counter()
-    while steps < 1 or (time.perf_counter() - t0 + warm < budget_s and steps < 8):
-        segmentation_step(model, opt, x, y)
-        steps += 1
-    dt = time.perf_counter() - t0
-    return {"value": round(n * steps / dt, 3), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} steps of batch {n}x3x{hw}x{hw} fp32 (the GPU leg runs batch 8) after 1 warm-up, "
-                      f"torch {torch.__version__} CPU, oracle/unet_ref.py UnetRef({encoder}) + torch.optim.Adam"}
+    for _ in range(warmups):
+        one()                                      # warm-up (oneDNN primitive creation, allocator)
+    warm = (time.perf_counter() - t0) / max(warmups, 1)
+    n_t = timed
+    if warm * (warmups + timed) > budget_s:
+        n_t = max(3, int(budget_s / warm) - warmups)
+    ts = []
+    for _ in range(n_t):
+        t0 = time.perf_counter()
+        one()
+        ts.append(time.perf_counter() - t0)
+    med = percentile(ts, 0.5)
+    return {"value": round(batch / med, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"median of {n_t} steps of batch {batch}x3x{hw}x{hw} fp32 after {warmups} warm-ups ({med:.2f} s per step), "
+                      f"torch {torch.__version__} CPU with {cores} threads, {what} on UnetRef({encoder}) + torch.optim.Adam"}
 
 
 def build_leg(workload, encoder, dtype, batch, size, classes, dev, rank, world, rehearse):
@@ -254,7 +297,7 @@ def roofline_leg(step, model, trainer, dtype, psteps=3, layer_table=False):
                                                       "launches_per_step": k[3] // psteps} for k in kern}}}
 
 
-def also_leg(name, workload, encoder, dtype, batch, size, classes, dev, steps=10, warmup=6):
+def also_leg(name, workload, encoder, dtype, batch, size, classes, dev, steps=10, warmup=6, cpu=False):
     """A short informational leg of another BASELINE config in the same process (N=1 only)."""
     step, model, trainer = build_leg(workload, encoder, dtype, batch, size, classes, dev, 0, 1, False)
     dt, ev_ms, loss = timed_region(step, steps, warmup, 1, dev, False)
@@ -270,6 +313,9 @@ def also_leg(name, workload, encoder, dtype, batch, size, classes, dev, steps=10
            "roofline": {k: roof[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launches_per_step",
                                              "avg_launch_us", "ms_per_step", "hbm_view")},
            "all_conv_kernels_ms_per_step": roof["all_conv_kernels"]["ms_per_step"]}
+    if cpu:
+        out["cpu_baseline"] = cpu_baseline(encoder, classes, size, workload=workload, batch=batch, warmups=1, timed=3,
+                                           budget_s=25.0)
     del step, model, trainer
     torch.cuda.empty_cache()
     return out
@@ -300,9 +346,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N` by itself: start the N ranks as a CHILD process before anything here touches the GPU
+        # (plain subprocess, never an exec), relay its output and exit with its code.
+        import subprocess
+        port = os.environ.get("MASTER_PORT", str(29500 + os.getpid() % 2000))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with python -m torch.distributed.run "
+                         f"--nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ... (or plain `python bench.py --gpus N`)")
     # UDASEG_BENCH_SHARE_GPU=1 + UDASEG_BENCH_BACKEND=gloo: rehearsal of the N>1 control flow on a one-GPU box (all ranks on
     # device 0, collectives through gloo); the real run is one rank per GPU over RCCL
     share = os.environ.get("UDASEG_BENCH_SHARE_GPU", "0") == "1"
@@ -377,7 +433,8 @@ def main():
             del step, model, trainer
             torch.cuda.empty_cache()
             out["also"] = [
-                also_leg("BASELINE cfg 3", "adversarial", "resnet18", "bf16", 8, 512, args.classes, dev),
+                also_leg("BASELINE cfg 3", "adversarial", "resnet18", "bf16", 8, 512, args.classes, dev,
+                         cpu=not args.no_cpu_baseline),
                 also_leg("BASELINE cfg 5 (per-GPU work)", "segmentation", "resnet50", "bf16", 8, 768, args.classes, dev),
             ]
         print(json.dumps(out), flush=True)

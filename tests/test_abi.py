@@ -83,3 +83,38 @@ def test_state_dict_schema_matches_oracle_and_reference_keys():
     d, r = DomainDiscriminator(), DomainDiscriminatorRef()
     assert list(d.state_dict()) == list(r.state_dict())
     assert sum(p.numel() for p in d.parameters()) == 2758849
+
+
+def test_bn_bindings_refuse_mismatched_operands_before_any_launch():
+    """The element-wise C-ABI entry points take one (pixels, c) extent and raw pointers: an operand of another dtype or size
+    would be read or written past its end by the kernel (round 2's tools/bn_bandwidth.py run ended in a GPU memory fault, not
+    an error code: profiles/r02_bn_bandwidth.txt).  The binding refuses such operands with ValueError -- checked here on CPU
+    tensors, i.e. strictly before the library is called."""
+    import torch
+    from uda_aerial_semantic_segmentation_research_amd import kernels as K
+    R = K.bn_replicas()
+    c, px = 16, 64
+    bf, f32 = torch.bfloat16, torch.float32
+    y = torch.zeros(px, c, dtype=bf)
+    vec = lambda: torch.zeros(c)
+    sums = torch.zeros(2 * c * R, dtype=torch.float64)
+    good = dict(y=y, sums=sums, gamma=vec(), beta=vec(), residual=None, z=torch.zeros(px, c, dtype=bf), eps=1e-5, momentum=0.1,
+                running_mean=vec(), running_var=vec(), save_mean=vec(), save_rstd=vec(), act=1, slope=0.0)
+    for bad in (dict(z=torch.zeros(px, c, dtype=f32)),                 # fp32 output for a bf16 launch: written at half its size
+                dict(z=torch.zeros(px // 2, c, dtype=bf)),              # half the pixels
+                dict(residual=torch.zeros(px, c, dtype=f32)),
+                dict(z=torch.zeros(px, 2 * c, dtype=bf)[:, :c]),        # not contiguous
+                dict(gamma=torch.zeros(c // 2)), dict(save_mean=torch.zeros(c, dtype=torch.float64)),
+                dict(sums=torch.zeros(2 * c, dtype=torch.float64)),     # one replica instead of R
+                dict(sums=torch.zeros(2 * c * R))):                     # fp32 accumulators
+        with pytest.raises(ValueError):
+            K.bn_apply(**{**good, **bad})
+    dz, z = torch.zeros(px, c, dtype=bf), torch.zeros(px, c, dtype=bf)
+    with pytest.raises(ValueError):
+        K.bn_bwd_reduce(dz.float(), z, y, vec(), vec(), sums, 1, 0.0)
+    with pytest.raises(ValueError):
+        K.bn_bwd_reduce(dz, z[: px // 2], y, vec(), vec(), sums, 1, 0.0)
+    with pytest.raises(ValueError):
+        K.bn_bwd_apply(dz, z, y, vec(), vec(), vec(), sums, torch.zeros(px, c, dtype=f32), None, vec(), vec(), 1, 0.0)
+    with pytest.raises(ValueError):
+        K.bn_bwd_apply(dz, z, y, vec(), vec(), vec(), sums[: c], dz, None, vec(), vec(), 1, 0.0)

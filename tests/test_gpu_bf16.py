@@ -150,10 +150,17 @@ def test_dgrad_with_bn_backward_reductions_bf16(K, n, h, w, c1, c2, act, slope):
     assert ((s - want).abs() / want.abs().max(dim=1, keepdim=True).values).max().item() < 1e-4
 
 
-@pytest.mark.parametrize("c", [16, 64, 512])
-@pytest.mark.parametrize("act,slope,with_res", [(0, 0.0, False), (1, 0.0, True), (1, 0.2, False)])
-def test_bn_bf16_fwd_bwd(K, c, act, slope, with_res):
-    n, h, w = (2, 6, 10) if c > 64 else (4, 24, 20)
+BN_SMALL = [(c, *v, None) for c in (16, 64, 512) for v in ((0, 0.0, False), (1, 0.0, True), (1, 0.2, False))]
+BN_FULL = [(16, 1, 0.0, False, (8, 512, 512)), (16, 1, 0.0, True, (8, 512, 512))]
+
+
+@pytest.mark.parametrize("c,act,slope,with_res,nhw", BN_SMALL + BN_FULL,
+                         ids=[f"c{c}_act{a}_{sl}_{'res' if r else 'nores'}_{'full' if s else 'small'}" for c, a, sl, r, s in BN_SMALL + BN_FULL])
+def test_bn_bf16_fwd_bwd(K, c, act, slope, with_res, nhw):
+    """The `full` cases run at 8 x 512 x 512 x 16 = 2 097 152 pixels x 16 channels, the first shape of tools/bn_bandwidth.py
+    (the launch that faulted in round 2, profiles/r02_bn_bandwidth.txt): grid-stride loops with four loads in flight, the
+    block-count caps and the tail iterations at a size the small cases never reach."""
+    n, h, w = nhw or ((2, 6, 10) if c > 64 else (4, 24, 20))
     g = torch.Generator().manual_seed(c + act)
     x = rb(torch.randn(n, c, h, w, generator=g) * 2 + 0.5).requires_grad_(True)
     res = rb(torch.randn(n, c, h, w, generator=g)).requires_grad_(True) if with_res else None

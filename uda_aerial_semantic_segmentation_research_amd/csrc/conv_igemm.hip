@@ -689,7 +689,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
       }
     }
   }
-  if (a.stats && !stats_done) {
+  // (bnb_y set but neither bnb epilogue ran -- fp32 off the fast path -- must not pass plain sum(out) / sum(out^2) off as
+  // the BatchNorm-backward sums: the host refuses such launches, this keeps a future host bug from being silent)
+  if (a.stats && !stats_done && (a.bnb_y == nullptr || fast_epi)) {
     // fold the two half-waves (same column), then the WAVES_M waves that share a column through LDS (the K loop is
     // over: its tiles are free), then one f64 atomic per (column, statistic) per block into replica blockIdx % R.
     float* red = As;  // [2][4 waves][TN][32]
@@ -1132,6 +1134,9 @@ static bool dgrad_bnreduce_ok(const udaseg_conv_desc* d) {
   if (check_desc(d) != UDASEG_OK || d->stride != 1 || tile_override() != 0) return false;
   if (d->kh == d->kw && small_conv_applicable(d->kh, d->stride, d->pad, d->co, d->ci)) return false;
   const long long M = (long long)d->n * d->hi * d->wi;
+  // the sums are formed in the kernel's fast epilogue only, which also needs the output to fit a 2 GiB buffer descriptor
+  // (fast_epi in conv_igemm_kernel); beyond that the launch would take the generic epilogue, which knows nothing of bnb_*
+  if (M * d->ci * 4 >= (1LL << 31)) return false;
   if (k_slices((int)M, d->ci, d->kh * d->kw, true) != 1) return false;
   if (d->ci > 32) return M % 64 == 0 && d->ci % 64 == 0;
   return M % 128 == 0 && d->ci % 32 == 0;

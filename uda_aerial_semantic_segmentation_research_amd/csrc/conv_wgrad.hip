@@ -480,8 +480,10 @@ static int launch_wgrad(WgradArgs a, int accumulate, hipStream_t s, bool bf16 = 
   const int tiles = cdiv(a.co, BMW) * cdiv(a.J, BNW);
   // enough blocks for ~4 per CU, at least 256 pixels per split (UDASEG_WGRAD_BLOCKS: tuning aid)
   static int target = -1;
+  static bool target_from_env = false;   // looked up once (the template's instantiations each keep their own copy)
   if (target < 0) {
     const char* e = getenv("UDASEG_WGRAD_BLOCKS");
+    target_from_env = e != nullptr;
     target = e ? atoi(e) : 3072;  // measured sweep 512..8192: 68.7 / 79.4 / 80.3 / 85.9 / 87.0 / 89.1 / 88.8 / 88.1 TFLOP/s
     if (target < 64) target = 3072;
   }
@@ -491,7 +493,7 @@ static int launch_wgrad(WgradArgs a, int accumulate, hipStream_t s, bool bf16 = 
   // (the <= 32-output-channel full-resolution layers -- 32 x 128 tile, 16 KB of partials per block, >= 1 M pixels -- are the
   // exception: latency-bound at two blocks per CU, 2048 blocks: 185 -> 152, 138 -> 120, 128 -> 109 us at 512^2)
   const int bf16_target = (BMW == 32 && a.M >= (1 << 20)) ? 2048 : 512;
-  int splits = cdiv(bf16 && getenv("UDASEG_WGRAD_BLOCKS") == nullptr ? bf16_target : target, tiles);
+  int splits = cdiv(bf16 && !target_from_env ? bf16_target : target, tiles);
   const int max_splits = cdiv(a.M, 256);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;

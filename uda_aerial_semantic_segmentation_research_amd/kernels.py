@@ -196,6 +196,33 @@ def nchw_to_nhwc(x, cpad=None, st=None, dtype=torch.float32):
     return y
 
 
+def _same_layout(who, y, **others):
+    """The element-wise entry points take ONE extent (pixels, c) for all their activation operands and raw pointers for each:
+    a tensor of another dtype or size would be read / written past its end by the kernel (a GPU memory fault, not an error
+    code -- the C-ABI has no per-pointer extents).  The binding therefore refuses operands that do not share y's dtype, element
+    count and device, or are not contiguous.  (Round 2's tools/bn_bandwidth.py fault: profiles/r02_bn_bandwidth.txt.)"""
+    n, dt, dev = y.numel(), y.dtype, y.device
+    if not y.is_contiguous():
+        raise ValueError(f"{who}: y must be contiguous")
+    for name, t in others.items():
+        if t is None:
+            continue
+        if t.dtype is not dt or t.numel() != n or t.device != dev or not t.is_contiguous():
+            raise ValueError(f"{who}: {name} must match y (dtype {dt}, {n} elements, contiguous, {dev}); got dtype {t.dtype}, "
+                             f"{t.numel()} elements on {t.device}")
+
+
+def _channel_vecs(who, c, f64=0, **vecs):
+    """Per-channel operands: fp32 vectors of >= c elements (f64 > 0: f64 accumulators of >= f64 elements)."""
+    for name, t in vecs.items():
+        if t is None:
+            continue
+        want = torch.float64 if f64 else torch.float32
+        need = f64 if f64 else c
+        if t.dtype is not want or t.numel() < need or not t.is_contiguous():
+            raise ValueError(f"{who}: {name} must be a contiguous {want} tensor of >= {need} elements; got {t.dtype}, {t.numel()}")
+
+
 _BN_R = None
 
 
@@ -215,6 +242,10 @@ def bn_stats(y, sums, st=None):
 def bn_apply(y, sums, gamma, beta, residual, z, eps, momentum, running_mean, running_var, save_mean, save_rstd, act, slope,
              st=None):
     c = y.shape[-1]
+    _same_layout("bn_apply", y, residual=residual, z=z)
+    _channel_vecs("bn_apply", c, gamma=gamma, beta=beta, running_mean=running_mean, running_var=running_var,
+                  save_mean=save_mean, save_rstd=save_rstd)
+    _channel_vecs("bn_apply", c, f64=2 * c * bn_replicas(), sums=sums)
     if y.dtype == torch.bfloat16:
         check(_lib.load().udaseg_bn_apply_bf16(y.data_ptr(), sums.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(residual),
                                                 z.data_ptr(), y.numel() // c, c, eps, momentum, _ptr(running_mean),
@@ -237,6 +268,9 @@ def bn_apply_eval(y, gamma, beta, running_mean, running_var, residual, z, eps, a
 def bn_bwd_reduce(dz, z, y, save_mean, save_rstd, bsums, act, slope, st=None, gamma=None, beta=None):
     """z=None (fp32 only, layers without a residual input): the activation's argument is re-evaluated from y, gamma, beta."""
     c = y.shape[-1]
+    _same_layout("bn_bwd_reduce", y, dz=dz, z=z)
+    _channel_vecs("bn_bwd_reduce", c, save_mean=save_mean, save_rstd=save_rstd, gamma=gamma, beta=beta)
+    _channel_vecs("bn_bwd_reduce", c, f64=2 * c * bn_replicas(), bsums=bsums)
     if y.dtype == torch.bfloat16:
         check(_lib.load().udaseg_bn_bwd_reduce_bf16(dz.data_ptr(), _ptr(z), y.data_ptr(), save_mean.data_ptr(),
                                                      save_rstd.data_ptr(), y.numel() // c, c, bsums.data_ptr(), act, slope,
@@ -250,6 +284,9 @@ def bn_bwd_reduce(dz, z, y, save_mean, save_rstd, bsums, act, slope, st=None, ga
 def bn_bwd_apply(dz, z, y, save_mean, save_rstd, gamma, bsums, dy, dres, dgamma, dbeta, act, slope, accumulate_dy=False,
                  accumulate_dres=False, accumulate_param=False, st=None, beta=None):
     c = y.shape[-1]
+    _same_layout("bn_bwd_apply", y, dz=dz, z=z, dy=dy, dres=dres)
+    _channel_vecs("bn_bwd_apply", c, save_mean=save_mean, save_rstd=save_rstd, gamma=gamma, beta=beta, dgamma=dgamma, dbeta=dbeta)
+    _channel_vecs("bn_bwd_apply", c, f64=2 * c * bn_replicas(), bsums=bsums)
     if y.dtype == torch.bfloat16:
         check(_lib.load().udaseg_bn_bwd_apply_bf16(dz.data_ptr(), _ptr(z), y.data_ptr(), save_mean.data_ptr(),
                                                     save_rstd.data_ptr(), gamma.data_ptr(), bsums.data_ptr(), dy.data_ptr(),
