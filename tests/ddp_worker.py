@@ -97,6 +97,44 @@ def main():
     res["avg_err"] = float((g_red - g_mean).abs().max() / g_mean.abs().max())
     res["local_vs_mean"] = float((g_local.double() - g_mean).abs().max() / g_mean.abs().max())   # must be large: ranks differ
 
+    # (2b) STREAM ORDER.  At 2x64x64 the side-stream weight gradients finish in microseconds, long before gloo's host round
+    # trip, so (2) cannot see a missing wait.  Here the side stream is held back by a ~50 ms spin kernel issued right after
+    # begin_backward: the main stream then runs through the whole backward (and every "final" report) while NO weight
+    # gradient has been written yet, and only the comm stream's wait on Plan.ready_events() keeps a bucket from being
+    # averaged early.  The control run drops the side-stream event from ready_events(): the result must then be WRONG -- which
+    # proves that this test would notice ddp.GradAllReducer._launch losing its wait.
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    torch.cuda._sleep(10_000_000)
+    e1.record()
+    torch.cuda.synchronize()
+    cycles_50ms = int(10_000_000 * 50.0 / max(e0.elapsed_time(e1), 1e-3))
+    orig_begin = engine.Plan.begin_backward
+
+    def delayed_begin(self):
+        orig_begin(self)
+        if self.side_stream is not None:
+            with torch.cuda.stream(self.side_stream):
+                torch.cuda._sleep(cycles_50ms)
+    engine.Plan.begin_backward = delayed_begin
+
+    def reduced_backward():
+        net.zero_grad()
+        tr.criterion(net(x), y).backward()
+        red.finish()
+        torch.cuda.synchronize()
+        g = net._grad_arena.detach().cpu().double()
+        return float((g - g_mean).abs().max() / g_mean.abs().max())
+    res["side_stream_in_use"] = bool(engine.SIDE_STREAM_WGRAD)
+    res["avg_err_delayed_side_stream"] = reduced_backward()
+    orig_ready = engine.Plan.ready_events
+    engine.Plan.ready_events = lambda self: orig_ready(self)[:1]        # control: forget the side stream's event
+    res["control_err_without_side_event"] = reduced_backward()
+    engine.Plan.ready_events = orig_ready
+    engine.Plan.begin_backward = orig_begin
+    dist.barrier()
+    net.zero_grad()
+
     # (3) three optimizer steps through the trainer: weights stay bit-identical across ranks
     opt = FusedAdam(net.parameters(), lr=1e-3)
     for _ in range(3):

@@ -250,10 +250,10 @@ def test_unet_bf16_vs_fp32_oracle(K, name, size):
     """bf16 storage / bf16 MFMA against the fp32 CPU oracle.  Stated tolerance ('bf16 configs compared to the
     fp32 CPU result with a stated, looser tolerance'): the logits may be no farther from the fp32 oracle than 1.5x what
     PyTorch's OWN bf16 execution of the same oracle is (measured in the test: 9e-2 for r18, 0.22 for r50 at random init,
-    norm-wise -- a 30-60-layer train-mode-BN net amplifies bf16 rounding that much); loss 1e-2; gradients of the shallow
-    tensors: head 0.05 norm-wise / cosine >= 0.995, last decoder conv 0.25 / 0.97; deeper gradients go through thousands of
-    flipped ReLU mask bits at bf16 resolution (see test_gpu_model.py): finite, and as aligned with the fp32 gradients (median
-    cosine over the tensors) as PyTorch's own bf16 backward is."""
+    norm-wise -- a 30-60-layer train-mode-BN net amplifies bf16 rounding that much); loss 1e-2; EVERY parameter gradient
+    against the fp32 oracle and its bf16-storage emulation under the HIP path's ReLU masks, each tensor within 2x the
+    emulation's own distance from the fp32 gradient + 2^-8 (tests/_parity.py::bf16_grads_vs_oracle; round 2 only compared a
+    median cosine with PyTorch's bf16 run, which any finite gradient passed for r50)."""
     import copy
     from oracle.adversarial_ref import synthetic_batch
     from uda_aerial_semantic_segmentation_research_amd.losses import CrossEntropyLoss
@@ -269,6 +269,7 @@ def test_unet_bf16_vs_fp32_oracle(K, name, size):
     loss_ref.backward()
     e_torch = ((torch_bf16 - logits_ref.detach()).abs().max() / logits_ref.abs().max()).item()
     opt = FusedAdam(net.parameters(), lr=1e-4)
+    net.debug_keep_tape = True               # the gradient check below takes the ReLU masks from this forward's activations
     logits = net(x.cuda())
     assert logits.dtype == torch.float32 and logits.shape == logits_ref.shape
     loss = CrossEntropyLoss()(logits, y.cuda())
@@ -276,30 +277,12 @@ def test_unet_bf16_vs_fp32_oracle(K, name, size):
     e = ((logits.detach().cpu() - logits_ref.detach()).abs().max() / logits_ref.abs().max()).item()
     assert e <= 1.5 * e_torch + 1e-2, f"bf16 logits rel err {e:.3e} vs torch-bf16 {e_torch:.3e}"
     assert abs(loss.item() - loss_ref.item()) <= 1e-2 * loss_ref.item()
-    gref = dict(ref.named_parameters())
-
-    def cosine(u, v):
-        u, v = u.double().flatten(), v.double().flatten()
-        return (u @ v / (u.norm() * v.norm()).clamp_min(1e-300)).item()
-    torch_cos = sorted(cosine(p16.grad, gref[k].grad) for k, p16 in t16.named_parameters())
-    cosines = []
-    for k, p in net.named_parameters():
-        assert p.grad is not None and p.grad.dtype == torch.float32 and torch.isfinite(p.grad).all(), k
-        a, b = p.grad.detach().double().cpu().flatten(), gref[k].grad.double().flatten()
-        cos = (a @ b / (a.norm() * b.norm()).clamp_min(1e-300)).item()
-        cosines.append(cos)
-        rel = ((a - b).abs().max() / b.abs().max()).item()
-        if k.startswith("segmentation_head"):                 # nothing but the loss behind it
-            assert rel <= 0.05 and cos >= 0.995, f"{k}: rel {rel:.3e} cos {cos:.4f}"
-        elif k.startswith("decoder.blocks.4.conv2"):          # one BN+ReLU behind it: ~1e3 mask bits flip at bf16 resolution
-            assert rel <= 0.25 and cos >= 0.97, f"{k}: rel {rel:.3e} cos {cos:.4f}"
-    cosines.sort()
-    med, tmed = cosines[len(cosines) // 2], torch_cos[len(torch_cos) // 2]
-    print(f"{name} bf16: logits rel err {e:.2e} (torch bf16 on CPU: {e_torch:.2e}); gradient cosine vs fp32 oracle: "
-          f"min {cosines[0]:.3f} median {med:.3f} (torch bf16: min {torch_cos[0]:.3f} median {tmed:.3f})")
-    # at random init bf16 rounding scrambles deep gradients for ANY implementation (torch's own bf16 backward: median cosine
-    # 0.81 for r18, 0.12 for r50): be at least as aligned with the fp32 gradients as PyTorch's bf16 run, minus a margin
-    assert med >= tmed - 0.15, (med, tmed)
+    # EVERY parameter gradient against an oracle value: the fp32 oracle and its bf16-storage emulation, both with the HIP
+    # path's ReLU masks forced in (tests/_parity.py::bf16_grads_vs_oracle states the rule and why it has this form)
+    from _parity import bf16_grads_vs_oracle
+    bf16_grads_vs_oracle(net, ref, x, lambda out: F.cross_entropy(out, y), f"{name} bf16 2x{size}x{size}")
+    print(f"{name} bf16: logits rel err {e:.2e} (torch bf16 on CPU: {e_torch:.2e})")
+    net.debug_keep_tape, net._last_tape = False, None
     opt.step()
     losses = []
     for _ in range(8):

@@ -16,7 +16,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from _parity import bf16_storage_emulation, pair
+from _parity import (bf16_grads_vs_oracle, bf16_rule, bf16_storage_emulation, d_bf16_emulation, l2rel, pair)
 
 pytestmark = pytest.mark.gpu
 
@@ -51,7 +51,36 @@ def test_cfg3_adversarial_iteration_full_size_bf16():
     w_before = net._arena.clone()
     d_before = tr.discriminator._arena.clone()
     opt = FusedAdam(net.parameters(), lr=1e-4)
+    # gradients INSIDE the iteration: the discriminator's, as its optimizer sees them (after d_loss.backward()), and the
+    # segmenter's (left in .grad after the iteration; its weights have moved by then, the oracle's have not yet)
+    tr.discriminator_optimizer = FusedAdam(tr.discriminator.parameters(), lr=1e-4)
+    d_grads = {}
+    d_step = tr.discriminator_optimizer.step
+
+    def snap_then_step(*a, **kw):
+        d_grads.update({k: p.grad.detach().float().cpu().clone() for k, p in tr.discriminator.named_parameters()})
+        return d_step(*a, **kw)
+    tr.discriminator_optimizer.step = snap_then_step
+    net.debug_keep_tape = True
     avg, dm = tr.train_epoch([(src, masks)], [tgt], opt, epoch=1)
+    bf16_grads_vs_oracle(net, ref, src, lambda out: F.cross_entropy(out, masks), "cfg3 segmenter 8x512x512 bf16")
+    net.debug_keep_tape, net._last_tape = False, None
+    adv = AdversarialLossRef(0.001)
+    d_state = {k: v.clone() for k, v in Dr.state_dict().items()}
+
+    def d_step_grads():
+        Dr.zero_grad()
+        adv.discriminator_loss(Dr(src), Dr(tgt)).backward()
+        g = {k: p.grad.detach().clone() for k, p in Dr.named_parameters()}
+        Dr.load_state_dict(d_state)
+        Dr.zero_grad()
+        return g
+    g32 = d_step_grads()
+    with d_bf16_emulation(Dr):
+        gE = d_step_grads()
+    assert set(d_grads) == set(g32)
+    bf16_rule([(k, l2rel(d_grads[k], g32[k]), ((d_grads[k].double() - gE[k].double()).norm() / g32[k].double().norm()).item(),
+                l2rel(gE[k], g32[k])) for k in g32], "cfg3 discriminator step gradients (hip-vs-fp32 / hip-vs-emulation / spread)")
     r = adversarial_step(ref, Dr, AdversarialLossRef(0.001), torch.optim.Adam(ref.parameters(), lr=1e-4),
                          torch.optim.Adam(Dr.parameters(), lr=1e-4), src, masks, tgt)
     for k in ("seg_loss", "d_loss", "adv_loss"):
@@ -98,6 +127,7 @@ def test_cfg5_r50_768_bf16_forward_loss_and_gradient_properties():
     xd, yd = x.cuda(), y.cuda()
     crit = CrossEntropyLoss()
     opt = FusedAdam(net.parameters(), lr=1e-4)
+    net.debug_keep_tape = True
     logits = net(xd)
     assert logits.dtype == torch.float32 and logits.shape == (8, 23, 768, 768)
     loss = crit(logits, yd)
@@ -108,6 +138,9 @@ def test_cfg5_r50_768_bf16_forward_loss_and_gradient_properties():
     assert abs(loss.item() - loss_ref) <= 1e-2 * loss_ref
     del logits_ref
     loss.backward()
+    # every parameter gradient at full size against the oracle (two CPU backward passes: fp32 and bf16-storage emulation)
+    bf16_grads_vs_oracle(net, ref, x, lambda out: F.cross_entropy(out, y), "cfg5 r50 8x768x768 bf16")
+    net.debug_keep_tape, net._last_tape = False, None
     g1 = net._grad_arena.clone()
     assert torch.isfinite(g1).all() and g1.abs().max() > 0
     net.zero_grad()

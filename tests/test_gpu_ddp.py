@@ -43,6 +43,12 @@ def test_two_ranks_real_unet(tmp_path):
         assert res["local_vs_mean"] > 1e-2                      # the two shards really produce different gradients
         # observed 8.2e-7: the two backward passes differ by the order of the fp32 split-K atomics only
         assert res["avg_err"] <= 5e-6, f"all-reduced arena differs from the mean of the ranks' gradients by {res['avg_err']:.3e}"
+        # stream order: weight gradients held back 50 ms on the side stream are still inside the averaged arena ...
+        assert res["side_stream_in_use"]
+        assert res["avg_err_delayed_side_stream"] <= 5e-6, \
+            f"a bucket was all-reduced before its side-stream weight gradients landed: {res['avg_err_delayed_side_stream']:.3e}"
+        # ... and the same run with the side stream's event dropped from Plan.ready_events() is caught (the test has teeth)
+        assert res["control_err_without_side_event"] > 1e-2, res["control_err_without_side_event"]
         assert res["weights_equal_after_steps"] and res["weights_moved"]
         assert res["bn_buffers_local"]
         assert res["double_backward_raises"]
