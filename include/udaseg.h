@@ -330,6 +330,37 @@ int udaseg_gap_bwd_param(const float* dp, const float* p, const float* pooled, f
                          int accumulate_param, void* stream);
 int udaseg_pack_dgrad_batched_bf16(const float* arena, void* packed, const int* table, int entries, void* stream);
 
+/* ---- bf16-first convolution kernels (round 3; csrc/conv_halo_bf16.hip): stride-1 3x3 / pad 1 and 1x1 / pad 0 convolutions of
+ *      smp.Unet.forward and their data gradients (reference src/models/train.py:341,343; src/models/adversarial_trainer.py:104,113)
+ *      for BASELINE configs 3 and 5.  The block stages the input halo of a channel chunk once into LDS, the weights arrive
+ *      pre-packed in MFMA-fragment order and never touch LDS.
+ *
+ *      Fragment packing of a convolution with N produced / K gathered channels and a ks x ks window:
+ *        packed[nb][dx][k16][dy][lane][j]  (nb < ceil(N/32), k16 < ceil(K/16), lane < 64, j < 8; bf16; udaseg_frag_elems elements)
+ *          = Wsrc[n = 32 nb + (lane & 31)][tap][k = 16 k16 + 8 (lane >> 5) + j]   (zero where n >= N or k >= K)
+ *      forward: Wsrc = the bf16 OHWI weights (N = co, K = ci, tap = dy*ks + dx); data gradient: Wsrc = the bf16 dgrad packing
+ *      [ci][taps][co] (N = ci, K = co) with the window flipped.  udaseg_pack_frag_batched_bf16 packs every convolution of a
+ *      network in one launch: table[i] = {mode (0 forward from w16 / 1 data gradient from wt16), source element offset,
+ *      destination element offset, N, K, ks} (int32 x 6, device memory). ---- */
+int64_t udaseg_frag_elems(int n_out, int k_in, int ks);
+int udaseg_pack_frag_batched_bf16(const void* w16, const void* wt16, void* packed, const int* table, int entries, void* stream);
+/* 1 when the convolution (dgrad = 0: forward, gathers ci and produces co; dgrad = 1: its data gradient; up_ca > 0: forward on the
+ * fused decoder input cat([nearest_x2(a), skip]) with up_ca channels from a) can take these kernels */
+int udaseg_conv_frag_ok(const udaseg_conv_desc* d, int dgrad, int up_ca);
+/* y = act(conv(X, w) + bias) (+ BatchNorm statistics of conv(X, w) + bias into stats, as udaseg_conv2d_fwd_bnstats).
+ * X = x [n][h][w][ci], or with up_ca > 0 the virtual cat([nearest_x2(x [n][h/2][w/2][up_ca]), skip [n][h][w][ci - up_ca]]), or with
+ * in_scale / in_shift (fp32 [ci]) the producer's BatchNorm + activation applied on the fly: X = in_act(x * in_scale + in_shift)
+ * rounded to bf16 -- the normalised activation of a single-consumer layer never reaches HBM.  out_f32: y is fp32 (logits). */
+int udaseg_conv2d_fwd_frag_bf16(const udaseg_conv_desc* d, const void* x, const void* skip, int up_ca, const void* wfrag,
+                                const float* bias, const float* in_scale, const float* in_shift, int in_act, float in_slope,
+                                void* y, int out_f32, int act, float slope, double* stats, void* stream);
+/* dx = conv_transpose(dy, w) from the data-gradient fragment packing.  split > 0: channels [0, split) of the gradient go to dx
+ * [n][h][w][split], the rest to dx2 (the two sources of a fused decoder input).  prev_y != NULL: also the BatchNorm-backward
+ * reductions of the layer behind (as udaseg_conv2d_dgrad_bnreduce_bf16). */
+int udaseg_conv2d_dgrad_frag_bf16(const udaseg_conv_desc* d, const void* dy, const void* wfrag_t, void* dx, void* dx2, int split,
+                                  const void* prev_y, const float* save_mean, const float* save_rstd, const float* gamma,
+                                  const float* beta, int bn_act, float bn_slope, double* bsums, void* stream);
+
 /* ---- diagnosis: while a device buffer of 6 * blocks u64 is registered, every implicit-GEMM launch of at most `blocks` blocks
  *      writes per block {entry, first tile load, end of K loop, exit} (100 MHz wall-clock ticks), HW_ID and XCC_ID into it
  *      (tools/igemm_timeline.py).  NULL switches it off.  Not for timed runs. ---- */

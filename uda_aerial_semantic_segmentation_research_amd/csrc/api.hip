@@ -34,7 +34,7 @@ struct KRec {
 };
 // exactly the symbols rocprofv3 prints (minus "void udaseg::" and the parameter list), so HIP-event and rocprof averages
 // can be compared per kernel
-static const char* const g_knames[PROF_NKERNELS] = {
+static const char* const g_knames_fixed[PROF_NKERNELS] = {
     "conv_igemm_kernel<128, 128, 2, 2, false, false, false>", "conv_igemm_kernel<128, 64, 2, 2, false, false, false>",
     "conv_igemm_kernel<64, 64, 2, 2, false, false, false>",   "conv_igemm_kernel<128, 32, 4, 1, false, false, false>",
     "conv3x3_small_kernel<1, 1>",                             "conv3x3_small_kernel<2, 1>",
@@ -47,7 +47,24 @@ static const char* const g_knames[PROF_NKERNELS] = {
     "conv_wgrad_kernel<64, 64, 2, 2, true>",                  "conv_wgrad_kernel<32, 128, 1, 4, true>",
     "conv_igemm_kernel<128, 128, 2, 2, false, true, true>",   "conv_igemm_kernel<128, 64, 2, 2, false, true, true>",
     "conv_igemm_kernel<64, 64, 2, 2, false, true, true>",     "conv_igemm_kernel<128, 32, 4, 1, false, true, true>"};
-static std::vector<KRec> g_krecs[PROF_NKERNELS];
+// ids 0 .. PROF_NKERNELS-1 are the fixed table above; kernels added later register their rocprofv3 symbol on first launch
+// (kprof_id) and get the next id, up to PROF_MAX_KERNELS
+constexpr int PROF_MAX_KERNELS = 160;
+static std::vector<KRec> g_krecs[PROF_MAX_KERNELS];
+static char g_knames_dyn[PROF_MAX_KERNELS][160];
+static int g_nkernels = PROF_NKERNELS;
+
+int kprof_id(const char* name) {
+  for (int k = PROF_NKERNELS; k < g_nkernels; ++k)
+    if (strcmp(g_knames_dyn[k], name) == 0) return k;
+  if (g_nkernels >= PROF_MAX_KERNELS) return PROF_NKERNELS;   // table full: lump into the first dynamic entry
+  strncpy(g_knames_dyn[g_nkernels], name, sizeof(g_knames_dyn[0]) - 1);
+  return g_nkernels++;
+}
+static const char* kname(int kid) {
+  if (kid < 0 || kid >= g_nkernels) return "";
+  return kid < PROF_NKERNELS ? g_knames_fixed[kid] : g_knames_dyn[kid];
+}
 static std::vector<ProfRec> g_recs[2];
 static std::vector<hipEvent_t> g_pool;
 static hipEvent_t g_open[2];
@@ -73,7 +90,7 @@ hipEvent_t kprof_begin(hipStream_t s) {
 void kprof_end(int kid, hipEvent_t a, hipStream_t s, double flops) {
   if (!a) return;
   hipEvent_t b = get_event();
-  if (!b) return;
+  if (!b || kid < 0 || kid >= PROF_MAX_KERNELS) return;
   (void)hipEventRecord(b, s);
   g_krecs[kid].push_back({a, b, flops});
 }
@@ -124,7 +141,7 @@ extern "C" int udaseg_prof_reset(void) {
     }
     g_recs[f].clear();
   }
-  for (int k = 0; k < PROF_NKERNELS; ++k) {
+  for (int k = 0; k < g_nkernels; ++k) {
     for (auto& r : g_krecs[k]) {
       g_pool.push_back(r.a);
       g_pool.push_back(r.b);
@@ -181,11 +198,11 @@ extern "C" int udaseg_set_option(int key, int value) {
   return UDASEG_OK;
 }
 
-extern "C" int udaseg_prof_kernel_count(void) { return PROF_NKERNELS; }
-extern "C" const char* udaseg_prof_kernel_name(int kid) { return (kid >= 0 && kid < PROF_NKERNELS) ? g_knames[kid] : ""; }
+extern "C" int udaseg_prof_kernel_count(void) { return g_nkernels; }
+extern "C" const char* udaseg_prof_kernel_name(int kid) { return kname(kid); }
 
 extern "C" int udaseg_prof_kernel_read(int kid, double* total_ms, double* total_flops, int64_t* launches) {
-  UDASEG_CHECK_ARG(kid >= 0 && kid < PROF_NKERNELS && total_ms && total_flops && launches, "prof_kernel_read: bad arguments");
+  UDASEG_CHECK_ARG(kid >= 0 && kid < g_nkernels && total_ms && total_flops && launches, "prof_kernel_read: bad arguments");
   double ms = 0.0, fl = 0.0;
   for (auto& r : g_krecs[kid]) {
     hipError_t e = hipEventSynchronize(r.b);

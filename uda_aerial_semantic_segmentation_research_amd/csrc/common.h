@@ -171,6 +171,7 @@ int launch_small_wgrad(const float* x, const float* dy, float* dw, int n, int h,
 
 // live launch timing (bench.py roofline leg): per API call (prof_*) and per kernel launch (kprof_*)
 constexpr int PROF_NKERNELS = 24;
+int kprof_id(const char* rocprof_symbol);   // id of a kernel symbol outside the fixed table (registered on first use)
 hipEvent_t kprof_begin(hipStream_t s);
 void kprof_end(int kid, hipEvent_t a, hipStream_t s, double flops);
 void prof_begin(int family, hipStream_t s);

@@ -1,0 +1,594 @@
+// bf16-first convolution kernels (round 3): stride-1 3x3 / pad 1 and 1x1 / pad 0 convolutions, forward and data gradient, NHWC
+// bf16 storage, fp32 accumulation on v_mfma_f32_32x32x16_bf16 (gfx950).
+//
+// Replaces, for BASELINE configs 3 and 5 (bf16), the shared fp32 / bf16 implicit-GEMM source (conv_igemm.hip) on the layers that
+// torch.nn.functional.conv2d / its autograd reach from smp.Unet.forward (reference src/models/train.py:341,343;
+// src/models/adversarial_trainer.py:104,113).  Why a second kernel: at bf16 MFMA rates the 64x64-tile gather re-reads every
+// input pixel nine times through L2 (32 FLOP per L2 byte; measured 0.12 of the MFMA peak AND 0.12 of HBM, bound by neither:
+// profiles/r02_kernel_stats_bf16_*.csv).  Here
+//   * a block owns a TH x TW patch of output pixels and stages the (TH+2) x (TW+2) input HALO of a channel chunk ONCE into LDS
+//     (padded pixel rows: conflict-free ds_read_b128); the nine taps are nine shifted reads of that halo;
+//   * the weights never touch LDS: they arrive pre-packed in MFMA-fragment order (udaseg_pack_frag_batched_bf16), one
+//     1 KB coalesced load per fragment straight into registers, and a fragment is used for every row block the wave owns;
+//   * operands are swapped (weights = MFMA A, pixels = MFMA B): an accumulator lane then holds 4 consecutive CHANNELS of one
+//     pixel, the epilogue exchanges one register pair with the lane's partner (v_permlane32_swap) and writes 16-byte
+//     row-contiguous bf16 stores straight from registers -- no LDS round trip, no barrier;
+//   * the fused decoder input (cat([nearest_x2(a), skip])) is a chunk-uniform choice of source during staging, the data
+//     gradient's split output a block-uniform choice of destination;
+//   * training-mode BatchNorm + activation of the PRODUCER can be applied while the halo is staged (in_scale / in_shift): the
+//     normalised activation of a single-consumer layer is then never written to HBM.
+// FLOP per L2 byte rises from 32 to 160-200; the kernels are then bound by HBM (most layers) or by the weight stream from L2
+// (the deep, low-resolution layers).
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace udaseg {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct HaloArgs {
+  const void* x;        // gathered tensor [n][h][w][cx] bf16, or the HALF-resolution tensor a [n][h/2][w/2][up_ca] (up_ca > 0)
+  const void* x2;       // up_ca > 0: the full-resolution skip tensor [n][h][w][ci - up_ca] (null when ci == up_ca)
+  const void* wf;       // fragment-packed weights (see pack_frag_batched_bf16_kernel)
+  const float* bias;    // [co] or null
+  void* y;              // [n][h][w][co] bf16 (fp32 when out_f32), or channels [0, split_n) of a split output
+  void* y2;             // channels [split_n, co) of a split output
+  int n, h, w;          // output = input extent (stride 1, "same" padding)
+  int ci, co;           // gathered / produced channel counts
+  int up_ca, split_n;
+  int out_f32, act;
+  float slope;
+  double* stats;        // [R][2][co] f64: BatchNorm statistics of the output, or the bnb_* sums
+  // BatchNorm-backward reductions of the layer behind a data gradient (see IgemmArgs::bnb_* in conv_igemm.hip)
+  const void* bnb_y;
+  const float* bnb_mean;
+  const float* bnb_rstd;
+  const float* bnb_gamma;
+  const float* bnb_beta;
+  int bnb_act;
+  float bnb_slope;
+  // producer's BatchNorm + activation applied to the gathered tensor while it is staged: v -> act(v * in_scale[c] + in_shift[c])
+  const float* in_scale;
+  const float* in_shift;
+  int in_act;
+  float in_slope;
+  int ntx, nty, ncb;    // tiles along x / y, channel blocks of 32 * WN
+  int nk16;             // ci / 16
+  unsigned x_bytes, x2_bytes, w_bytes, y_bytes, y2_bytes, bnb_bytes;
+};
+
+constexpr int HALO_STATS_REPLICAS = 16;   // == udaseg_bn_replicas()
+
+template <int KS, int CK, int WM, int WN, int RPW, int TW>
+struct HaloCfg {
+  static constexpr int NT = 64 * WM * WN;
+  static constexpr int RB = 32 / TW;               // image rows per 32-pixel MFMA block
+  static constexpr int TH = WM * RPW * RB;
+  static constexpr int PAD = KS / 2;
+  static constexpr int HR = TH + KS - 1, HWD = TW + KS - 1;
+  static constexpr int OCT = CK / 8;               // 16-byte pieces per pixel per chunk
+  static constexpr int STRIDE = CK * 2 + 16;       // padded pixel row in LDS (bytes)
+  static constexpr int NPIECE = HR * HWD * OCT;
+  static constexpr int NI = (NPIECE + NT - 1) / NT;
+  static constexpr int LDS_HALO = HR * HWD * STRIDE;
+  static constexpr int LDS_RED = 2 * WM * WN * 32 * 4;   // [2][waves][32] floats
+  static constexpr int LDS = LDS_HALO > LDS_RED ? LDS_HALO : LDS_RED;
+  static constexpr int S = RB * (RPW - 1) + KS;   // distinct start rows of pixel fragments per (dx, k16)
+  static constexpr int GPC = KS * (CK / 16);       // (dx, k16) groups per chunk
+};
+
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+  return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)a) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)b) << 16);
+}
+__device__ __forceinline__ float bf_lo(unsigned d) { return __builtin_bit_cast(float, d << 16); }
+__device__ __forceinline__ float bf_hi(unsigned d) { return __builtin_bit_cast(float, d & 0xffff0000u); }
+
+template <int KS, int CK, int WM, int WN, int RPW, int TW>
+__global__ __launch_bounds__(64 * WM * WN, 2) void conv_halo_bf16_kernel(const HaloArgs a) {
+  using C = HaloCfg<KS, CK, WM, WN, RPW, TW>;
+  static_assert(C::NT % C::OCT == 0, "a thread stages one fixed channel octet");
+  static_assert(TW == 32 || TW == 16, "tile width");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lp = lane & 31, lh = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+
+  // ---- block -> (image, tile, channel block); XCD-aware: blocks sharing blockIdx % 8 take a contiguous run of tiles
+  int bid = blockIdx.x;
+  {
+    const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int cb = bid % a.ncb;
+  int t = bid / a.ncb;
+  const int tx = t % a.ntx;
+  t /= a.ntx;
+  const int ty = t % a.nty;
+  const int img = t / a.nty;
+  const int y0 = ty * C::TH, x0 = tx * TW;
+  const int H = a.h, W = a.w;
+
+  // ---- staging slots: piece = tid + i * NT -> (halo pixel, octet)
+  const int oct = tid % C::OCT;
+  unsigned voff[C::NI], voff2[C::NI];
+  unsigned okbits = 0;
+  const bool UPC = a.up_ca > 0;
+  const int cx = UPC ? a.up_ca : a.ci, cx2 = a.ci - a.up_ca;
+#pragma unroll
+  for (int i = 0; i < C::NI; ++i) {
+    const int piece = tid + i * C::NT;
+    const int pix = piece / C::OCT;
+    const int hy = pix / C::HWD, hx = pix - hy * C::HWD;
+    const int iy = y0 + hy - C::PAD, ix = x0 + hx - C::PAD;
+    const bool ok = piece < C::NPIECE && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+    okbits |= (ok ? 1u : 0u) << i;
+    if (UPC) {
+      voff[i] = ok ? (unsigned)((((img * (H >> 1) + (iy >> 1)) * (W >> 1) + (ix >> 1)) * cx + oct * 8) * 2) : 0x80000000u;
+      voff2[i] = ok ? (unsigned)((((img * H + iy) * W + ix) * cx2 + oct * 8) * 2) : 0x80000000u;
+    } else {
+      voff[i] = ok ? (unsigned)((((img * H + iy) * W + ix) * cx + oct * 8) * 2) : 0x80000000u;
+      voff2[i] = 0x80000000u;
+    }
+  }
+  __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_x2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(UPC && a.x2 ? a.x2 : a.x), 0,
+                                                                   (int)(UPC && a.x2 ? a.x2_bytes : 0u), 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wf), 0, (int)a.w_bytes, 0x00020000);
+
+  // ---- this wave's channel block and its fragment stream
+  const int nblocks32 = (a.co + 31) >> 5;
+  int nb = cb * WN + wn;
+  const bool wave_live = nb < nblocks32;          // a dead wave (co not a multiple of 32 * WN) computes on block 0 and stores nothing
+  if (!wave_live) nb = 0;
+  const int frag_per_nb = KS * a.nk16 * KS;       // fragments of one 32-channel block: [dx][k16][dy]
+  const unsigned wlane = (unsigned)(nb * frag_per_nb) * 1024u + (unsigned)lane * 16u;
+
+  // pixel fragment base address in the halo: lane pixel (ly, lx), K half lh
+  const int ly = lp / TW, lx = lp % TW;
+  const int pbase = ((wm * RPW * C::RB + ly) * C::HWD + lx) * C::STRIDE + lh * 16;
+
+  f32x16 acc[RPW];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[r][v] = 0.f;
+
+  const int nchunk = (a.ci + CK - 1) / CK;
+  u32x4 stage[C::NI];
+  auto load_chunk = [&](int c) {
+    const int cbeg = c * CK;
+    const bool second = UPC && cbeg >= a.up_ca;
+    const int soff = (second ? cbeg - a.up_ca : cbeg) * 2;
+    // channel tail (gathered channels not a multiple of the chunk, e.g. the 24-channel logits gradient): octets past the last
+    // channel read zeros instead of the next pixel (their weights are zero, but 0 x NaN is not)
+    const unsigned kill = (cbeg + oct * 8 < a.ci) ? 0u : 0x80000000u;
+    if (second) {
+#pragma unroll
+      for (int i = 0; i < C::NI; ++i) stage[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x2, (int)(voff2[i] | kill), soff, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < C::NI; ++i) stage[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(voff[i] | kill), soff, 0);
+    }
+  };
+  auto store_chunk = [&](int c) {
+    if (a.in_scale != nullptr) {
+      // the producer's BatchNorm + activation, applied in registers; halo pixels outside the image stay zero (the padding is
+      // applied to the ACTIVATION, after the transform)
+      const int ch = c * CK + oct * 8;
+      const f32x4 s0 = *reinterpret_cast<const f32x4*>(a.in_scale + ch), s1 = *reinterpret_cast<const f32x4*>(a.in_scale + ch + 4);
+      const f32x4 h0 = *reinterpret_cast<const f32x4*>(a.in_shift + ch), h1 = *reinterpret_cast<const f32x4*>(a.in_shift + ch + 4);
+#pragma unroll
+      for (int i = 0; i < C::NI; ++i) {
+        u32x4 d = stage[i];
+        const bool ok = (okbits >> i) & 1u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float sc0 = e < 2 ? s0[2 * e] : s1[2 * e - 4], sc1 = e < 2 ? s0[2 * e + 1] : s1[2 * e - 3];
+          const float sh0 = e < 2 ? h0[2 * e] : h1[2 * e - 4], sh1 = e < 2 ? h0[2 * e + 1] : h1[2 * e - 3];
+          float t0 = __builtin_fmaf(bf_lo(d[e]), sc0, sh0), t1 = __builtin_fmaf(bf_hi(d[e]), sc1, sh1);
+          t0 = act_apply(t0, a.in_act, a.in_slope);
+          t1 = act_apply(t1, a.in_act, a.in_slope);
+          d[e] = ok ? pack_bf16x2(t0, t1) : 0u;
+        }
+        stage[i] = d;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < C::NI; ++i) {
+      const int piece = tid + i * C::NT;
+      if (i < C::NI - 1 || piece < C::NPIECE) {
+        const int pix = piece / C::OCT;
+        *reinterpret_cast<u32x4*>(smem + pix * C::STRIDE + oct * 16) = stage[i];
+      }
+    }
+  };
+
+  // weight fragments of (chunk c, group g = dx * (CK/16) + k): KS fragments (dy), contiguous 1 KB each
+  u32x4 bcur[KS], bnxt[KS];
+  auto load_b = [&](int c, int g, u32x4* bf) {
+    const int dx = g / (CK / 16), k = g % (CK / 16);
+    const int f0 = (dx * a.nk16 + c * (CK / 16) + k) * KS;
+#pragma unroll
+    for (int dy = 0; dy < KS; ++dy) bf[dy] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)wlane, (f0 + dy) * 1024, 0);
+  };
+
+  load_chunk(0);
+  load_b(0, 0, bnxt);
+  for (int c = 0; c < nchunk; ++c) {
+    store_chunk(c);
+    __syncthreads();
+    if (c + 1 < nchunk) load_chunk(c + 1);
+#pragma unroll
+    for (int g = 0; g < C::GPC; ++g) {
+#pragma unroll
+      for (int dy = 0; dy < KS; ++dy) bcur[dy] = bnxt[dy];
+      // prefetch the next group's fragments (next chunk's first group at the end of a chunk; clamped on the very last group)
+      if (g + 1 < C::GPC) load_b(c, g + 1, bnxt);
+      else load_b(c + 1 < nchunk ? c + 1 : c, 0, bnxt);
+      const int dx = g / (CK / 16), k = g % (CK / 16);
+#pragma unroll
+      for (int s = 0; s < C::S; ++s) {
+        const u32x4 pf = *reinterpret_cast<const u32x4*>(smem + pbase + (s * C::HWD + dx) * C::STRIDE + k * 32);
+#pragma unroll
+        for (int dy = 0; dy < KS; ++dy) {
+          if ((s - dy) >= 0 && (s - dy) % C::RB == 0 && (s - dy) / C::RB < RPW) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int r = (s - dy) / C::RB;
+            acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bcur[dy]), __builtin_bit_cast(bf16x8, pf),
+                                                             acc[r], 0, 0, 0);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue.  acc[r][v] of lane (lp, lh): channel nb*32 + (v&3) + 8*(v>>2) + 4*lh of pixel (row block r, lane pixel lp)
+  const int cbase = nb * 32;
+  void* yb = a.y;
+  int ldc = a.co, csub = 0;
+  unsigned ybytes = a.y_bytes;
+  if (a.split_n > 0) {
+    if (cbase >= a.split_n) { yb = a.y2; ldc = a.co - a.split_n; csub = a.split_n; ybytes = a.y2_bytes; }
+    else ldc = a.split_n;
+  }
+  __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(yb, 0, (int)ybytes, 0x00020000);
+  const bool want_stats = a.stats != nullptr && a.bnb_y == nullptr;
+  const bool want_bnb = a.bnb_y != nullptr;
+  float sA[16], sB[16];
+#pragma unroll
+  for (int v = 0; v < 16; ++v) sA[v] = sB[v] = 0.f;
+  float bv[16];
+#pragma unroll
+  for (int v = 0; v < 16; ++v) bv[v] = 0.f;
+  if (a.bias != nullptr) {
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int c = cbase + (v & 3) + 8 * (v >> 2) + 4 * lh;
+      bv[v] = c < a.co ? a.bias[c] : 0.f;
+    }
+  }
+  __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(want_bnb ? a.bnb_y : a.x), 0,
+                                                                  (int)(want_bnb ? a.bnb_bytes : 0u), 0x00020000);
+  const int es = a.out_f32 ? 4 : 2;
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    const int oy = y0 + (wm * RPW + r) * C::RB + ly, ox = x0 + lx;
+    const bool pv = wave_live && oy < H && ox < W;
+    const unsigned pixoff = (unsigned)((img * H + oy) * W + ox);
+    unsigned dw[8];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int c0 = cbase + 8 * g + 4 * lh;      // this lane's 4 consecutive channels of group g
+      const bool cv = pv && c0 < a.co;
+      float val[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) val[e] = acc[r][4 * g + e] + bv[4 * g + e];
+      if (want_stats) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float q = cv ? val[e] : 0.f;
+          sA[4 * g + e] += q;
+          sB[4 * g + e] = __builtin_fmaf(q, q, sB[4 * g + e]);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) val[e] = act_apply(val[e], a.act, a.slope);
+      if (a.out_f32) {
+        const unsigned off = cv ? (pixoff * (unsigned)ldc + (unsigned)(c0 - csub)) * 4u : 0x80000000u;
+        u32x4 d;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] = __builtin_bit_cast(unsigned, val[e]);
+        __builtin_amdgcn_raw_buffer_store_b128(d, rs_y, (int)off, 0, 0);
+      } else {
+        dw[2 * g] = pack_bf16x2(val[0], val[1]);
+        dw[2 * g + 1] = pack_bf16x2(val[2], val[3]);
+        if (want_bnb) {
+          // g from the bf16-ROUNDED gradient (what a stand-alone bn_bwd_reduce would read back), the activation's argument
+          // re-evaluated from the producer's conv output with bn_apply's own fused multiply-add
+          const unsigned poff = cv ? (pixoff * (unsigned)a.co + (unsigned)c0) * 2u : 0x80000000u;
+          const u32x2 yv = __builtin_amdgcn_raw_buffer_load_b64(rs_p, (int)poff, 0, 0);
+          const f32x4 mu = *reinterpret_cast<const f32x4*>(a.bnb_mean + (c0 < a.co ? c0 : 0));
+          const f32x4 rsd = *reinterpret_cast<const f32x4*>(a.bnb_rstd + (c0 < a.co ? c0 : 0));
+          const f32x4 gm = *reinterpret_cast<const f32x4*>(a.bnb_gamma + (c0 < a.co ? c0 : 0));
+          const f32x4 bt = *reinterpret_cast<const f32x4*>(a.bnb_beta + (c0 < a.co ? c0 : 0));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float yy = (e & 1) ? bf_hi(yv[e >> 1]) : bf_lo(yv[e >> 1]);
+            const float gr = (e & 1) ? bf_hi(dw[2 * g + (e >> 1)]) : bf_lo(dw[2 * g + (e >> 1)]);
+            const float sc = gm[e] * rsd[e], sh = bt[e] - mu[e] * sc;
+            const float gg = cv ? gr * act_grad(yy * sc + sh, a.bnb_act, a.bnb_slope) : 0.f;
+            sA[4 * g + e] += gg;
+            sB[4 * g + e] = __builtin_fmaf(gg, (yy - mu[e]) * rsd[e], sB[4 * g + e]);
+          }
+        }
+      }
+    }
+    if (!a.out_f32) {
+      // lanes (lp, 0) and (lp, 1) hold channels 8g + {0..3} and 8g + {4..7}: after the swap the low lane owns all 8 channels of
+      // the even group, the high lane those of the odd group -> two 16-byte stores per lane per row block
+#pragma unroll
+      for (int gp = 0; gp < 2; ++gp) {
+        const u32x2 s0 = __builtin_amdgcn_permlane32_swap(dw[4 * gp], dw[4 * gp + 2], false, false);
+        const u32x2 s1 = __builtin_amdgcn_permlane32_swap(dw[4 * gp + 1], dw[4 * gp + 3], false, false);
+        const u32x4 d = {s0[0], s1[0], s0[1], s1[1]};
+        const int c8 = cbase + 8 * (2 * gp + lh);
+        const unsigned off = (pv && c8 < a.co) ? (pixoff * (unsigned)ldc + (unsigned)(c8 - csub)) * 2u : 0x80000000u;
+        __builtin_amdgcn_raw_buffer_store_b128(d, rs_y, (int)off, 0, 0);
+      }
+    }
+  }
+  (void)es;
+
+  if (want_stats || want_bnb) {
+    // per-channel totals: 32 lanes of a half-wave hold the same channels -> butterfly over lane bits 0..4, then the waves
+    // that share a channel block fold through LDS (the halo is free: the K loop ended with a barrier), one f64 atomic per
+    // (channel, statistic) per block into replica blockIdx % R
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) {
+        sA[v] += __shfl_xor(sA[v], o, 64);
+        sB[v] += __shfl_xor(sB[v], o, 64);
+      }
+    }
+    float* red = reinterpret_cast<float*>(smem);   // [2][waves][32]
+    if (lp == 0) {
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int cl = (v & 3) + 8 * (v >> 2) + 4 * lh;
+        red[wave * 32 + cl] = wave_live ? sA[v] : 0.f;
+        red[WM * WN * 32 + wave * 32 + cl] = wave_live ? sB[v] : 0.f;
+      }
+    }
+    __syncthreads();
+    if (tid < 32 * WN) {
+      const int wc = tid >> 5, cl = tid & 31;
+      const int c = (cb * WN + wc) * 32 + cl;
+      if (c < a.co) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int m = 0; m < WM; ++m) {
+          t1 += red[(m * WN + wc) * 32 + cl];
+          t2 += red[WM * WN * 32 + (m * WN + wc) * 32 + cl];
+        }
+        double* rep = a.stats + (size_t)(blockIdx.x % HALO_STATS_REPLICAS) * 2 * a.co;
+        atomicAdd(rep + c, (double)t1);
+        atomicAdd(rep + a.co + c, (double)t2);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ fragment packing
+// Weights in MFMA-fragment order.  For a convolution with N produced and K gathered channels and a KS x KS window:
+//   packed[nb][dx][k16][dy][lane][j]  (nb < ceil(N/32), k16 < ceil(K/16), lane < 64, j < 8; bf16)
+//     = Wsrc[n = 32 nb + (lane & 31)][tap][k = 16 k16 + 8 (lane >> 5) + j]      (zero where n >= N or k >= K)
+// i.e. exactly the 16 bytes lane `lane` feeds v_mfma_f32_32x32x16_bf16 as its A operand.  Wsrc is [N][KS*KS][K] bf16 in both
+// directions: the forward reads the OHWI weights (N = co, K = ci, tap = dy * KS + dx), the data gradient reads the dgrad
+// packing [ci][taps][co] (N = ci, K = co) with the window flipped (tap = KS*KS - 1 - (dy * KS + dx)).
+// table row (int32 x 6): {mode (0 forward / 1 data gradient), src element offset, dst element offset, N, K, KS}
+__global__ void pack_frag_batched_bf16_kernel(const __bf16* __restrict__ w16, const __bf16* __restrict__ wt16,
+                                              __bf16* __restrict__ packed, const int* __restrict__ table) {
+  const int* e = table + 6 * blockIdx.y;
+  const int mode = e[0], N = e[3], K = e[4], KS = e[5];
+  const __bf16* src = (mode ? wt16 : w16) + e[1];
+  __bf16* dst = packed + e[2];
+  const int T = KS * KS, nb = (N + 31) >> 5, nk16 = (K + 15) >> 4;
+  const long long total = (long long)nb * KS * nk16 * KS * 64;     // one 16-byte item per (fragment, lane)
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int lane = (int)(i & 63);
+    long long f = i >> 6;
+    const int dy = (int)(f % KS);
+    f /= KS;
+    const int kk = (int)(f % nk16);
+    f /= nk16;
+    const int dx = (int)(f % KS);
+    const int b = (int)(f / KS);
+    const int n = b * 32 + (lane & 31), k0 = kk * 16 + 8 * (lane >> 5);
+    const int tap = mode ? T - 1 - (dy * KS + dx) : dy * KS + dx;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (n < N && k0 < K) v = *reinterpret_cast<const u32x4*>(src + ((size_t)n * T + tap) * K + k0);
+    *reinterpret_cast<u32x4*>(dst + i * 8) = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- host side
+template <int KS, int CK, int WM, int WN, int RPW, int TW>
+static int launch_halo_t(HaloArgs a, hipStream_t s, double flops) {
+  using C = HaloCfg<KS, CK, WM, WN, RPW, TW>;
+  auto kern = conv_halo_bf16_kernel<KS, CK, WM, WN, RPW, TW>;
+  static bool attr_done = false;
+  if (!attr_done && C::LDS > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv_halo_bf16)");
+    attr_done = true;
+  }
+  a.ntx = cdiv(a.w, TW);
+  a.nty = cdiv(a.h, C::TH);
+  a.ncb = cdiv(a.co, 32 * WN);
+  a.nk16 = (a.ci + 15) / 16;
+  const long long blocks = (long long)a.n * a.nty * a.ntx * a.ncb;
+  if (blocks <= 0) return UDASEG_OK;
+  static int kid = -1;
+  if (kid < 0) {
+    char nm[96];
+    snprintf(nm, sizeof(nm), "conv_halo_bf16_kernel<%d, %d, %d, %d, %d, %d>", KS, CK, WM, WN, RPW, TW);
+    kid = kprof_id(nm);
+  }
+  hipEvent_t ev = kprof_begin(s);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::NT), C::LDS, s, a);
+  kprof_end(kid, ev, s, flops);
+  UDASEG_LAUNCH_CHECK("conv_halo_bf16 launch");
+  return UDASEG_OK;
+}
+
+static int halo_cfg_override() {
+  static int v = -1;   // tuning aid: UDASEG_HALO_CFG = 1..n forces one configuration (0 / unset: heuristic)
+  if (v < 0) {
+    const char* e = getenv("UDASEG_HALO_CFG");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
+
+// Can this convolution take the halo kernel?  gathered / produced: channel counts of the launch (for a data gradient: co / ci).
+bool halo_applicable(const udaseg_conv_desc* d, int gathered, int produced, int up_ca) {
+  static int off = -1;   // UDASEG_NO_HALO=1: keep every layer on the shared implicit-GEMM source (A/B, cross-check)
+  if (off < 0) off = getenv("UDASEG_NO_HALO") != nullptr ? 1 : 0;
+  if (off) return false;
+  if (d->kh != d->kw || (d->kh != 3 && d->kh != 1) || d->stride != 1 || d->pad != d->kh / 2) return false;
+  if (gathered % 8 != 0 || produced % 8 != 0) return false;
+  if (up_ca > 0 && (up_ca % 16 != 0 || (gathered - up_ca) % 16 != 0 || d->hi % 2 != 0 || d->wi % 2 != 0)) return false;
+  const long long px = (long long)d->n * d->hi * d->wi;
+  if (px * gathered * 2 >= (1LL << 31) || px * produced * 4 >= (1LL << 31)) return false;     // buffer descriptors: 2 GiB
+  return true;
+}
+
+int launch_halo(const udaseg_conv_desc* d, HaloArgs a, hipStream_t s) {
+  const double flops = 2.0 * (double)a.n * a.h * a.w * (double)a.co * (double)a.ci * d->kh * d->kw;
+  // chunk: the largest of 64 / 32 / 16 that divides the gathered channels and both sources of a fused input
+  int ck = 32;
+  if (a.ci % 32 != 0 || (a.up_ca > 0 && (a.up_ca % 32 != 0 || (a.ci - a.up_ca) % 32 != 0))) ck = 16;
+  const int ov = halo_cfg_override();
+  if (d->kh == 3) {
+    if (ck == 16) {
+      if (a.co <= 32) return launch_halo_t<3, 16, 4, 1, 2, 32>(a, s, flops);
+      return launch_halo_t<3, 16, 2, 2, 4, 32>(a, s, flops);
+    }
+    if (a.co <= 32 || ov == 3) return launch_halo_t<3, 32, 4, 1, 2, 32>(a, s, flops);
+    if (a.co >= 128 && ov != 1) {
+      if (ov == 4) return launch_halo_t<3, 32, 2, 4, 4, 32>(a, s, flops);
+      return launch_halo_t<3, 32, 1, 4, 8, 32>(a, s, flops);
+    }
+    return launch_halo_t<3, 32, 2, 2, 4, 32>(a, s, flops);
+  }
+  // 1x1
+  if (ck == 16) return launch_halo_t<1, 16, 2, 2, 4, 32>(a, s, flops);
+  if (a.co >= 128 && ov != 1) return launch_halo_t<1, 32, 1, 4, 8, 32>(a, s, flops);
+  return launch_halo_t<1, 32, 2, 2, 4, 32>(a, s, flops);
+}
+
+}  // namespace udaseg
+
+using namespace udaseg;
+
+extern "C" int64_t udaseg_frag_elems(int n_out, int k_in, int ks) {
+  if (n_out <= 0 || k_in <= 0 || ks <= 0) return 0;
+  return (int64_t)((n_out + 31) / 32) * ks * ((k_in + 15) / 16) * ks * 512;
+}
+
+extern "C" int udaseg_pack_frag_batched_bf16(const void* w16, const void* wt16, void* packed, const int* table, int entries,
+                                             void* stream) {
+  UDASEG_CHECK_ARG(packed && table && entries > 0 && (w16 || wt16), "pack_frag_batched_bf16: NULL pointer / no entries");
+  hipLaunchKernelGGL(pack_frag_batched_bf16_kernel, dim3(64, (unsigned)entries), dim3(256), 0, as_stream(stream),
+                     static_cast<const __bf16*>(w16), static_cast<const __bf16*>(wt16), static_cast<__bf16*>(packed), table);
+  UDASEG_LAUNCH_CHECK("pack_frag_batched_bf16 launch");
+  return UDASEG_OK;
+}
+
+extern "C" int udaseg_conv_frag_ok(const udaseg_conv_desc* d, int dgrad, int up_ca) {
+  if (!d) return 0;
+  return halo_applicable(d, dgrad ? d->co : d->ci, dgrad ? d->ci : d->co, up_ca) ? 1 : 0;
+}
+
+static int frag_common(const udaseg_conv_desc* d, HaloArgs& a, const char* who) {
+  UDASEG_CHECK_ARG(d != nullptr, "%s: conv desc is NULL", who);
+  UDASEG_CHECK_ARG(d->n > 0 && d->hi > 0 && d->wi > 0 && d->ho == d->hi && d->wo == d->wi && d->ci > 0 && d->co > 0,
+                   "%s: stride-1 'same' convolutions only (hi=%d wi=%d ho=%d wo=%d)", who, d->hi, d->wi, d->ho, d->wo);
+  a.n = d->n; a.h = d->hi; a.w = d->wi;
+  return UDASEG_OK;
+}
+
+extern "C" int udaseg_conv2d_fwd_frag_bf16(const udaseg_conv_desc* d, const void* x, const void* skip, int up_ca, const void* wfrag,
+                                           const float* bias, const float* in_scale, const float* in_shift, int in_act,
+                                           float in_slope, void* y, int out_f32, int act, float slope, double* stats, void* stream) {
+  HaloArgs a = {};
+  int rc = frag_common(d, a, "conv2d_fwd_frag_bf16");
+  if (rc) return rc;
+  UDASEG_CHECK_ARG(x && wfrag && y, "conv2d_fwd_frag_bf16: NULL pointer");
+  UDASEG_CHECK_ARG(up_ca >= 0 && up_ca <= d->ci && (up_ca == 0 ? skip == nullptr : (up_ca == d->ci) == (skip == nullptr)),
+                   "conv2d_fwd_frag_bf16: up_ca=%d of ci=%d channels, skip %s", up_ca, d->ci, skip ? "given" : "NULL");
+  UDASEG_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "conv2d_fwd_frag_bf16: in_scale and in_shift come together");
+  UDASEG_CHECK_ARG(!(in_scale && (up_ca > 0 || d->ci % 16 != 0)),
+                   "conv2d_fwd_frag_bf16: the input transform needs a plain input with a multiple of 16 channels");
+  if (!halo_applicable(d, d->ci, d->co, up_ca)) {
+    set_error("conv2d_fwd_frag_bf16: geometry not supported (ask udaseg_conv_frag_ok first)");
+    return UDASEG_E_UNSUPPORTED;
+  }
+  const long long px = (long long)d->n * d->hi * d->wi;
+  a.x = x; a.x2 = skip; a.wf = wfrag; a.bias = bias; a.y = y;
+  a.ci = d->ci; a.co = d->co; a.up_ca = up_ca;
+  a.out_f32 = out_f32; a.act = act; a.slope = slope; a.stats = stats;
+  a.in_scale = in_scale; a.in_shift = in_shift; a.in_act = in_act; a.in_slope = in_slope;
+  a.x_bytes = (unsigned)(up_ca > 0 ? (long long)d->n * (d->hi / 2) * (d->wi / 2) * up_ca * 2 : px * d->ci * 2);
+  a.x2_bytes = (unsigned)(up_ca > 0 ? px * (d->ci - up_ca) * 2 : 0);
+  a.w_bytes = (unsigned)(udaseg_frag_elems(d->co, d->ci, d->kh) * 2);
+  a.y_bytes = (unsigned)(px * d->co * (out_f32 ? 4 : 2));
+  hipStream_t st = as_stream(stream);
+  prof_begin(0, st);
+  rc = launch_halo(d, a, st);
+  prof_end(0, st, udaseg_conv_flops(d), 0, d);
+  return rc;
+}
+
+extern "C" int udaseg_conv2d_dgrad_frag_bf16(const udaseg_conv_desc* d, const void* dy, const void* wfrag_t, void* dx, void* dx2,
+                                             int split, const void* prev_y, const float* save_mean, const float* save_rstd,
+                                             const float* gamma, const float* beta, int bn_act, float bn_slope, double* bsums,
+                                             void* stream) {
+  HaloArgs a = {};
+  int rc = frag_common(d, a, "conv2d_dgrad_frag_bf16");
+  if (rc) return rc;
+  UDASEG_CHECK_ARG(dy && wfrag_t && dx, "conv2d_dgrad_frag_bf16: NULL pointer");
+  UDASEG_CHECK_ARG(split == 0 ? dx2 == nullptr : (dx2 != nullptr && split > 0 && split < d->ci && split % 32 == 0),
+                   "conv2d_dgrad_frag_bf16: split=%d needs dx2 and a multiple of 32 inside (0, ci=%d)", split, d->ci);
+  UDASEG_CHECK_ARG(prev_y == nullptr || (save_mean && save_rstd && gamma && beta && bsums && split == 0),
+                   "conv2d_dgrad_frag_bf16: the BatchNorm-backward reductions need mean / rstd / gamma / beta / bsums and no split");
+  if (!halo_applicable(d, d->co, d->ci, 0)) {
+    set_error("conv2d_dgrad_frag_bf16: geometry not supported (ask udaseg_conv_frag_ok first)");
+    return UDASEG_E_UNSUPPORTED;
+  }
+  const long long px = (long long)d->n * d->hi * d->wi;
+  a.x = dy; a.wf = wfrag_t; a.y = dx; a.y2 = dx2; a.split_n = split;
+  a.ci = d->co; a.co = d->ci;        // the launch gathers dy (co channels) and produces dx (ci channels)
+  a.act = UDASEG_ACT_NONE;
+  a.x_bytes = (unsigned)(px * d->co * 2);
+  a.w_bytes = (unsigned)(udaseg_frag_elems(d->ci, d->co, d->kh) * 2);
+  a.y_bytes = (unsigned)(px * (split > 0 ? split : d->ci) * 2);
+  a.y2_bytes = (unsigned)(split > 0 ? px * (d->ci - split) * 2 : 0);
+  if (prev_y) {
+    a.bnb_y = prev_y; a.bnb_mean = save_mean; a.bnb_rstd = save_rstd; a.bnb_gamma = gamma; a.bnb_beta = beta;
+    a.bnb_act = bn_act; a.bnb_slope = bn_slope; a.stats = bsums;
+    a.bnb_bytes = (unsigned)(px * d->ci * 2);
+  }
+  hipStream_t st = as_stream(stream);
+  prof_begin(0, st);
+  rc = launch_halo(d, a, st);
+  prof_end(0, st, udaseg_conv_flops(d), 1, d);
+  return rc;
+}

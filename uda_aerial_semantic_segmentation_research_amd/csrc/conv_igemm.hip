@@ -760,7 +760,17 @@ static int launch_cfg_t(const IgemmArgs& a, hipStream_t s) {
   b.timeline = (g_timeline && b.tile_begin[a.nclass] <= g_timeline_blocks) ? g_timeline : nullptr;
   dim3 grid((unsigned)b.tile_begin[a.nclass]), block(256);
   constexpr int tile_id = (BM == 128 && BN == 128) ? 0 : (BM == 128 && BN == 64) ? 1 : (BM == 64) ? 2 : 3;
-  constexpr int kid = BF ? 12 : (UP ? 20 + tile_id : (UNI ? 14 + tile_id : tile_id));
+  int kid = UP ? 20 + tile_id : (UNI ? 14 + tile_id : tile_id);
+  if constexpr (BF) {      // bf16 instantiations report under their own rocprofv3 symbol (round 2 lumped them into one id)
+    static int bf_kid = -1;
+    if (bf_kid < 0) {
+      char nm[96];
+      snprintf(nm, sizeof(nm), "conv_igemm_kernel<%d, %d, %d, %d, true, %s, %s>", BM, BN, WAVES_M, WAVES_N, UNI ? "true" : "false",
+               UP ? "true" : "false");
+      bf_kid = kprof_id(nm);
+    }
+    kid = bf_kid;
+  }
   hipEvent_t ev = kprof_begin(s);
   hipLaunchKernelGGL(kern, grid, block, lds, s, b);
   kprof_end(kid, ev, s, flops);

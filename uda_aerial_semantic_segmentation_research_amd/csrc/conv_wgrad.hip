@@ -516,14 +516,23 @@ static int launch_wgrad(WgradArgs a, int accumulate, hipStream_t s, bool bf16 = 
     constexpr int b_rows16 = 256 / (BNW / 8);
     const long long xb16 = (long long)a.M / (a.ho * a.wo) * (a.up ? (a.hi >> 1) * (a.wi >> 1) : a.hi * a.wi) * a.ci * 2,
                     dyb16 = (long long)a.M * a.co * 2;
-    a.row_uniform = !(g_opt_generic_gather >= 0 ? g_opt_generic_gather : getenv("UDASEG_WGRAD_GENERIC") != nullptr) && a.wo % b_rows16 == 0 && xb16 <= (1LL << 30) && dyb16 <= (1LL << 30);
+    static int generic16 = -1;
+    if (generic16 < 0) generic16 = getenv("UDASEG_WGRAD_GENERIC") != nullptr ? 1 : 0;
+    a.row_uniform = !(g_opt_generic_gather >= 0 ? g_opt_generic_gather : generic16) && a.wo % b_rows16 == 0 && xb16 <= (1LL << 30) && dyb16 <= (1LL << 30);
     a.x_bytes = (unsigned)xb16;
     a.dy_bytes = (unsigned)dyb16;
     if (a.row_uniform)
       hipLaunchKernelGGL((conv_wgrad_bf16_kernel<BMW, BNW, WAVES_M, WAVES_N, true>), grid, block, 0, s, a);
     else
       hipLaunchKernelGGL((conv_wgrad_bf16_kernel<BMW, BNW, WAVES_M, WAVES_N, false>), grid, block, 0, s, a);
-    kprof_end(13, ev, s, 2.0 * (double)a.M * a.co * a.J);
+    static int kid16[2] = {-1, -1};     // one id per rocprofv3 symbol (round 2 lumped the bf16 instantiations into one)
+    int& kid = kid16[a.row_uniform ? 1 : 0];
+    if (kid < 0) {
+      char nm[96];
+      snprintf(nm, sizeof(nm), "conv_wgrad_bf16_kernel<%d, %d, %d, %d, %s>", BMW, BNW, WAVES_M, WAVES_N, a.row_uniform ? "true" : "false");
+      kid = kprof_id(nm);
+    }
+    kprof_end(kid, ev, s, 2.0 * (double)a.M * a.co * a.J);
   } else {
     constexpr int b_rows = 256 / (BNW / 4);
     static int generic = -1;   // tuning aid: UDASEG_WGRAD_GENERIC=1 keeps the generic gather loop

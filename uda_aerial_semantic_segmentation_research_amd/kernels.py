@@ -151,6 +151,40 @@ def upcat_fusable(ca, cb, co, dtype):
     return ca % 32 == 0 and cb % 32 == 0 and (cb == 0 or ca % 64 == 0)
 
 
+def frag_elems(n_out, k_in, ks):
+    """bf16 elements of the MFMA-fragment packing of a convolution with n_out produced / k_in gathered channels, ks x ks window."""
+    return int(_lib.load().udaseg_frag_elems(n_out, k_in, ks))
+
+
+def pack_frag_batched(w16, wt16, packed, table, st=None):
+    """Fragment-pack every listed convolution in one launch (table rows: mode, src offset, dst offset, N, K, ks; int32 x 6)."""
+    check(_lib.load().udaseg_pack_frag_batched_bf16(_ptr(w16), _ptr(wt16), packed.data_ptr(), table.data_ptr(), table.shape[0],
+                                                     st if st is not None else stream()), "pack_frag_batched_bf16")
+
+
+def conv_frag_ok(d, dgrad=False, up_ca=0):
+    return bool(_lib.load().udaseg_conv_frag_ok(_byref(d), int(dgrad), up_ca))
+
+
+def conv2d_fwd_frag(d, x, skip, wfrag, bias, y, act=ACT_NONE, slope=0.0, stats=None, in_scale=None, in_shift=None, in_act=ACT_NONE,
+                    in_slope=0.0, up=False, st=None):
+    """bf16-first forward convolution (csrc/conv_halo_bf16.hip).  up: x is the half-resolution tensor of a fused decoder input."""
+    check(_lib.load().udaseg_conv2d_fwd_frag_bf16(_byref(d), x.data_ptr(), _ptr(skip), x.shape[-1] if up else 0, wfrag.data_ptr(),
+                                                   _ptr(bias), _ptr(in_scale), _ptr(in_shift), in_act, in_slope, y.data_ptr(),
+                                                   int(y.dtype == torch.float32), act, slope, _ptr(stats),
+                                                   st if st is not None else stream()), "conv2d_fwd_frag_bf16")
+
+
+def conv2d_dgrad_frag(d, dy, wfrag_t, dx, dx2=None, bn=None, st=None):
+    """bf16-first data gradient.  dx2: second destination of a split gradient (channels [dx.shape[-1], ci)).
+    bn = (prev_y, save_mean, save_rstd, gamma, beta, act, slope, bsums): BatchNorm-backward reductions of the layer behind."""
+    py, mu, rs, ga, be, act, slope, bs = bn if bn is not None else (None, None, None, None, None, ACT_NONE, 0.0, None)
+    check(_lib.load().udaseg_conv2d_dgrad_frag_bf16(_byref(d), dy.data_ptr(), wfrag_t.data_ptr(), dx.data_ptr(), _ptr(dx2),
+                                                     dx.shape[-1] if dx2 is not None else 0, _ptr(py), _ptr(mu), _ptr(rs), _ptr(ga),
+                                                     _ptr(be), act, slope, _ptr(bs), st if st is not None else stream()),
+          "conv2d_dgrad_frag_bf16")
+
+
 def pack_dgrad_weights(d, w, w_t, st=None):
     check(_lib.load().udaseg_pack_dgrad_weights(_byref(d), w.data_ptr(), w_t.data_ptr(),
                                                  st if st is not None else stream()), "pack_dgrad_weights")
