@@ -347,6 +347,9 @@ int udaseg_pack_frag_batched_bf16(const void* w16, const void* wt16, void* packe
 /* 1 when the convolution (dgrad = 0: forward, gathers ci and produces co; dgrad = 1: its data gradient; up_ca > 0: forward on the
  * fused decoder input cat([nearest_x2(a), skip]) with up_ca channels from a) can take these kernels */
 int udaseg_conv_frag_ok(const udaseg_conv_desc* d, int dgrad, int up_ca);
+/* 1 when, in addition, they are expected to be FASTER than the shared implicit-GEMM source for this shape (measured heuristic:
+ * csrc/conv_halo_bf16.hip halo_choice) -- what the Python side asks before it routes a layer */
+int udaseg_conv_frag_preferred(const udaseg_conv_desc* d, int dgrad, int up_ca);
 /* y = act(conv(X, w) + bias) (+ BatchNorm statistics of conv(X, w) + bias into stats, as udaseg_conv2d_fwd_bnstats).
  * X = x [n][h][w][ci], or with up_ca > 0 the virtual cat([nearest_x2(x [n][h/2][w/2][up_ca]), skip [n][h][w][ci - up_ca]]), or with
  * in_scale / in_shift (fp32 [ci]) the producer's BatchNorm + activation applied on the fly: X = in_act(x * in_scale + in_shift)
@@ -356,10 +359,10 @@ int udaseg_conv2d_fwd_frag_bf16(const udaseg_conv_desc* d, const void* x, const 
                                 void* y, int out_f32, int act, float slope, double* stats, void* stream);
 /* dx = conv_transpose(dy, w) from the data-gradient fragment packing.  split > 0: channels [0, split) of the gradient go to dx
  * [n][h][w][split], the rest to dx2 (the two sources of a fused decoder input).  prev_y != NULL: also the BatchNorm-backward
- * reductions of the layer behind (as udaseg_conv2d_dgrad_bnreduce_bf16). */
+ * reductions of the layer behind (as udaseg_conv2d_dgrad_bnreduce_bf16).  accumulate: dx += (one rounding of the fp32 sum). */
 int udaseg_conv2d_dgrad_frag_bf16(const udaseg_conv_desc* d, const void* dy, const void* wfrag_t, void* dx, void* dx2, int split,
                                   const void* prev_y, const float* save_mean, const float* save_rstd, const float* gamma,
-                                  const float* beta, int bn_act, float bn_slope, double* bsums, void* stream);
+                                  const float* beta, int bn_act, float bn_slope, double* bsums, int accumulate, void* stream);
 
 /* ---- diagnosis: while a device buffer of 6 * blocks u64 is registered, every implicit-GEMM launch of at most `blocks` blocks
  *      writes per block {entry, first tile load, end of K loop, exit} (100 MHz wall-clock ticks), HW_ID and XCC_ID into it

@@ -105,6 +105,11 @@ def test_conv_frag_fwd_dgrad(K, case):
     dx = torch.full((n, h, w, ci), float("nan"), device="cuda", dtype=bf)
     K.conv2d_dgrad_frag(d, nhwc(dy), wfd, dx)
     close(nchw32(dx), xr.grad, "frag dgrad")
+    # accumulation onto an existing gradient (the identity branch of a residual block): ONE rounding of the fp32 sum
+    base = rb(torch.randn(n, ci, h, w, generator=g))
+    dx2 = nhwc(base)
+    K.conv2d_dgrad_frag(d, nhwc(dy), wfd, dx2, accumulate=True)
+    close(nchw32(dx2), xr.grad + base, "frag dgrad + acc")
 
 
 @pytest.mark.parametrize("n,h,w,c1,c2,act,slope", [(8, 64, 64, 64, 64, 1, 0.0), (2, 32, 32, 256, 128, 1, 0.0),

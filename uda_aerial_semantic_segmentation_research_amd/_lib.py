@@ -111,8 +111,9 @@ SIGNATURES = {
     "udaseg_frag_elems": (_L, [_I, _I, _I]),
     "udaseg_pack_frag_batched_bf16": (_I, [_P, _P, _P, _P, _I, _P]),
     "udaseg_conv_frag_ok": (_I, [_D, _I, _I]),
+    "udaseg_conv_frag_preferred": (_I, [_D, _I, _I]),
     "udaseg_conv2d_fwd_frag_bf16": (_I, [_D, _P, _P, _I, _P, _P, _P, _P, _I, _F, _P, _I, _I, _F, _P, _P]),
-    "udaseg_conv2d_dgrad_frag_bf16": (_I, [_D, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _F, _P, _P]),
+    "udaseg_conv2d_dgrad_frag_bf16": (_I, [_D, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _F, _P, _I, _P]),
     "udaseg_set_workspace": (_I, [_P, C.c_size_t]),
     "udaseg_workspace_bytes": (C.c_size_t, [_P]),
     "udaseg_debug_set_timeline": (_I, [_P, _I]),

@@ -39,6 +39,7 @@ struct HaloArgs {
   int n, h, w;          // output = input extent (stride 1, "same" padding)
   int ci, co;           // gathered / produced channel counts
   int up_ca, split_n;
+  int accumulate;       // bf16 output only: y += result (one rounding of the fp32 sum), the identity branch's gradient in dx
   int out_f32, act;
   float slope;
   double* stats;        // [R][2][co] f64: BatchNorm statistics of the output, or the bnb_* sums
@@ -74,10 +75,14 @@ struct HaloCfg {
   static constexpr int NPIECE = HR * HWD * OCT;
   static constexpr int NI = (NPIECE + NT - 1) / NT;
   static constexpr int LDS_HALO = HR * HWD * STRIDE;
-  static constexpr int LDS_RED = 2 * WM * WN * 32 * 4;   // [2][waves][32] floats
-  static constexpr int LDS = LDS_HALO > LDS_RED ? LDS_HALO : LDS_RED;
   static constexpr int S = RB * (RPW - 1) + KS;   // distinct start rows of pixel fragments per (dx, k16)
   static constexpr int GPC = KS * (CK / 16);       // (dx, k16) groups per chunk
+  static constexpr int FPC = GPC * KS;             // weight fragments per chunk per 32-channel block
+  static constexpr int NW = WM * WN;               // waves
+  static constexpr int NWI = (WN * FPC + NW - 1) / NW;   // weight fragments a wave stages per chunk
+  static constexpr int LDS_W = WN * FPC * 1024;
+  static constexpr int LDS = LDS_HALO + LDS_W;     // (the statistics reduction reuses the halo region: 2 * NW * 32 floats)
+  static_assert(LDS_HALO >= 2 * NW * 32 * 4 && LDS_HALO % 16 == 0, "reduction scratch fits the halo region");
 };
 
 __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
@@ -139,13 +144,28 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_halo_bf16_kernel(const H
                                                                    (int)(UPC && a.x2 ? a.x2_bytes : 0u), 0x00020000);
   __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wf), 0, (int)a.w_bytes, 0x00020000);
 
-  // ---- this wave's channel block and its fragment stream
+  // ---- this wave's channel block
   const int nblocks32 = (a.co + 31) >> 5;
   int nb = cb * WN + wn;
-  const bool wave_live = nb < nblocks32;          // a dead wave (co not a multiple of 32 * WN) computes on block 0 and stores nothing
+  const bool wave_live = nb < nblocks32;          // a dead wave (co not a multiple of 32 * WN) computes on zeros and stores nothing
   if (!wave_live) nb = 0;
-  const int frag_per_nb = KS * a.nk16 * KS;       // fragments of one 32-channel block: [dx][k16][dy]
-  const unsigned wlane = (unsigned)(nb * frag_per_nb) * 1024u + (unsigned)lane * 16u;
+  // ---- weight staging: the block's WN x FPC fragments of a chunk (1 KB each, fragment order [dx][k16][dy]) are loaded by the
+  // waves round-robin, lane-linear (one coalesced 1 KB load per fragment), one chunk AHEAD of their use -- a fragment fetched
+  // right before its MFMAs costs an L2 round trip per (dx, k16) group: 35 us instead of ~8 for a 64-channel layer (round 3)
+  const int frag_per_nb = KS * a.nk16 * KS;       // fragments of one 32-channel block
+  unsigned wvoff[C::NWI];
+#pragma unroll
+  for (int i = 0; i < C::NWI; ++i) {
+    const int q = wave + C::NW * i;               // fragment slot of the block: (channel block q / FPC, fragment q % FPC)
+    const int wq = q / C::FPC, fi = q - wq * C::FPC;
+    const int g = fi / KS, dy = fi - g * KS;
+    const int dx = g / (CK / 16), k = g - dx * (CK / 16);
+    int nbq = cb * WN + wq;
+    const bool live = q < WN * C::FPC && nbq < nblocks32;
+    wvoff[i] = live ? (unsigned)((nbq * frag_per_nb + (dx * a.nk16 + k) * KS + dy) * 1024 + lane * 16) : 0x80000000u;
+  }
+  char* wlds = smem + C::LDS_HALO;
+  const int wrd = (wn * C::FPC) * 1024 + lane * 16;     // this wave's fragments in the weight region
 
   // pixel fragment base address in the halo: lane pixel (ly, lx), K half lh
   const int ly = lp / TW, lx = lp % TW;
@@ -207,39 +227,44 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_halo_bf16_kernel(const H
     }
   };
 
-  // weight fragments of (chunk c, group g = dx * (CK/16) + k): KS fragments (dy), contiguous 1 KB each
-  u32x4 bcur[KS], bnxt[KS];
-  auto load_b = [&](int c, int g, u32x4* bf) {
-    const int dx = g / (CK / 16), k = g % (CK / 16);
-    const int f0 = (dx * a.nk16 + c * (CK / 16) + k) * KS;
+  u32x4 wstage[C::NWI];
+  auto load_w = [&](int c) {
+    const int soff = c * (CK / 16) * KS * 1024;   // k16 advances by CK/16 per chunk
 #pragma unroll
-    for (int dy = 0; dy < KS; ++dy) bf[dy] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)wlane, (f0 + dy) * 1024, 0);
+    for (int i = 0; i < C::NWI; ++i) wstage[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)wvoff[i], soff, 0);
+  };
+  auto store_w = [&]() {
+#pragma unroll
+    for (int i = 0; i < C::NWI; ++i) {
+      const int q = wave + C::NW * i;
+      if (i < C::NWI - 1 || q < WN * C::FPC) *reinterpret_cast<u32x4*>(wlds + q * 1024 + lane * 16) = wstage[i];
+    }
   };
 
+  load_w(0);
   load_chunk(0);
-  load_b(0, 0, bnxt);
   for (int c = 0; c < nchunk; ++c) {
     store_chunk(c);
+    store_w();
     __syncthreads();
-    if (c + 1 < nchunk) load_chunk(c + 1);
+    if (c + 1 < nchunk) {
+      load_w(c + 1);
+      load_chunk(c + 1);
+    }
 #pragma unroll
     for (int g = 0; g < C::GPC; ++g) {
-#pragma unroll
-      for (int dy = 0; dy < KS; ++dy) bcur[dy] = bnxt[dy];
-      // prefetch the next group's fragments (next chunk's first group at the end of a chunk; clamped on the very last group)
-      if (g + 1 < C::GPC) load_b(c, g + 1, bnxt);
-      else load_b(c + 1 < nchunk ? c + 1 : c, 0, bnxt);
       const int dx = g / (CK / 16), k = g % (CK / 16);
+      u32x4 bf[KS];
+#pragma unroll
+      for (int dy = 0; dy < KS; ++dy) bf[dy] = *reinterpret_cast<const u32x4*>(wlds + wrd + (g * KS + dy) * 1024);
 #pragma unroll
       for (int s = 0; s < C::S; ++s) {
         const u32x4 pf = *reinterpret_cast<const u32x4*>(smem + pbase + (s * C::HWD + dx) * C::STRIDE + k * 32);
 #pragma unroll
         for (int dy = 0; dy < KS; ++dy) {
           if ((s - dy) >= 0 && (s - dy) % C::RB == 0 && (s - dy) / C::RB < RPW) {
-            constexpr int dummy = 0;
-            (void)dummy;
             const int r = (s - dy) / C::RB;
-            acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bcur[dy]), __builtin_bit_cast(bf16x8, pf),
+            acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bf[dy]), __builtin_bit_cast(bf16x8, pf),
                                                              acc[r], 0, 0, 0);
           }
         }
@@ -299,6 +324,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_halo_bf16_kernel(const H
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) val[e] = act_apply(val[e], a.act, a.slope);
+      if (a.accumulate) {     // host-checked: bf16 output, no split
+        const unsigned ooff = cv ? (pixoff * (unsigned)ldc + (unsigned)(c0 - csub)) * 2u : 0x80000000u;
+        const u32x2 old = __builtin_amdgcn_raw_buffer_load_b64(rs_y, (int)ooff, 0, 0);
+        val[0] += bf_lo(old[0]); val[1] += bf_hi(old[0]); val[2] += bf_lo(old[1]); val[3] += bf_hi(old[1]);
+      }
       if (a.out_f32) {
         const unsigned off = cv ? (pixoff * (unsigned)ldc + (unsigned)(c0 - csub)) * 4u : 0x80000000u;
         u32x4 d;
@@ -363,7 +393,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_halo_bf16_kernel(const H
       for (int v = 0; v < 16; ++v) {
         const int cl = (v & 3) + 8 * (v >> 2) + 4 * lh;
         red[wave * 32 + cl] = wave_live ? sA[v] : 0.f;
-        red[WM * WN * 32 + wave * 32 + cl] = wave_live ? sB[v] : 0.f;
+        red[C::NW * 32 + wave * 32 + cl] = wave_live ? sB[v] : 0.f;
       }
     }
     __syncthreads();
@@ -375,7 +405,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_halo_bf16_kernel(const H
 #pragma unroll
         for (int m = 0; m < WM; ++m) {
           t1 += red[(m * WN + wc) * 32 + cl];
-          t2 += red[WM * WN * 32 + (m * WN + wc) * 32 + cl];
+          t2 += red[C::NW * 32 + (m * WN + wc) * 32 + cl];
         }
         double* rep = a.stats + (size_t)(blockIdx.x % HALO_STATS_REPLICAS) * 2 * a.co;
         atomicAdd(rep + c, (double)t1);
@@ -470,27 +500,56 @@ bool halo_applicable(const udaseg_conv_desc* d, int gathered, int produced, int 
   return true;
 }
 
-int launch_halo(const udaseg_conv_desc* d, HaloArgs a, hipStream_t s) {
+// Which tile configuration, or none: the launcher's choice and the "is this kernel the faster one" heuristic are one decision.
+//   0: leave the layer to the shared implicit-GEMM source      1: 32 output channels per block (<= 32 produced channels)
+//   2: 64 output channels per block (4 waves)                  3: 128 output channels per block (8 waves)
+// Measured on MI355X (bench.py --layer-table, r18 8x512^2 and r50 8x768^2 steps, this kernel against conv_igemm_kernel<64, 64,
+// ..., bf16>; profiles/r03_halo_layer_table.txt):
+//   * 3x3, <= 64 produced channels at >= 128^2: always faster (16 -> 24 at 512^2 195 -> 75 us, 128 -> 32 at 256^2 117 -> 72,
+//     192 -> 64 at 128^2 66 -> 49, 64 -> 64 at 128^2 40 -> 34);
+//   * 3x3, >= 128 produced channels: faster while the launch still has a block per CU (384 -> 64 at 192^2 217 -> 147 us, the
+//     3072-channel decoder input at 48^2 437 -> 367, its data gradient 553 -> 343), slower on the deep low-resolution layers
+//     (512 -> 512 at 16^2: 32 blocks of 256 pixels x 128 channels against 256 tiles of the 64 x 64 kernel: 48 -> 78 us);
+//   * 1x1 (r50): HBM-bound either way; faster only where the gradient PRODUCES more channels than it gathers (256 <- 64 at
+//     192^2: 246 -> 126 us; the old kernel's one-K-tile launches), slower or equal in the forward direction.
+static int halo_choice(int ks, int h, int w, int n, int gathered, int produced, bool dgrad) {
+  const int ov = halo_cfg_override();
+  if (ov > 0) return ov > 3 ? 3 : ov;
+  const long long tiles = (long long)n * cdiv(h, 8) * cdiv(w, 32);
+  if (ks == 1) {
+    if (!dgrad || produced <= gathered) return 0;
+    return produced >= 128 ? 3 : 2;
+  }
+  if (produced <= 32) return 1;
+  if (produced <= 64) return 2;
+  if (tiles * cdiv(produced, 128) >= 192) return 3;
+  if (tiles * cdiv(produced, 64) >= 256) return 2;
+  return 0;
+}
+
+int launch_halo(const udaseg_conv_desc* d, HaloArgs a, hipStream_t s, bool dgrad) {
   const double flops = 2.0 * (double)a.n * a.h * a.w * (double)a.co * (double)a.ci * d->kh * d->kw;
-  // chunk: the largest of 64 / 32 / 16 that divides the gathered channels and both sources of a fused input
+  // chunk: 32 channels (64 for the 1x1 kernels) when that divides the gathered channels and both sources of a fused input
   int ck = 32;
   if (a.ci % 32 != 0 || (a.up_ca > 0 && (a.up_ca % 32 != 0 || (a.ci - a.up_ca) % 32 != 0))) ck = 16;
-  const int ov = halo_cfg_override();
+  int choice = halo_choice(d->kh, a.h, a.w, a.n, a.ci, a.co, dgrad);
+  if (choice == 0) choice = a.co <= 32 ? 1 : (a.co <= 64 ? 2 : 3);     // called although not preferred (tests, UDASEG_FRAG=2)
   if (d->kh == 3) {
     if (ck == 16) {
-      if (a.co <= 32) return launch_halo_t<3, 16, 4, 1, 2, 32>(a, s, flops);
+      if (choice == 1) return launch_halo_t<3, 16, 4, 1, 2, 32>(a, s, flops);
       return launch_halo_t<3, 16, 2, 2, 4, 32>(a, s, flops);
     }
-    if (a.co <= 32 || ov == 3) return launch_halo_t<3, 32, 4, 1, 2, 32>(a, s, flops);
-    if (a.co >= 128 && ov != 1) {
-      if (ov == 4) return launch_halo_t<3, 32, 2, 4, 4, 32>(a, s, flops);
-      return launch_halo_t<3, 32, 1, 4, 8, 32>(a, s, flops);
-    }
+    if (choice == 1) return launch_halo_t<3, 32, 4, 1, 2, 32>(a, s, flops);
+    if (choice == 3) return launch_halo_t<3, 32, 2, 4, 4, 32>(a, s, flops);
     return launch_halo_t<3, 32, 2, 2, 4, 32>(a, s, flops);
   }
-  // 1x1
+  // 1x1: two MFMAs per 16 channels -- long chunks, or the loop is all barriers
+  if (ck == 32 && a.ci % 64 == 0) {
+    if (choice == 3) return launch_halo_t<1, 64, 2, 4, 4, 32>(a, s, flops);
+    return launch_halo_t<1, 64, 2, 2, 4, 32>(a, s, flops);
+  }
   if (ck == 16) return launch_halo_t<1, 16, 2, 2, 4, 32>(a, s, flops);
-  if (a.co >= 128 && ov != 1) return launch_halo_t<1, 32, 1, 4, 8, 32>(a, s, flops);
+  if (choice == 3) return launch_halo_t<1, 32, 2, 4, 4, 32>(a, s, flops);
   return launch_halo_t<1, 32, 2, 2, 4, 32>(a, s, flops);
 }
 
@@ -515,6 +574,11 @@ extern "C" int udaseg_pack_frag_batched_bf16(const void* w16, const void* wt16, 
 extern "C" int udaseg_conv_frag_ok(const udaseg_conv_desc* d, int dgrad, int up_ca) {
   if (!d) return 0;
   return halo_applicable(d, dgrad ? d->co : d->ci, dgrad ? d->ci : d->co, up_ca) ? 1 : 0;
+}
+
+extern "C" int udaseg_conv_frag_preferred(const udaseg_conv_desc* d, int dgrad, int up_ca) {
+  if (!udaseg_conv_frag_ok(d, dgrad, up_ca)) return 0;
+  return halo_choice(d->kh, d->hi, d->wi, d->n, dgrad ? d->co : d->ci, dgrad ? d->ci : d->co, dgrad != 0) != 0 ? 1 : 0;
 }
 
 static int frag_common(const udaseg_conv_desc* d, HaloArgs& a, const char* who) {
@@ -552,7 +616,7 @@ extern "C" int udaseg_conv2d_fwd_frag_bf16(const udaseg_conv_desc* d, const void
   a.y_bytes = (unsigned)(px * d->co * (out_f32 ? 4 : 2));
   hipStream_t st = as_stream(stream);
   prof_begin(0, st);
-  rc = launch_halo(d, a, st);
+  rc = launch_halo(d, a, st, false);
   prof_end(0, st, udaseg_conv_flops(d), 0, d);
   return rc;
 }
@@ -560,15 +624,17 @@ extern "C" int udaseg_conv2d_fwd_frag_bf16(const udaseg_conv_desc* d, const void
 extern "C" int udaseg_conv2d_dgrad_frag_bf16(const udaseg_conv_desc* d, const void* dy, const void* wfrag_t, void* dx, void* dx2,
                                              int split, const void* prev_y, const float* save_mean, const float* save_rstd,
                                              const float* gamma, const float* beta, int bn_act, float bn_slope, double* bsums,
-                                             void* stream) {
+                                             int accumulate, void* stream) {
   HaloArgs a = {};
   int rc = frag_common(d, a, "conv2d_dgrad_frag_bf16");
   if (rc) return rc;
   UDASEG_CHECK_ARG(dy && wfrag_t && dx, "conv2d_dgrad_frag_bf16: NULL pointer");
   UDASEG_CHECK_ARG(split == 0 ? dx2 == nullptr : (dx2 != nullptr && split > 0 && split < d->ci && split % 32 == 0),
                    "conv2d_dgrad_frag_bf16: split=%d needs dx2 and a multiple of 32 inside (0, ci=%d)", split, d->ci);
-  UDASEG_CHECK_ARG(prev_y == nullptr || (save_mean && save_rstd && gamma && beta && bsums && split == 0),
-                   "conv2d_dgrad_frag_bf16: the BatchNorm-backward reductions need mean / rstd / gamma / beta / bsums and no split");
+  UDASEG_CHECK_ARG(prev_y == nullptr || (save_mean && save_rstd && gamma && beta && bsums && split == 0 && !accumulate),
+                   "conv2d_dgrad_frag_bf16: the BatchNorm-backward reductions need mean / rstd / gamma / beta / bsums, no split, "
+                   "no accumulation");
+  UDASEG_CHECK_ARG(!(accumulate && split > 0), "conv2d_dgrad_frag_bf16: accumulation onto a split gradient is not supported");
   if (!halo_applicable(d, d->co, d->ci, 0)) {
     set_error("conv2d_dgrad_frag_bf16: geometry not supported (ask udaseg_conv_frag_ok first)");
     return UDASEG_E_UNSUPPORTED;
@@ -577,6 +643,7 @@ extern "C" int udaseg_conv2d_dgrad_frag_bf16(const udaseg_conv_desc* d, const vo
   a.x = dy; a.wf = wfrag_t; a.y = dx; a.y2 = dx2; a.split_n = split;
   a.ci = d->co; a.co = d->ci;        // the launch gathers dy (co channels) and produces dx (ci channels)
   a.act = UDASEG_ACT_NONE;
+  a.accumulate = accumulate ? 1 : 0;
   a.x_bytes = (unsigned)(px * d->co * 2);
   a.w_bytes = (unsigned)(udaseg_frag_elems(d->ci, d->co, d->kh) * 2);
   a.y_bytes = (unsigned)(px * (split > 0 ? split : d->ci) * 2);
@@ -588,7 +655,7 @@ extern "C" int udaseg_conv2d_dgrad_frag_bf16(const udaseg_conv_desc* d, const vo
   }
   hipStream_t st = as_stream(stream);
   prof_begin(0, st);
-  rc = launch_halo(d, a, st);
+  rc = launch_halo(d, a, st, true);
   prof_end(0, st, udaseg_conv_flops(d), 1, d);
   return rc;
 }

@@ -30,6 +30,12 @@ FUSE_BN_REDUCE = os.environ.get("UDASEG_FUSE_BN_REDUCE", "1") != "0"
 # 645.3 / 646.1 images/s with it against 648.4 / 650.8 without -- the 0.1 ms pass competes with the forward convolutions for
 # HBM and costs more than it hides; off by default.
 PREPACK_DGRAD = os.environ.get("UDASEG_PREPACK", "0") == "1"
+# bf16 storage: the stride-1 3x3 / 1x1 convolutions run on the bf16-first kernels (halo staged once, fragment-packed weights);
+# UDASEG_FRAG=0 keeps them on the shared implicit-GEMM source (A/B, cross-check; tests flip the module attribute)
+USE_FRAG_KERNELS = os.environ.get("UDASEG_FRAG", "1") != "0"
+# "auto": a layer takes them where the library's measured heuristic prefers them (udaseg_conv_frag_preferred); "always": wherever
+# they are supported (UDASEG_FRAG=2; network-level tests at small sizes, where "auto" would leave most layers on the old kernel)
+FRAG_POLICY = "always" if os.environ.get("UDASEG_FRAG") == "2" else "auto"
 
 
 _SIDE_STREAMS = {}   # device -> the one side HIP stream the weight gradients of every network on that device run on
@@ -224,6 +230,27 @@ class ArenaModule(nn.Module):
             if isinstance(m, ConvP) and m.needs_dgrad:
                 rows.append([self._idx[(id(m), "weight")][0], self._wt_off[id(m)], m.cout_p, m.k * m.k, m.cin_p])
         self._wt_table = torch.tensor(rows or [[0, 0, 0, 1, 0]], dtype=torch.int32, device=device)
+        # bf16 storage: MFMA-fragment packings of the stride-1 3x3 / 1x1 convolutions for the bf16-first kernels
+        # (csrc/conv_halo_bf16.hip), refreshed once per step by one batched launch per direction
+        self._frag_off, self._frag_fwd_table, self._frag_bwd_table, self._frag_arena = {}, None, None, None
+        if self.compute_dtype == torch.bfloat16 and USE_FRAG_KERNELS:
+            foff, frows, brows = 0, [], []
+            for m in self.modules():
+                if isinstance(m, ConvP) and m.stride == 1 and ((m.k == 3 and m.pad == 1) or (m.k == 1 and m.pad == 0)):
+                    nf = K.frag_elems(m.cout_p, m.cin_p, m.k)
+                    frows.append([0, self._idx[(id(m), "weight")][0], foff, m.cout_p, m.cin_p, m.k])
+                    ent = [foff, nf, None, 0]
+                    foff += nf
+                    if m.needs_dgrad:
+                        nd = K.frag_elems(m.cin_p, m.cout_p, m.k)
+                        brows.append([1, self._wt_off[id(m)], foff, m.cin_p, m.cout_p, m.k])
+                        ent[2], ent[3] = foff, nd
+                        foff += nd
+                    self._frag_off[id(m)] = tuple(ent)
+            if frows:
+                self._frag_arena = torch.empty(foff, device=device, dtype=torch.bfloat16)
+                self._frag_fwd_table = torch.tensor(frows, dtype=torch.int32, device=device)
+                self._frag_bwd_table = torch.tensor(brows, dtype=torch.int32, device=device) if brows else None
         return self
 
     def _arena_ok(self, full=True):
@@ -329,6 +356,9 @@ class Plan:
         self.bf16 = self.adt == torch.bfloat16
         # bf16 storage: one cast of the whole fp32 master arena per forward (same offsets / physical shapes)
         self.w16 = K.cast_to_bf16(net._arena, st=self.st) if self.bf16 else None
+        self.frag = training and self.bf16 and getattr(net, "_frag_arena", None) is not None
+        if self.frag:
+            K.pack_frag_batched(self.w16, None, net._frag_arena, net._frag_fwd_table, self.st)
         nbn = net._nbn
         self.dev = dev
         if training:
@@ -384,13 +414,28 @@ class Plan:
     def offset_of(self, mod, name="weight"):
         return self.idx[(id(mod), name)][0]
 
+    def wfrag(self, conv, d, dgrad=False, up_ca=0):
+        """The conv's fragment-packed weights (forward or data gradient) when this launch can take the bf16-first kernels."""
+        if not self.frag:
+            return None
+        ent = self.net._frag_off.get(id(conv))
+        ok = K.conv_frag_ok if FRAG_POLICY == "always" else K.conv_frag_preferred
+        if ent is None or (dgrad and ent[2] is None) or not ok(d, dgrad, up_ca):
+            return None
+        o, n = (ent[2], ent[3]) if dgrad else (ent[0], ent[1])
+        return self.net._frag_arena[o:o + n]
+
     # -- forward pieces
     def conv(self, conv, x, act=ACT_NONE, slope=0.0, out_dtype=None):
         n, h, w, ci = x.shape
         assert ci == conv.cin_p, (ci, conv.cin_p)
         d = K.conv_desc(n, h, w, ci, conv.cout_p, conv.k, conv.stride, conv.pad)
         y = torch.empty((n, d.ho, d.wo, conv.cout_p), device=x.device, dtype=out_dtype or self.adt)
-        K.conv2d_fwd(d, x, self.w(conv), self.b(conv) if conv.bias is not None else None, y, act, slope, False, self.st)
+        wf = self.wfrag(conv, d)
+        if wf is not None:
+            K.conv2d_fwd_frag(d, x, None, wf, self.b(conv) if conv.bias is not None else None, y, act, slope, st=self.st)
+        else:
+            K.conv2d_fwd(d, x, self.w(conv), self.b(conv) if conv.bias is not None else None, y, act, slope, False, self.st)
         return y, d
 
     def bn(self, bn, y, act, slope, residual=None, sums=None):
@@ -434,7 +479,10 @@ class Plan:
             d = K.conv_desc(n, h, w, ci, conv.cout_p, conv.k, conv.stride, conv.pad)
             y = torch.empty((n, d.ho, d.wo, conv.cout_p), device=dev, dtype=self.adt)
             sums = self._next_stats(ceil4(bn.c))
-            if up:
+            wf = self.wfrag(conv, d, up_ca=x.a.shape[3] if up else 0)
+            if wf is not None:
+                K.conv2d_fwd_frag(d, x.a if up else x, x.skip if up else None, wf, bias, y, stats=sums[0], up=up, st=self.st)
+            elif up:
                 K.conv2d_fwd_upcat(d, x.a, x.skip, self.w(conv), bias, y, ACT_NONE, 0.0, sums[0], self.st)
             else:
                 K.conv2d_fwd_bnstats(d, x, self.w(conv), bias, y, sums[0], self.st)
@@ -480,6 +528,8 @@ class Plan:
             self.main_stream.wait_event(self._packed)
         else:
             K.pack_dgrad_batched(net._arena, net._wt_arena, net._wt_table, self.st)
+        if self.frag and net._frag_bwd_table is not None:
+            K.pack_frag_batched(None, net._wt_arena, net._frag_arena, net._frag_bwd_table, self.st)
         if self.side_stream is not None:
             self.side_stream.wait_stream(self.main_stream)      # zeroed gradient arena is visible to the side stream
 
@@ -518,7 +568,10 @@ class Plan:
                 K.conv2d_wgrad_part(d, x.skip, x.a.shape[-1], False, dy, gw, True, wst)
             d_up, d_skip = dx
             assert not dx_acc and conv.bias is None
-            if x.skip is None:
+            wfd = self.wfrag(conv, d, dgrad=True)
+            if wfd is not None and (x.skip is None or x.a.shape[-1] % 32 == 0):
+                K.conv2d_dgrad_frag(d, dy, wfd, d_up, d_skip if x.skip is not None else None, st=self.st)
+            elif x.skip is None:
                 K.conv2d_dgrad(d, dy, self.packed_wt(conv), d_up, False, self.st)
             else:
                 K.conv2d_dgrad_split(d, dy, self.packed_wt(conv), d_up, d_skip, self.st)
@@ -530,13 +583,21 @@ class Plan:
             else:
                 K.channel_sum(dy, self.gvec(conv, "bias"), True, wst)
         if dx is not None:
-            if (prev is not None and FUSE_BN_REDUCE and not dx_acc and not prev[9] and prev[7] != ACT_NONE
-                    and K.conv2d_dgrad_bnreduce_ok(d, dy.dtype) and prev[4].shape == dx.shape):
+            wfd = self.wfrag(conv, d, dgrad=True)
+            fuse = (prev is not None and FUSE_BN_REDUCE and not dx_acc and not prev[9] and prev[7] != ACT_NONE
+                    and prev[4].shape == dx.shape and (wfd is not None or K.conv2d_dgrad_bnreduce_ok(d, dy.dtype)))
+            if fuse:
                 p_bn, p_y, (p_mean, p_rstd) = prev[1], prev[4], prev[6]
                 bs = self._next_bstats(p_y.shape[-1] if self.bf16 else ceil4(p_bn.c))
-                K.conv2d_dgrad_bnreduce(d, dy, self.packed_wt(conv), dx, p_y, p_mean, p_rstd, self.pvec(p_bn, "weight"),
-                                        self.pvec(p_bn, "bias"), prev[7], prev[8], bs, self.st)
+                if wfd is not None:
+                    K.conv2d_dgrad_frag(d, dy, wfd, dx, bn=(p_y, p_mean, p_rstd, self.pvec(p_bn, "weight"), self.pvec(p_bn, "bias"),
+                                                            prev[7], prev[8], bs), st=self.st)
+                else:
+                    K.conv2d_dgrad_bnreduce(d, dy, self.packed_wt(conv), dx, p_y, p_mean, p_rstd, self.pvec(p_bn, "weight"),
+                                            self.pvec(p_bn, "bias"), prev[7], prev[8], bs, self.st)
                 self._bnb[id(p_y)] = bs
+            elif wfd is not None:
+                K.conv2d_dgrad_frag(d, dy, wfd, dx, accumulate=dx_acc, st=self.st)
             else:
                 K.conv2d_dgrad(d, dy, self.packed_wt(conv), dx, dx_acc, self.st)
 

@@ -166,6 +166,11 @@ def conv_frag_ok(d, dgrad=False, up_ca=0):
     return bool(_lib.load().udaseg_conv_frag_ok(_byref(d), int(dgrad), up_ca))
 
 
+def conv_frag_preferred(d, dgrad=False, up_ca=0):
+    """Supported AND expected to beat the shared implicit-GEMM kernel for this shape (the library's measured heuristic)."""
+    return bool(_lib.load().udaseg_conv_frag_preferred(_byref(d), int(dgrad), up_ca))
+
+
 def conv2d_fwd_frag(d, x, skip, wfrag, bias, y, act=ACT_NONE, slope=0.0, stats=None, in_scale=None, in_shift=None, in_act=ACT_NONE,
                     in_slope=0.0, up=False, st=None):
     """bf16-first forward convolution (csrc/conv_halo_bf16.hip).  up: x is the half-resolution tensor of a fused decoder input."""
@@ -175,14 +180,14 @@ def conv2d_fwd_frag(d, x, skip, wfrag, bias, y, act=ACT_NONE, slope=0.0, stats=N
                                                    st if st is not None else stream()), "conv2d_fwd_frag_bf16")
 
 
-def conv2d_dgrad_frag(d, dy, wfrag_t, dx, dx2=None, bn=None, st=None):
+def conv2d_dgrad_frag(d, dy, wfrag_t, dx, dx2=None, bn=None, accumulate=False, st=None):
     """bf16-first data gradient.  dx2: second destination of a split gradient (channels [dx.shape[-1], ci)).
     bn = (prev_y, save_mean, save_rstd, gamma, beta, act, slope, bsums): BatchNorm-backward reductions of the layer behind."""
     py, mu, rs, ga, be, act, slope, bs = bn if bn is not None else (None, None, None, None, None, ACT_NONE, 0.0, None)
     check(_lib.load().udaseg_conv2d_dgrad_frag_bf16(_byref(d), dy.data_ptr(), wfrag_t.data_ptr(), dx.data_ptr(), _ptr(dx2),
                                                      dx.shape[-1] if dx2 is not None else 0, _ptr(py), _ptr(mu), _ptr(rs), _ptr(ga),
-                                                     _ptr(be), act, slope, _ptr(bs), st if st is not None else stream()),
-          "conv2d_dgrad_frag_bf16")
+                                                     _ptr(be), act, slope, _ptr(bs), int(accumulate),
+                                                     st if st is not None else stream()), "conv2d_dgrad_frag_bf16")
 
 
 def pack_dgrad_weights(d, w, w_t, st=None):
