@@ -171,7 +171,8 @@ def test_conv_frag_over_fused_upsample_concat(K, n, h, w, ca, cb, co):
     K.conv2d_fwd_frag(d, nhwc(a), nhwc(skip) if cb else None, wf, None, y, stats=st, up=True)
     if ca % 32 == 0 and cb % 32 == 0:
         assert torch.equal(y, y_mat)
-        assert torch.allclose(st.view(R, 2, co).sum(0), st_mat.view(R, 2, co).sum(0), rtol=1e-9, atol=1e-9)
+        # a block sums its tiles' statistics in fp32 (LDS adds, any order) before the f64 atomics: equal to fp32 rounding
+        assert torch.allclose(st.view(R, 2, co).sum(0), st_mat.view(R, 2, co).sum(0), rtol=1e-5, atol=1e-5)
     else:
         close(y.float().cpu(), y_mat.float().cpu(), "fused input, 16-channel chunks", BF_TOL)
         assert torch.allclose(st.view(R, 2, co).sum(0), st_mat.view(R, 2, co).sum(0), rtol=1e-5, atol=1e-5)

@@ -1,0 +1,69 @@
+#!/usr/bin/env python
+"""Per-block timestamps from inside conv_halo_bf16_kernel (udaseg_debug_set_timeline): where a launch spends its time.
+
+    python tools/halo_timeline.py [n,h,w,ci,co,k ...]
+
+Stamps per block: entry, first chunk staged (after the first barrier), end of the K loop, exit (after the stores have left).
+"""
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def pct(a, q):
+    return float(np.percentile(a, q))
+
+
+def main():
+    from uda_aerial_semantic_segmentation_research_amd import _lib, kernels as K
+    lib = _lib.require_gpu()
+    shapes = [tuple(int(v) for v in s.split(",")) for s in sys.argv[1:]] or [
+        (8, 128, 128, 64, 64, 3), (8, 64, 64, 128, 128, 3), (8, 256, 256, 128, 32, 3), (8, 512, 512, 16, 16, 3), (8, 192, 192, 64, 256, 1)]
+    cap = 1 << 16
+    buf = torch.zeros(cap * 6, dtype=torch.int64, device="cuda")
+    R = K.bn_replicas()
+    for (n, h, w, ci, co, k) in shapes:
+        d = K.conv_desc(n, h, w, ci, co, k, 1, k // 2)
+        x = torch.randn(n, h, w, ci, device="cuda").to(torch.bfloat16)
+        wt = (torch.randn(co, k, k, ci, device="cuda") / math.sqrt(ci * k * k)).to(torch.bfloat16)
+        nf = K.frag_elems(co, ci, k)
+        wf = torch.empty(nf, device="cuda", dtype=torch.bfloat16)
+        K.pack_frag_batched(wt, None, wf, torch.tensor([[0, 0, 0, co, ci, k]], dtype=torch.int32, device="cuda"))
+        y = torch.empty(n, h, w, co, device="cuda", dtype=torch.bfloat16)
+        st = torch.zeros(R * 2 * co, dtype=torch.float64, device="cuda")
+        for _ in range(5):
+            K.conv2d_fwd_frag(d, x, None, wf, None, y, stats=st)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(20):
+            K.conv2d_fwd_frag(d, x, None, wf, None, y, stats=st)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / 20
+        buf.zero_()
+        _lib.check(lib.udaseg_debug_set_timeline(buf.data_ptr(), cap))
+        K.conv2d_fwd_frag(d, x, None, wf, None, y, stats=st)
+        torch.cuda.synchronize()
+        _lib.check(lib.udaseg_debug_set_timeline(None, 0))
+        t = buf.cpu().numpy().reshape(-1, 6)
+        nb = int((t[:, 3] != 0).sum())
+        t = t[:nb].astype(np.int64)
+        t0 = t[:, 0].min()
+        ent, ld, kend, ex = [(t[:, i] - t0) / 100.0 for i in range(4)]
+        fl = 2.0 * n * h * w * co * ci * k * k
+        by = (n * h * w * (ci + co) * 2) / 1e6
+        print(f"== {(n, h, w, ci, co, k)}: {nb} blocks; back-to-back {us:.1f} us ({fl / us / 1e6:.0f} TFLOP/s, {by / us:.2f} TB/s algorithmic); "
+              f"first entry -> last exit {ex.max():.1f} us")
+        for name, v in (("entry", ent), ("first chunk staged - entry", ld - ent), ("K loop after that", kend - ld), ("epilogue + stores", ex - kend),
+                        ("whole block", ex - ent), ("exit", ex)):
+            print(f"   {name:28s} p10 {pct(v, 10):6.1f}  p50 {pct(v, 50):6.1f}  p90 {pct(v, 90):6.1f}  max {v.max():6.1f} us")
+
+
+if __name__ == "__main__":
+    main()

@@ -730,8 +730,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
 
 // ------------------------------------------------------------------------------------------------- host side
 
-static unsigned long long* g_timeline = nullptr;
-static int g_timeline_blocks = 0;
+unsigned long long* g_timeline = nullptr;     // also read by conv_halo_bf16.hip
+int g_timeline_blocks = 0;
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool BF, bool UNI, bool UP>
 static int launch_cfg_t(const IgemmArgs& a, hipStream_t s) {
