@@ -344,6 +344,23 @@ int udaseg_pack_dgrad_batched_bf16(const float* arena, void* packed, const int* 
  *      destination element offset, N, K, ks} (int32 x 6, device memory). ---- */
 int64_t udaseg_frag_elems(int n_out, int k_in, int ks);
 int udaseg_pack_frag_batched_bf16(const void* w16, const void* wt16, void* packed, const int* table, int entries, void* stream);
+/* ---- a BatchNorm + activation that is never written (single-consumer layers, bf16): the producer's statistics are finalised
+ *      into per-channel scale = gamma * rstd and shift = beta - mean * scale (plus the saved mean / rstd and the running
+ *      statistics, exactly as udaseg_bn_apply_bf16 would), and every consumer of the activation applies
+ *      act(fma(y, scale, shift)) rounded to bf16 while it stages y: the forward convolution (udaseg_conv2d_fwd_frag_bf16
+ *      in_scale / in_shift), its weight gradient (udaseg_conv2d_wgrad_bnin_bf16) and the layer's own BatchNorm backward
+ *      (udaseg_bn_bwd_apply_recompute_bf16: the mask is re-evaluated with the same fused multiply-add; its two reductions come
+ *      from the consumer's data gradient, udaseg_conv2d_dgrad_frag_bf16 prev_y).  nn.BatchNorm2d + nn.ReLU inside smp.Unet's
+ *      blocks, reference src/models/train.py:341,343. ---- */
+int udaseg_bn_finalize(const double* sums, const float* gamma, const float* beta, int64_t pixels, int c, float eps, float momentum,
+                       float* running_mean, float* running_var, float* save_mean, float* save_rstd, float* scale, float* shift,
+                       void* stream);
+int udaseg_bn_bwd_apply_recompute_bf16(const void* dz, const void* y, const float* fwd_scale, const float* fwd_shift,
+                                       const float* save_mean, const float* save_rstd, const float* gamma, const double* bsums,
+                                       void* dy, float* dgamma, float* dbeta, int64_t pixels, int c, int act, float slope,
+                                       void* stream);
+int udaseg_conv2d_wgrad_bnin_bf16(const udaseg_conv_desc* d, const void* x, const float* in_scale, const float* in_shift, int in_act,
+                                  float in_slope, const void* dy, float* dw, int accumulate, void* stream);
 /* 1 when the convolution (dgrad = 0: forward, gathers ci and produces co; dgrad = 1: its data gradient; up_ca > 0: forward on the
  * fused decoder input cat([nearest_x2(a), skip]) with up_ca channels from a) can take these kernels */
 int udaseg_conv_frag_ok(const udaseg_conv_desc* d, int dgrad, int up_ca);

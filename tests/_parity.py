@@ -73,6 +73,7 @@ def gpu_relu_outputs(net):
         else:
             zs = [blk.relu_outputs(rec)[0], out]
         outs += [(unit, z) for z in zs]
+    outs = [(u, z.materialize() if hasattr(z, "materialize") else z) for u, z in outs]     # engine.LazyAct: never written
     return [(u, z.detach().float().cpu().permute(0, 3, 1, 2)) for u, z in outs]
 
 

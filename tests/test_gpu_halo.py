@@ -207,3 +207,87 @@ def test_conv_frag_applies_the_producers_batchnorm_while_staging(K, n, h, w, ci,
     K.conv2d_fwd_frag(d, x, None, wf, None, y, in_scale=scale, in_shift=shift, in_act=act, in_slope=slope)
     assert torch.equal(y, y_mat)
     close(nchw32(y), F.conv2d(z.float().cpu().permute(0, 3, 1, 2), wt, None, padding=k // 2), "conv over the fused BatchNorm input")
+
+
+@pytest.mark.parametrize("n,h,w,c,co,act,slope", [(2, 16, 32, 64, 64, 1, 0.0), (1, 9, 21, 32, 16, 1, 0.2), (2, 12, 12, 16, 48, 1, 0.0)])
+def test_unwritten_batchnorm_activation_pieces(K, n, h, w, c, co, act, slope):
+    """The pieces behind engine.LazyAct (BatchNorm + activation of a single-consumer layer that is never written):
+    udaseg_bn_finalize gives the statistics, running statistics and scale / shift that udaseg_bn_apply_bf16 uses internally;
+    the weight gradient with the transform in its gather == the weight gradient over the materialised activation; the
+    BatchNorm backward with the mask re-evaluated from y == the one that reads the stored activation, bit for bit."""
+    g = torch.Generator().manual_seed(c + co + h)
+    R = K.bn_replicas()
+    y = (torch.randn(n, h, w, c, generator=g) * 1.5 + 0.2).to(bf).cuda()
+    gamma, beta = (torch.rand(c, generator=g) + 0.5).cuda(), (torch.randn(c, generator=g) * 0.3).cuda()
+    yd = y.double().reshape(-1, c)
+    sums = torch.zeros(R * 2 * c, dtype=torch.float64, device="cuda")
+    sums.view(R, 2, c)[0, 0], sums.view(R, 2, c)[3, 1] = yd.sum(0), (yd * yd).sum(0)
+    px = n * h * w
+    # reference: the stand-alone pass
+    rm, rv = torch.zeros(c, device="cuda"), torch.ones(c, device="cuda")
+    sm, sr = torch.empty(c, device="cuda"), torch.empty(c, device="cuda")
+    z = torch.empty_like(y)
+    K.bn_apply(y, sums, gamma, beta, None, z, 1e-5, 0.1, rm, rv, sm, sr, act, slope)
+    # finalize only
+    rm2, rv2 = torch.zeros(c, device="cuda"), torch.ones(c, device="cuda")
+    sm2, sr2, sc, sh = (torch.empty(c, device="cuda") for _ in range(4))
+    K.bn_finalize(sums, gamma, beta, px, 1e-5, 0.1, rm2, rv2, sm2, sr2, sc, sh)
+    assert torch.equal(sm, sm2) and torch.equal(sr, sr2) and torch.equal(rm, rm2) and torch.equal(rv, rv2)
+    from uda_aerial_semantic_segmentation_research_amd.engine import LazyAct
+    lazy = LazyAct(y, sc, sh, act, slope)
+    assert torch.equal(lazy.materialize(), z), "LazyAct.materialize() must reproduce what bn_apply stores"
+    # weight gradient: transform in the gather vs the materialised activation
+    d = K.conv_desc(n, h, w, c, co, 3, 1, 1)
+    dy = torch.randn(n, h, w, co, generator=g).to(bf).cuda()
+    dw_ref = torch.zeros(co, 3, 3, c, device="cuda")
+    K.conv2d_wgrad(d, z, dy, dw_ref, True)
+    dw = torch.zeros_like(dw_ref)
+    K.conv2d_wgrad_bnin(d, y, sc, sh, act, slope, dy, dw, True)
+    close(dw.cpu(), dw_ref.cpu(), "wgrad with the BatchNorm transform in its gather", 2e-6)     # same bf16 operands: atomics order only
+    # forward convolution over the unwritten activation == over the stored one
+    wt = rb(torch.randn(co, c, 3, 3, generator=g) / math.sqrt(9 * c))
+    wf, _ = pack(K, wt)
+    y2_ref, y2 = torch.empty(n, h, w, co, device="cuda", dtype=bf), torch.empty(n, h, w, co, device="cuda", dtype=bf)
+    K.conv2d_fwd_frag(d, z, None, wf, None, y2_ref)
+    K.conv2d_fwd_frag(d, y, None, wf, None, y2, in_scale=sc, in_shift=sh, in_act=act, in_slope=slope)
+    assert torch.equal(y2, y2_ref)
+    # BatchNorm backward: mask from the stored activation vs re-evaluated from y
+    dz = torch.randn(n, h, w, c, generator=g).to(bf).cuda()
+    bs = torch.zeros(R * 2 * c, dtype=torch.float64, device="cuda")
+    K.bn_bwd_reduce(dz, z, y, sm, sr, bs, act, slope)
+    dy_ref, dg_ref, db_ref = torch.empty_like(y), torch.empty(c, device="cuda"), torch.empty(c, device="cuda")
+    K.bn_bwd_apply(dz, z, y, sm, sr, gamma, bs, dy_ref, None, dg_ref, db_ref, act, slope)
+    dyo, dg, db = torch.empty_like(y), torch.empty(c, device="cuda"), torch.empty(c, device="cuda")
+    K.bn_bwd_apply_recompute(dz, y, sc, sh, sm, sr, gamma, bs, dyo, dg, db, act, slope)
+    assert torch.equal(dyo, dy_ref) and torch.equal(dg, dg_ref) and torch.equal(db, db_ref)
+
+
+def test_network_with_and_without_unwritten_activations(K, monkeypatch):
+    """r18-Unet bf16 train step with engine.FUSE_BN_APPLY on and off: the forward is bit-identical (the consumer convolutions see
+    the same bf16 activation values), the gradients agree to the order of the fp32 atomics."""
+    from uda_aerial_semantic_segmentation_research_amd import engine
+    from uda_aerial_semantic_segmentation_research_amd.losses import CrossEntropyLoss
+    from uda_aerial_semantic_segmentation_research_amd.unet import Unet
+    monkeypatch.setattr(engine, "FRAG_POLICY", "always")
+    torch.manual_seed(7)
+    net = Unet("resnet18", encoder_weights=None, in_channels=3, classes=23, compute_dtype=torch.bfloat16).to("cuda").train()
+    x = torch.randn(2, 3, 128, 96, device="cuda")
+    t = torch.randint(0, 23, (2, 128, 96), device="cuda")
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+    outs = {}
+    for fuse in (False, True):
+        monkeypatch.setattr(engine, "FUSE_BN_APPLY", fuse)
+        net.load_state_dict(state)
+        net.zero_grad()
+        net.debug_keep_tape = True
+        logits = net(x)
+        lazies = sum(isinstance(rec[1] if not hasattr(blk, "relu_outputs") else rec[3], engine.LazyAct) for blk, rec, _ in net._last_tape[1])
+        CrossEntropyLoss()(logits, t).backward()
+        outs[fuse] = (logits.detach().clone(), net._grad_arena.clone(), lazies, {k: v.clone() for k, v in net.state_dict().items()})
+        net.debug_keep_tape, net._last_tape = False, None
+    assert outs[False][2] == 0 and outs[True][2] >= 8, (outs[False][2], outs[True][2])
+    assert torch.equal(outs[True][0], outs[False][0]), "logits differ between written and unwritten activations"
+    ga, gb = outs[True][1], outs[False][1]
+    assert ((ga - gb).abs().max() / gb.abs().max()).item() < 1e-5
+    for k, v in outs[True][3].items():          # BatchNorm running statistics updated identically
+        assert torch.equal(v, outs[False][3][k]), k

@@ -379,8 +379,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_halo_bf16_kernel(const H
           for (int e = 0; e < 4; ++e) {
             const float yy = (e & 1) ? bf_hi(yv[e >> 1]) : bf_lo(yv[e >> 1]);
             const float gr = (e & 1) ? bf_hi(dw[2 * g + (e >> 1)]) : bf_lo(dw[2 * g + (e >> 1)]);
-            const float sc = gm[e] * rsd[e], sh = bt[e] - mu[e] * sc;
-            const float gg = cv ? gr * act_grad(yy * sc + sh, a.bnb_act, a.bnb_slope) : 0.f;
+            const float sc = gm[e] * rsd[e], sh = bt[e] - mu[e] * sc;      // as bn_apply / bn_finalize form them
+            const float gg = cv ? gr * act_grad(__builtin_fmaf(yy, sc, sh), a.bnb_act, a.bnb_slope) : 0.f;
             sA[4 * g + e] += gg;
             sB[4 * g + e] = __builtin_fmaf(gg, (yy - mu[e]) * rsd[e], sB[4 * g + e]);
           }

@@ -47,6 +47,13 @@ struct WgradArgs {
   // count), its columns land at dw[co][tap * ci_full + c_off + c], dW rows are J_ld = taps * ci_full long.
   // up: the source sits at half resolution behind a nearest x2 up-sampling: pixel (iy, ix) reads (iy >> 1, ix >> 1).
   int ci_full, c_off, J_ld, up;
+  // bf16 kernel only: x is a convolution output whose training-mode BatchNorm + activation was never written (its consumer applied
+  // it while staging: udaseg_conv2d_fwd_frag_bf16 in_scale / in_shift); the gather applies the same transform
+  // v -> act(fma(v, in_scale[c], in_shift[c])) rounded to bf16, padded taps stay zero.  null: x is used as it is.
+  const float* in_scale;
+  const float* in_shift;
+  int in_act;
+  float in_slope;
 };
 
 constexpr int WBK = 32;  // pixels per K-tile
@@ -325,6 +332,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradArgs a)
 
   f32x4 ra[A_PASS], rb[B_PASS];
   const int nkt = (kend - kbeg + WBKB - 1) / WBKB;
+  // producer's BatchNorm + activation on the gathered operand (WgradArgs::in_scale): this thread's 8 channels are fixed
+  const bool xform = a.in_scale != nullptr;
+  float x_sc[8], x_sh[8];
+  unsigned x_ok = 0;          // bit p: pass p of the tile in the registers is inside the image
+  if (xform) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      x_sc[e] = b_ok ? a.in_scale[b_c + e] : 0.f;
+      x_sh[e] = b_ok ? a.in_shift[b_c + e] : 0.f;
+    }
+  }
 
   // row-uniform gather (see conv_wgrad_kernel): a pass covers B_ROWS consecutive pixels of one image row
   static_assert(!ROWU || (WBKB % A_ROWS == 0 && WBKB % B_ROWS == 0), "row-uniform passes must tile the K-tile");
@@ -377,6 +395,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradArgs a)
           voff = u_bc + s_off;
         }
         voff = ok ? voff : 0x80000000u;
+        x_ok = (x_ok & ~(1u << p)) | ((ok && b_ok ? 1u : 0u) << p);
         rb[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)voff, 0, 0));
         s_ox[p] += WBKB;
         while (s_ox[p] >= a.wo) {
@@ -401,6 +420,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradArgs a)
     for (int p = 0; p < B_PASS; ++p) {
       const int row = brow + B_ROWS * p, m = mb + row;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      bool inside = false;
       if (b_ok && row < WBKB && m < kend) {
         const int t1 = fast_div(m, a.wo, a.inv_wo);
         const int ox = m - t1 * a.wo;
@@ -410,8 +430,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradArgs a)
         if ((unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi) {
           const size_t pix = a.up ? (size_t)(ni * (a.hi >> 1) + (iy >> 1)) * (a.wi >> 1) + (ix >> 1) : (size_t)(ni * a.hi + iy) * a.wi + ix;
           v = *reinterpret_cast<const f32x4*>(xg + pix * (size_t)a.ci + b_c);
+          inside = true;
         }
       }
+      x_ok = (x_ok & ~(1u << p)) | ((inside ? 1u : 0u) << p);
       rb[p] = v;
     }
   };
@@ -419,6 +441,26 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradArgs a)
 #pragma unroll
     for (int p = 0; p < A_PASS; ++p)
       if (arow + A_ROWS * p < WBKB) *reinterpret_cast<f32x4*>(&As[buf][arow + A_ROWS * p][aq * 8]) = ra[p];
+    if (xform) {
+#pragma unroll
+      for (int p = 0; p < B_PASS; ++p) {
+        typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
+        const u32x4w wv = __builtin_bit_cast(u32x4w, rb[p]);
+        u32x4w dv;
+        const bool ok = (x_ok >> p) & 1u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const unsigned w = wv[e];
+          float t0 = __builtin_fmaf(__builtin_bit_cast(float, w << 16), x_sc[2 * e], x_sh[2 * e]);
+          float t1 = __builtin_fmaf(__builtin_bit_cast(float, w & 0xffff0000u), x_sc[2 * e + 1], x_sh[2 * e + 1]);
+          t0 = act_apply(t0, a.in_act, a.in_slope);
+          t1 = act_apply(t1, a.in_act, a.in_slope);
+          dv[e] = ok ? ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)t0) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)t1) << 16))
+                     : 0u;
+        }
+        rb[p] = __builtin_bit_cast(f32x4, dv);
+      }
+    }
 #pragma unroll
     for (int p = 0; p < B_PASS; ++p)
       if (brow + B_ROWS * p < WBKB) *reinterpret_cast<f32x4*>(&Bs[buf][brow + B_ROWS * p][bq * 8]) = rb[p];
@@ -562,7 +604,8 @@ using namespace udaseg;
 // One implementation behind the four entry points.  src_c / c_off / up describe a channel slice of dW (WgradArgs::ci_full):
 // the whole gradient is src_c == d->ci, c_off == 0, up == 0.
 static int conv2d_wgrad_impl(const udaseg_conv_desc* d, const void* x, int src_c, int c_off, int up, const void* dy, float* dw,
-                             int accumulate, void* stream, int bf16) {
+                             int accumulate, void* stream, int bf16, const float* in_scale = nullptr, const float* in_shift = nullptr,
+                             int in_act = UDASEG_ACT_NONE, float in_slope = 0.f) {
   UDASEG_CHECK_ARG(d && x && dy && dw, "conv2d_wgrad: NULL pointer");
   const int g = bf16 ? 8 : 4;
   UDASEG_CHECK_ARG(d->ci % g == 0 && d->co % g == 0 && d->ci > 0 && d->co > 0, "conv2d_wgrad: channels must be multiples of %d", g);
@@ -586,6 +629,7 @@ static int conv2d_wgrad_impl(const udaseg_conv_desc* d, const void* x, int src_c
   a.M = d->n * d->ho * d->wo;
   a.J = d->kh * d->kw * src_c;
   a.ci_full = d->ci; a.c_off = c_off; a.J_ld = d->kh * d->kw * d->ci; a.up = up;
+  a.in_scale = in_scale; a.in_shift = in_shift; a.in_act = in_act; a.in_slope = in_slope;
   a.inv_ci = 1.0f / src_c; a.inv_kw = 1.0f / d->kw; a.inv_wo = 1.0f / d->wo; a.inv_ho = 1.0f / d->ho;
   if (d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0 && !up) {
     // a 1x1 / stride 1 convolution gathers pixel m from pixel m: the batch is ONE image row of M pixels as far as the gather is
@@ -621,6 +665,12 @@ extern "C" int udaseg_conv2d_wgrad_bf16(const udaseg_conv_desc* d, const void* x
                                         void* stream) {
   UDASEG_CHECK_ARG(d != nullptr, "conv2d_wgrad_bf16: NULL desc");
   return conv2d_wgrad_impl(d, x, d->ci, 0, 0, dy, dw, accumulate, stream, 1);
+}
+
+extern "C" int udaseg_conv2d_wgrad_bnin_bf16(const udaseg_conv_desc* d, const void* x, const float* in_scale, const float* in_shift,
+                                             int in_act, float in_slope, const void* dy, float* dw, int accumulate, void* stream) {
+  UDASEG_CHECK_ARG(d != nullptr && in_scale != nullptr && in_shift != nullptr, "conv2d_wgrad_bnin_bf16: NULL desc / scale / shift");
+  return conv2d_wgrad_impl(d, x, d->ci, 0, 0, dy, dw, accumulate, stream, 1, in_scale, in_shift, in_act, in_slope);
 }
 
 extern "C" int udaseg_conv2d_wgrad_part(const udaseg_conv_desc* d, const float* src, int src_c, int c_off, int up,

@@ -178,8 +178,12 @@ __global__ void bn_bwd_apply_bf16_kernel(const f32x4* __restrict__ dz, const f32
                                          const float* __restrict__ save_rstd, const float* __restrict__ gamma,
                                          const double* __restrict__ bsums, f32x4* __restrict__ dy, f32x4* __restrict__ dres,
                                          float* dgamma, float* dbeta, int64_t n8, int c8, int64_t pixels, int act,
-                                         float slope, int acc_dy, int acc_dres, int acc_param) {
-  extern __shared__ __attribute__((aligned(16))) float coef[];  // [5][C]: mean, rstd, scale, mean(g), mean(g*xhat)
+                                         float slope, int acc_dy, int acc_dres, int acc_param,
+                                         const float* __restrict__ fwd_scale, const float* __restrict__ fwd_shift) {
+  // fwd_scale / fwd_shift != null: the activation was never written (its consumer applied BatchNorm + activation while staging,
+  // udaseg_conv2d_fwd_frag_bf16's in_scale / in_shift): its argument is re-evaluated here from y with the SAME fused
+  // multiply-add and the same two vectors, so the mask is bit-identical to the forward's; z is not read
+  extern __shared__ __attribute__((aligned(16))) float coef[];  // [5 (+2)][C]: mean, rstd, scale, mean(g), mean(g*xhat) (, fwd scale, shift)
   const int C = c8 * 8;
   const double inv = 1.0 / (double)pixels;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -195,6 +199,10 @@ __global__ void bn_bwd_apply_bf16_kernel(const f32x4* __restrict__ dz, const f32
     coef[2 * C + c] = gamma[c] * rs;
     coef[3 * C + c] = (float)(s1 * inv);
     coef[4 * C + c] = (float)(s2 * inv);
+    if (fwd_scale) {
+      coef[5 * C + c] = fwd_scale[c];
+      coef[6 * C + c] = fwd_shift[c];
+    }
     if (blockIdx.x == 0) {
       const float db = (float)s1, dg = (float)s2;
       if (dbeta) dbeta[c] = acc_param ? dbeta[c] + db : db;
@@ -211,12 +219,17 @@ __global__ void bn_bwd_apply_bf16_kernel(const f32x4* __restrict__ dz, const f32
     const int c = q * 8 + e;
     mean[e] = coef[c]; rstd[e] = coef[C + c]; scale[e] = coef[2 * C + c]; mg[e] = coef[3 * C + c]; mgx[e] = coef[4 * C + c];
   }
+  const bool recompute = fwd_scale != nullptr;
   auto body = [&](int64_t i, const f32x4 gv, const f32x4 yv, const f32x4 zv, const f32x4 ov, const f32x4 rv) {
     float gz[8], zz[8], yy[8], out[8], old[8];
     unpack8(gv, gz);
     unpack8(yv, yy);
-    if (act != UDASEG_ACT_NONE) unpack8(zv, zz);
+    if (act != UDASEG_ACT_NONE && !recompute) unpack8(zv, zz);
     if (acc_dy) unpack8(ov, old);
+    if (recompute) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) zz[e] = __builtin_fmaf(yy[e], coef[5 * C + q * 8 + e], coef[6 * C + q * 8 + e]);
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       if (act != UDASEG_ACT_NONE) gz[e] *= act_grad(zz[e], act, slope);
@@ -235,8 +248,41 @@ __global__ void bn_bwd_apply_bf16_kernel(const f32x4* __restrict__ dz, const f32
     }
   };
   const f32x4 zero = {0, 0, 0, 0};       // plain loop: see bn_bwd_apply_kernel (the four-deep unroll lost here)
-  const bool need_z = act != UDASEG_ACT_NONE, need_res = dres != nullptr && acc_dres;
+  const bool need_z = act != UDASEG_ACT_NONE && !recompute, need_res = dres != nullptr && acc_dres;
   for (int64_t i = g; i < n8; i += T) body(i, dz[i], y[i], need_z ? z[i] : zero, acc_dy ? dy[i] : zero, need_res ? dres[i] : zero);
+}
+
+// Training-mode BatchNorm statistics -> everything the layer's consumers need, WITHOUT touching the activation: mean / rstd
+// (saved for the backward), the running statistics, and the per-channel scale = gamma * rstd, shift = beta - mean * scale that
+// a consumer applies while it stages its input (udaseg_conv2d_fwd_frag_bf16 in_scale / in_shift).  Same arithmetic as the
+// prologue of bn_apply_bf16_kernel, so a layer gives the same numbers whichever way it is applied.
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   int C, int64_t pixels, float eps, float momentum, float* running_mean, float* running_var,
+                                   float* save_mean, float* save_rstd, float* scale, float* shift) {
+  const double inv = 1.0 / (double)pixels;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int r = 0; r < BN_REPLICAS; ++r) {
+      s1 += sums[(size_t)r * 2 * C + c];
+      s2 += sums[(size_t)r * 2 * C + C + c];
+    }
+    const double m = s1 * inv;
+    double var = s2 * inv - m * m;
+    var = var > 0.0 ? var : 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * rstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)m * sc;
+    if (save_mean) save_mean[c] = (float)m;
+    if (save_rstd) save_rstd[c] = rstd;
+    if (running_mean) {
+      const float v = (float)var;
+      const float unb = pixels > 1 ? v * ((float)pixels / (float)(pixels - 1)) : v;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+    }
+  }
 }
 
 __global__ void act_bwd_bf16_kernel(const f32x4* __restrict__ dz, const f32x4* __restrict__ z, f32x4* __restrict__ dy,
@@ -563,8 +609,37 @@ extern "C" int udaseg_bn_bwd_apply_bf16(const void* dz, const void* z, const voi
   const StreamShape s = stream_shape(n8, c / 8);
   hipLaunchKernelGGL(bn_bwd_apply_bf16_kernel, dim3(s.grid), dim3(s.bs), (size_t)5 * c * sizeof(float), as_stream(stream),
                      (const f32x4*)dz, (const f32x4*)z, (const f32x4*)y, save_mean, save_rstd, gamma, bsums, (f32x4*)dy,
-                     (f32x4*)dres, dgamma, dbeta, n8, s.c4, pixels, act, slope, accumulate_dy, accumulate_dres, accumulate_param);
+                     (f32x4*)dres, dgamma, dbeta, n8, s.c4, pixels, act, slope, accumulate_dy, accumulate_dres, accumulate_param,
+                     (const float*)nullptr, (const float*)nullptr);
   UDASEG_LAUNCH_CHECK("bn_bwd_apply_bf16 launch");
+  return UDASEG_OK;
+}
+
+extern "C" int udaseg_bn_bwd_apply_recompute_bf16(const void* dz, const void* y, const float* fwd_scale, const float* fwd_shift,
+                                                  const float* save_mean, const float* save_rstd, const float* gamma,
+                                                  const double* bsums, void* dy, float* dgamma, float* dbeta, int64_t pixels, int c,
+                                                  int act, float slope, void* stream) {
+  int rc = check_pc8(pixels, c, "bn_bwd_apply_recompute_bf16");
+  if (rc) return rc;
+  UDASEG_CHECK_ARG(dz && y && fwd_scale && fwd_shift && save_mean && save_rstd && gamma && bsums && dy,
+                   "bn_bwd_apply_recompute_bf16: NULL pointer");
+  UDASEG_CHECK_ARG((size_t)7 * c * sizeof(float) <= 65536, "bn_bwd_apply_recompute_bf16: too many channels");
+  const int64_t n8 = pixels * (c / 8);
+  const StreamShape s = stream_shape(n8, c / 8);
+  hipLaunchKernelGGL(bn_bwd_apply_bf16_kernel, dim3(s.grid), dim3(s.bs), (size_t)7 * c * sizeof(float), as_stream(stream),
+                     (const f32x4*)dz, (const f32x4*)nullptr, (const f32x4*)y, save_mean, save_rstd, gamma, bsums, (f32x4*)dy,
+                     (f32x4*)nullptr, dgamma, dbeta, n8, s.c4, pixels, act, slope, 0, 0, 0, fwd_scale, fwd_shift);
+  UDASEG_LAUNCH_CHECK("bn_bwd_apply_recompute_bf16 launch");
+  return UDASEG_OK;
+}
+
+extern "C" int udaseg_bn_finalize(const double* sums, const float* gamma, const float* beta, int64_t pixels, int c, float eps,
+                                  float momentum, float* running_mean, float* running_var, float* save_mean, float* save_rstd,
+                                  float* scale, float* shift, void* stream) {
+  UDASEG_CHECK_ARG(sums && gamma && beta && scale && shift && pixels > 0 && c > 0, "bn_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(c, 256)), dim3(256), 0, as_stream(stream), sums, gamma, beta, c, pixels, eps,
+                     momentum, running_mean, running_var, save_mean, save_rstd, scale, shift);
+  UDASEG_LAUNCH_CHECK("bn_finalize launch");
   return UDASEG_OK;
 }
 

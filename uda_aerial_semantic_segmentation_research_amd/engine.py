@@ -38,6 +38,11 @@ USE_FRAG_KERNELS = os.environ.get("UDASEG_FRAG", "1") != "0"
 FRAG_POLICY = "always" if os.environ.get("UDASEG_FRAG") == "2" else "auto"
 
 
+# bf16 storage: BatchNorm + activation of a layer whose ONLY consumer is a convolution on the bf16-first kernels is not written at
+# all -- the consumer applies it while it stages its input (UDASEG_FUSE_BN_APPLY=0: always the stand-alone bn_apply pass)
+FUSE_BN_APPLY = os.environ.get("UDASEG_FUSE_BN_APPLY", "1") != "0"
+
+
 _SIDE_STREAMS = {}   # device -> the one side HIP stream the weight gradients of every network on that device run on
 _ARENA_OWNERS = {}   # parameter-arena storage pointer -> weakref of the ArenaModule that owns it
 
@@ -85,6 +90,28 @@ class UpCat:
 
     def __init__(self, a, skip):
         self.a, self.skip = a, skip
+
+
+class LazyAct:
+    """act(batchnorm(y)) that is never written: ``y`` is the producer's raw convolution output, ``scale`` / ``shift`` the finalised
+    per-channel coefficients (udaseg_bn_finalize).  Its single consumer applies act(fma(y, scale, shift)) rounded to bf16 while
+    staging (forward convolution, weight gradient); the producer's BatchNorm backward re-evaluates the mask the same way."""
+    __slots__ = ("y", "scale", "shift", "act", "slope")
+
+    def __init__(self, y, scale, shift, act, slope):
+        self.y, self.scale, self.shift, self.act, self.slope = y, scale, shift, act, slope
+
+    shape = property(lambda self: self.y.shape)
+    dtype = property(lambda self: self.y.dtype)
+    device = property(lambda self: self.y.device)
+
+    def materialize(self):
+        """The activation as a tensor (tests / debugging only): one rounding of y * scale + shift like the kernels' fused
+        multiply-add (evaluated in f64, rounded once to fp32), activation, round to the storage type."""
+        t = torch.addcmul(self.shift.double(), self.y.double(), self.scale.double()).float()
+        if self.act != ACT_NONE:
+            t = torch.where(t > 0, t, self.slope * t)
+        return t.to(self.y.dtype)
 
 
 class ConvP(nn.Module):
@@ -364,6 +391,7 @@ class Plan:
         if training:
             self.stats = torch.zeros(max(nbn, 2) * self.R, dtype=torch.float64, device=dev)  # [R][sum | sumsq] per BN
             self.saved_stats = torch.empty(max(nbn, 2), dtype=torch.float32, device=dev)  # [mean | rstd] per BN
+            self.coefs = torch.empty(max(nbn, 2), dtype=torch.float32, device=dev) if self.bf16 else None  # [scale | shift] of lazy BNs
         else:
             # inference: BatchNorm is folded into the conv weights (scratch refreshed per forward: one pass over the weights)
             self.fold_w = torch.empty_like(net._arena)
@@ -461,13 +489,29 @@ class Plan:
         self._stat_off += 2 * c
         return self.stats[o * self.R:(o + 2 * c) * self.R], o
 
-    def conv_bn_act(self, conv, bn, x, act=ACT_LEAKY, slope=0.0, residual=None):
+    def like(self, t):
+        """An empty tensor shaped like activation ``t`` (which may be a LazyAct)."""
+        return torch.empty_like(t.y if isinstance(t, LazyAct) else t)
+
+    def _lazy_ok(self, c, n, ho, wo, consumer, act, residual):
+        """May BatchNorm + activation of this [n, ho, wo, c] output stay unwritten?  Only when its single consumer runs on the
+        bf16-first kernels in BOTH directions (the forward applies the transform while staging; the data gradient's epilogue
+        makes this layer's BatchNorm-backward sums, which then need no activation either)."""
+        if not (FUSE_BN_APPLY and FUSE_BN_REDUCE and self.frag and consumer is not None and residual is None and act != ACT_NONE):
+            return False
+        if consumer.stride != 1 or consumer.cin_p != c or c % 16 != 0:
+            return False
+        d2 = K.conv_desc(n, ho, wo, c, consumer.cout_p, consumer.k, 1, consumer.pad)
+        return self.wfrag(consumer, d2) is not None and self.wfrag(consumer, d2, dgrad=True) is not None
+
+    def conv_bn_act(self, conv, bn, x, act=ACT_LEAKY, slope=0.0, residual=None, lazy_for=None):
         """z = act(bn(conv(x)) (+ residual)); returns (z, record for backward).  In training the conv's epilogue also
         accumulates the BN statistics of its output (no separate pass over y).
 
         ``x`` may be an ``UpCat(a, skip)``: the convolution then runs on cat([nearest_x2(a), skip], channels) without that
         tensor ever being written (fused gather; smp's decoder block input)."""
         up = isinstance(x, UpCat)
+        lazy_in = isinstance(x, LazyAct)
         if up:
             n, h, w = x.a.shape[0], 2 * x.a.shape[1], 2 * x.a.shape[2]
             ci, dev = x.a.shape[3] + (0 if x.skip is None else x.skip.shape[3]), x.a.device
@@ -480,13 +524,26 @@ class Plan:
             y = torch.empty((n, d.ho, d.wo, conv.cout_p), device=dev, dtype=self.adt)
             sums = self._next_stats(ceil4(bn.c))
             wf = self.wfrag(conv, d, up_ca=x.a.shape[3] if up else 0)
-            if wf is not None:
+            if lazy_in:
+                assert wf is not None, "a LazyAct input needs the bf16-first kernels (decided by the producer)"
+                K.conv2d_fwd_frag(d, x.y, None, wf, bias, y, stats=sums[0], in_scale=x.scale, in_shift=x.shift, in_act=x.act,
+                                  in_slope=x.slope, st=self.st)
+            elif wf is not None:
                 K.conv2d_fwd_frag(d, x.a if up else x, x.skip if up else None, wf, bias, y, stats=sums[0], up=up, st=self.st)
             elif up:
                 K.conv2d_fwd_upcat(d, x.a, x.skip, self.w(conv), bias, y, ACT_NONE, 0.0, sums[0], self.st)
             else:
                 K.conv2d_fwd_bnstats(d, x, self.w(conv), bias, y, sums[0], self.st)
-            z, ms = self.bn(bn, y, act, slope, residual, sums)
+            c = ceil4(bn.c)
+            if y.shape[-1] == c and self._lazy_ok(c, n, d.ho, d.wo, lazy_for, act, residual):
+                so, o = sums
+                mean, rstd = self.saved_stats[o:o + c], self.saved_stats[o + c:o + 2 * c]
+                scale, shift = self.coefs[o:o + c], self.coefs[o + c:o + 2 * c]
+                K.bn_finalize(so, self.pvec(bn, "weight"), self.pvec(bn, "bias"), n * d.ho * d.wo, bn.eps, bn.momentum,
+                              bn.running_mean, bn.running_var, mean, rstd, scale, shift, self.st)
+                z, ms = LazyAct(y, scale, shift, act, slope), (mean, rstd)
+            else:
+                z, ms = self.bn(bn, y, act, slope, residual, sums)
         else:
             # eval mode: ONE kernel per conv+BN(+add)+activation block
             d = K.conv_desc(n, h, w, ci, conv.cout_p, conv.k, conv.stride, conv.pad)
@@ -576,7 +633,10 @@ class Plan:
             else:
                 K.conv2d_dgrad_split(d, dy, self.packed_wt(conv), d_up, d_skip, self.st)
             return
-        K.conv2d_wgrad(d, x, dy, self.gw(conv), True, wst)
+        if isinstance(x, LazyAct):
+            K.conv2d_wgrad_bnin(d, x.y, x.scale, x.shift, x.act, x.slope, dy, self.gw(conv), True, wst)
+        else:
+            K.conv2d_wgrad(d, x, dy, self.gw(conv), True, wst)
         if conv.bias is not None:
             if dbias is not None:
                 K.axpy(self.gvec(conv, "bias"), dbias, 1.0, wst)
@@ -586,6 +646,9 @@ class Plan:
             wfd = self.wfrag(conv, d, dgrad=True)
             fuse = (prev is not None and FUSE_BN_REDUCE and not dx_acc and not prev[9] and prev[7] != ACT_NONE
                     and prev[4].shape == dx.shape and (wfd is not None or K.conv2d_dgrad_bnreduce_ok(d, dy.dtype)))
+            if prev is not None and isinstance(prev[5], LazyAct) and not fuse:
+                raise RuntimeError("internal: the producer's activation was not written, its consumer's data gradient must make "
+                                   "the BatchNorm-backward sums")
             if fuse:
                 p_bn, p_y, (p_mean, p_rstd) = prev[1], prev[4], prev[6]
                 bs = self._next_bstats(p_y.shape[-1] if self.bf16 else ceil4(p_bn.c))
@@ -608,6 +671,11 @@ class Plan:
         mean, rstd = ms
         gamma = self.pvec(bn, "weight")
         beta = None
+        if isinstance(z, LazyAct):
+            bs = self._bnb.pop(id(y))        # made by the consumer's data gradient (conv_bwd refuses to run without them)
+            K.bn_bwd_apply_recompute(dz, y, z.scale, z.shift, mean, rstd, gamma, bs, dz, self.gvec(bn, "weight"),
+                                     self.gvec(bn, "bias"), act, slope, self.st)
+            return dz
         if not has_res and not self.bf16 and act != ACT_NONE:
             z, beta = None, self.pvec(bn, "bias")
         bs = self._bnb.pop(id(y), None)           # the consumer's data gradient already made the two reductions

@@ -151,6 +151,40 @@ def upcat_fusable(ca, cb, co, dtype):
     return ca % 32 == 0 and cb % 32 == 0 and (cb == 0 or ca % 64 == 0)
 
 
+def bn_finalize(sums, gamma, beta, pixels, eps, momentum, running_mean, running_var, save_mean, save_rstd, scale, shift, st=None):
+    """Statistics -> saved mean / rstd, running statistics and the per-channel scale / shift a consumer applies while staging."""
+    c = scale.numel()
+    _channel_vecs("bn_finalize", c, gamma=gamma, beta=beta, running_mean=running_mean, running_var=running_var, save_mean=save_mean,
+                  save_rstd=save_rstd, scale=scale, shift=shift)
+    _channel_vecs("bn_finalize", c, f64=2 * c * bn_replicas(), sums=sums)
+    check(_lib.load().udaseg_bn_finalize(sums.data_ptr(), gamma.data_ptr(), beta.data_ptr(), pixels, c, eps, momentum,
+                                          _ptr(running_mean), _ptr(running_var), _ptr(save_mean), _ptr(save_rstd), scale.data_ptr(),
+                                          shift.data_ptr(), st if st is not None else stream()), "bn_finalize")
+
+
+def bn_bwd_apply_recompute(dz, y, fwd_scale, fwd_shift, save_mean, save_rstd, gamma, bsums, dy, dgamma, dbeta, act, slope, st=None):
+    """BatchNorm backward of a layer whose activation was never written: the mask is re-evaluated from y, fwd_scale, fwd_shift."""
+    c = y.shape[-1]
+    _same_layout("bn_bwd_apply_recompute", y, dz=dz, dy=dy)
+    _channel_vecs("bn_bwd_apply_recompute", c, fwd_scale=fwd_scale, fwd_shift=fwd_shift, save_mean=save_mean, save_rstd=save_rstd,
+                  gamma=gamma, dgamma=dgamma, dbeta=dbeta)
+    _channel_vecs("bn_bwd_apply_recompute", c, f64=2 * c * bn_replicas(), bsums=bsums)
+    if y.dtype != torch.bfloat16:
+        raise ValueError("bn_bwd_apply_recompute: bf16 storage only")
+    check(_lib.load().udaseg_bn_bwd_apply_recompute_bf16(dz.data_ptr(), y.data_ptr(), fwd_scale.data_ptr(), fwd_shift.data_ptr(),
+                                                          save_mean.data_ptr(), save_rstd.data_ptr(), gamma.data_ptr(),
+                                                          bsums.data_ptr(), dy.data_ptr(), _ptr(dgamma), _ptr(dbeta), y.numel() // c,
+                                                          c, act, slope, st if st is not None else stream()),
+          "bn_bwd_apply_recompute_bf16")
+
+
+def conv2d_wgrad_bnin(d, y_prev, in_scale, in_shift, in_act, in_slope, dy, dw, accumulate=False, st=None):
+    """Weight gradient whose gathered operand is act(fma(y_prev, in_scale, in_shift)) (never written), bf16."""
+    check(_lib.load().udaseg_conv2d_wgrad_bnin_bf16(_byref(d), y_prev.data_ptr(), in_scale.data_ptr(), in_shift.data_ptr(), in_act,
+                                                     in_slope, dy.data_ptr(), dw.data_ptr(), int(accumulate),
+                                                     st if st is not None else stream()), "conv2d_wgrad_bnin_bf16")
+
+
 def frag_elems(n_out, k_in, ks):
     """bf16 elements of the MFMA-fragment packing of a convolution with n_out produced / k_in gathered channels, ks x ks window."""
     return int(_lib.load().udaseg_frag_elems(n_out, k_in, ks))

@@ -46,7 +46,7 @@ class BasicBlock(nn.Module):
         self.downsample = nn.Sequential(ConvP(inplanes, planes, 1, stride, 0), BNP(planes)) if downsample else None
 
     def fwd(self, P, x):
-        a1, r1 = P.conv_bn_act(self.conv1, self.bn1, x, *RELU)
+        a1, r1 = P.conv_bn_act(self.conv1, self.bn1, x, *RELU, lazy_for=self.conv2)      # a1 feeds conv2 only
         if self.downsample is not None:
             idt, rd = P.conv_bn_act(self.downsample[0], self.downsample[1], x, ACT_NONE, 0.0)
         else:
@@ -60,12 +60,12 @@ class BasicBlock(nn.Module):
         dx, dx_acc = G.slot(x)
         if rd is None:
             # identity branch: the masked gradient goes straight into dx; conv1's dgrad accumulates on top
-            d_a1 = torch.empty_like(a1)
+            d_a1 = P.like(a1)
             P.conv_bn_act_bwd(r2, d_out, dx=d_a1, dres=dx, dres_acc=dx_acc, prev=r1)     # a1 feeds conv2 only
             P.conv_bn_act_bwd(r1, d_a1, dx=dx, dx_acc=True)
         else:
             d_idt = torch.empty_like(idt)
-            d_a1 = torch.empty_like(a1)
+            d_a1 = P.like(a1)
             P.conv_bn_act_bwd(r2, d_out, dx=d_a1, dres=d_idt, prev=r1)
             P.conv_bn_act_bwd(rd, d_idt, dx=dx, dx_acc=dx_acc)
             P.conv_bn_act_bwd(r1, d_a1, dx=dx, dx_acc=True)
@@ -85,8 +85,8 @@ class Bottleneck(nn.Module):
         self.downsample = nn.Sequential(ConvP(inplanes, planes * 4, 1, stride, 0), BNP(planes * 4)) if downsample else None
 
     def fwd(self, P, x):
-        a1, r1 = P.conv_bn_act(self.conv1, self.bn1, x, *RELU)
-        a2, r2 = P.conv_bn_act(self.conv2, self.bn2, a1, *RELU)
+        a1, r1 = P.conv_bn_act(self.conv1, self.bn1, x, *RELU, lazy_for=self.conv2)      # a1 feeds conv2 only
+        a2, r2 = P.conv_bn_act(self.conv2, self.bn2, a1, *RELU, lazy_for=self.conv3)     # a2 feeds conv3 only
         if self.downsample is not None:
             idt, rd = P.conv_bn_act(self.downsample[0], self.downsample[1], x, ACT_NONE, 0.0)
         else:
@@ -98,8 +98,8 @@ class Bottleneck(nn.Module):
         x, a1, a2, idt, r1, r2, r3, rd = rec
         d_out = G.pop(out)
         dx, dx_acc = G.slot(x)
-        d_a2 = torch.empty_like(a2)
-        d_a1 = torch.empty_like(a1)
+        d_a2 = P.like(a2)
+        d_a1 = P.like(a1)
         if rd is None:
             P.conv_bn_act_bwd(r3, d_out, dx=d_a2, dres=dx, dres_acc=dx_acc, prev=r2)     # a2 feeds conv3 only
         else:
@@ -151,7 +151,7 @@ class DecoderBlock(nn.Module):
             cat = UpCat(x, skip)              # conv1 gathers straight from x (at (iy >> 1, ix >> 1)) and skip
         else:
             cat = K.upsample2x_concat_fwd(x, skip, P.st)
-        a1, r1 = P.conv_bn_act(self.conv1[0], self.conv1[1], cat, *RELU)
+        a1, r1 = P.conv_bn_act(self.conv1[0], self.conv1[1], cat, *RELU, lazy_for=self.conv2[0])   # a1 feeds conv2 only
         out, r2 = P.conv_bn_act(self.conv2[0], self.conv2[1], a1, *RELU)
         return out, (x, skip, cat, a1, r1, r2)
 
@@ -163,7 +163,7 @@ class DecoderBlock(nn.Module):
     def bwd(self, P, G, rec, out):
         x, skip, cat, a1, r1, r2 = rec
         d_out = G.pop(out)
-        d_a1 = torch.empty_like(a1)
+        d_a1 = P.like(a1)
         P.conv_bn_act_bwd(r2, d_out, dx=d_a1, prev=r1)             # a1 feeds conv2 only
         dx, dx_acc = G.slot(x)
         if skip is not None:
