@@ -55,13 +55,16 @@ def synthetic(n, h, w, classes, seed, device):
     return x.to(device), y.to(device)
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, prefer=None):
     """(HBM-side bytes per launch of `kernel`, source file) from the newest committed PMC reduction (rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE in separate passes, corrected as MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py).  The PMC
     passes cannot run inside this script (counter collection needs its own rocprofv3 process): the value is a committed
     measurement of the same kernel symbol, (None, None) when no committed file knows the symbol."""
     import glob
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")), reverse=True):
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")), reverse=True)
+    if prefer:      # the same symbol runs other shapes in another configuration: take the file collected on THIS workload first
+        files.sort(key=lambda f: prefer not in os.path.basename(f))
+    for f in files:
         try:
             k = json.load(open(f))["kernels"].get(kernel)
         except Exception:
@@ -226,7 +229,7 @@ def timed_region(step, steps, warmup, world, dev, rehearse):
     return dt, [a.elapsed_time(b) for a, b in evs], loss
 
 
-def roofline_leg(step, model, trainer, dtype, psteps=3, layer_table=False):
+def roofline_leg(step, model, trainer, dtype, psteps=3, layer_table=False, pmc_tag=None):
     """Separate leg: HIP events around every conv-kernel launch on the launch stream (C-ABI udaseg_prof_*), single stream --
     with the weight gradients on their side stream concurrent kernels stretch each other's durations and a per-kernel rate
     would under-state the kernel (the timed region keeps the overlap).  No collective may be issued here."""
@@ -268,14 +271,56 @@ def roofline_leg(step, model, trainer, dtype, psteps=3, layer_table=False):
         for (kind, d), (ms, fl, cnt) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
             print(f"{('fwd', 'dgrad', 'wgrad')[kind]:5s} {d[0]:2d} {d[1]:3d} {d[2]:3d} {d[3]:4d} {d[6]:4d} {d[7]} {d[9]} | "
                   f"{cnt / psteps:5.1f} {ms / cnt:9.4f} {fl / cnt / 1e9:8.2f} {fl / ms / 1e9:8.1f}", file=sys.stderr)
-    kern = [k for k in K.prof_kernels() if k[3] > 0]
+    allk = [k for k in K.prof_kernels() if k[3] > 0]
     K.prof_reset()
+    kern = [k for k in allk if k[0].startswith("conv")]            # MFMA kernels: k[2] = FLOPs
+    hbm_k = [k for k in allk if not k[0].startswith("conv")]       # bandwidth kernels (BatchNorm passes): k[2] = algorithmic bytes
+    # single-stream step time without any event in the stream (for the "other" share of the split below)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    _engine.SIDE_STREAM_WGRAD = False
+    e0.record()
+    for _ in range(psteps):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    _engine.SIDE_STREAM_WGRAD = was_side
+    serial_ms = e0.elapsed_time(e1) / psteps
+    # BASELINE cfg 5 asks for the split "HBM-bound vs MFMA-bound": every conv call is classed by its arithmetic intensity
+    # (FLOPs / algorithmic bytes) against the machine balance peak / 6.3 TB/s (measured copy rate, MI355X_MICROARCH.md)
+    balance = (BF16_MFMA_PEAK_TFLOPS if dtype == "bf16" else FP32_MFMA_PEAK_TFLOPS) * 1e12 / 6.3e12
+    split = {"mfma": [0.0, 0.0, 0.0, 0], "hbm": [0.0, 0.0, 0.0, 0]}
+    for (kind, d), (ms, fl, cnt) in agg.items():
+        n_, hi_, wi_, ci_, ho_, wo_, co_, kh_, kw_ = d[:9]
+        by = cnt * (n_ * hi_ * wi_ * ci_ * es + n_ * ho_ * wo_ * co_ * es + co_ * kh_ * kw_ * ci_ * (4 if kind == 2 else es))
+        cls = split["mfma" if fl / max(by, 1) >= balance else "hbm"]
+        cls[0] += ms
+        cls[1] += fl
+        cls[2] += by
+        cls[3] += cnt
+    api_ms = max(split["mfma"][0] + split["hbm"][0], 1e-9)
+    kern_ms = sum(k[1] for k in kern)                               # kernel-level events: free of the API-level event overhead
+    bn_ms, bn_bytes = sum(k[1] for k in hbm_k), sum(k[2] for k in hbm_k)
+    time_split = {
+        "serial_step_ms": round(serial_ms, 3),
+        "note": "single-stream leg; conv calls classed by FLOPs / algorithmic bytes against the machine balance "
+                f"({balance:.0f} FLOP/B = dense MFMA peak / 6.3 TB/s); class times are the API-level event times scaled to the "
+                "kernel-level conv total (the API-level pair carries ~8 us of event overhead per call)",
+        "conv_mfma_bound": {"ms": round(split["mfma"][0] / api_ms * kern_ms / psteps, 3), "calls": split["mfma"][3] // psteps,
+                            "tflops": round(split["mfma"][1] / max(split["mfma"][0] / api_ms * kern_ms, 1e-9) / 1e9, 1)},
+        "conv_hbm_bound": {"ms": round(split["hbm"][0] / api_ms * kern_ms / psteps, 3), "calls": split["hbm"][3] // psteps,
+                           "TB_per_s": round(split["hbm"][2] / max(split["hbm"][0] / api_ms * kern_ms, 1e-9) / 1e9, 3),
+                           "tflops": round(split["hbm"][1] / max(split["hbm"][0] / api_ms * kern_ms, 1e-9) / 1e9, 1)},
+        "batchnorm_passes": {"ms": round(bn_ms / psteps, 3), "TB_per_s": round(bn_bytes / max(bn_ms, 1e-9) / 1e9, 3),
+                             "by_kernel": {k[0]: {"ms": round(k[1] / psteps, 3), "TB_per_s": round(k[2] / max(k[1], 1e-9) / 1e9, 3),
+                                                  "launches": k[3] // psteps} for k in hbm_k}},
+        "other_ms": round(serial_ms - (kern_ms + bn_ms) / psteps, 3)}
     kern.sort(key=lambda k: -k[1])
     dom = kern[0]                                   # the kernel symbol with the most device time
     achieved = dom[2] / (dom[1] * 1e-3) / 1e12
     conv_ms = sum(k[1] for k in kern) / psteps
     peak = BF16_MFMA_PEAK_TFLOPS if dtype == "bf16" else FP32_MFMA_PEAK_TFLOPS
-    traffic, traffic_src = pmc_traffic(dom[0])
+    traffic, traffic_src = pmc_traffic(dom[0], pmc_tag)
     return {"bound": "mfma", "kernel": dom[0], "achieved": round(achieved, 2), "peak": peak,
             "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
             "traffic_source": (traffic_src + " (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this symbol; "
@@ -287,6 +332,7 @@ def roofline_leg(step, model, trainer, dtype, psteps=3, layer_table=False):
                          "achieved_TB_per_s": round(conv_bytes / (conv_ms_api * 1e-3) / 1e12, 3) if conv_ms_api else None,
                          "frac_of_8TBps": round(conv_bytes / (conv_ms_api * 1e-3) / 8e12, 4) if conv_ms_api else None,
                          "note": "all conv launches: (gathered tensor + output + weights, each counted once) / summed launch time"},
+            "time_split": time_split,
             "all_conv_kernels": {"ms_per_step": round(conv_ms, 3),
                                  "achieved": round(sum(k[2] for k in kern) / psteps / (conv_ms * 1e-3) / 1e12, 2),
                                  "flops_note": "per-kernel GEMM FLOPs count PHYSICAL channels (image 3->4, logits 23->24): the "
@@ -301,7 +347,7 @@ def also_leg(name, workload, encoder, dtype, batch, size, classes, dev, steps=10
     """A short informational leg of another BASELINE config in the same process (N=1 only)."""
     step, model, trainer = build_leg(workload, encoder, dtype, batch, size, classes, dev, 0, 1, False)
     dt, ev_ms, loss = timed_region(step, steps, warmup, 1, dev, False)
-    roof = roofline_leg(step, model, trainer, dtype, psteps=2)
+    roof = roofline_leg(step, model, trainer, dtype, psteps=2, pmc_tag="cfg3" if workload == "adversarial" else "cfg5")
     value = batch * steps / dt
     gf = CONV_GFLOP_PER_IMAGE.get((workload, encoder, size))
     peak = BF16_MFMA_PEAK_TFLOPS if dtype == "bf16" else FP32_MFMA_PEAK_TFLOPS
@@ -310,8 +356,10 @@ def also_leg(name, workload, encoder, dtype, batch, size, classes, dev, steps=10
            "ms_per_step": round(1e3 * dt / steps, 3), "step_ms_median": round(percentile(ev_ms, 0.5), 3),
            "final_loss": round(float(loss.item()), 5),
            "conv_mfma_util": round(value * gf / 1e3 / peak, 4) if gf else None,
-           "roofline": {k: roof[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launches_per_step",
-                                             "avg_launch_us", "ms_per_step", "hbm_view")},
+           "roofline": {k: roof[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
+                                             "launches_per_step", "avg_launch_us", "ms_per_step", "hbm_view")},
+           "time_split": roof["time_split"],
+           "conv_kernels": roof["all_conv_kernels"]["by_kernel"],
            "all_conv_kernels_ms_per_step": roof["all_conv_kernels"]["ms_per_step"]}
     if cpu:
         out["cpu_baseline"] = cpu_baseline(encoder, classes, size, workload=workload, batch=batch, warmups=1, timed=3,
@@ -400,7 +448,8 @@ def main():
     roofline = None
     if not args.no_roofline and rank == 0:
         # only rank 0 runs this leg (the other ranks are already at the barrier below)
-        roofline = roofline_leg(step, model, trainer, args.dtype, layer_table=args.layer_table)
+        tag = "cfg3" if args.workload == "adversarial" else ("cfg5" if args.encoder == "resnet50" else "fp32")
+        roofline = roofline_leg(step, model, trainer, args.dtype, layer_table=args.layer_table, pmc_tag=tag)
     if world > 1:
         dist.barrier()
 

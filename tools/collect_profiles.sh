@@ -37,6 +37,23 @@ UDASEG_SERIAL=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${T
         --no-cpu-baseline --no-roofline --no-also --no-sustain --encoder resnet50 --size 768 --dtype bf16 > $OUT/${TAG}_prof_bf16_cfg5.log 2>&1 || exit 1
 cp $(find $OUT/${TAG}_prof_bf16_cfg5 -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats_bf16_cfg5.csv
 echo "bf16 stats done"
+# bf16 legs: HBM-side traffic and matrix-pipe busy per kernel symbol (separate PMC passes, program directly after --)
+for CFG in cfg3 cfg5; do
+  if [ $CFG = cfg3 ]; then WL="--workload adversarial --dtype bf16"; TXT="r18-Unet + discriminator adversarial iteration 8+8x512x512 bf16 (BASELINE cfg 3)";
+  else WL="--encoder resnet50 --size 768 --dtype bf16"; TXT="r50-Unet 8x3x768x768 bf16 train step (BASELINE cfg 5 per-GPU work)"; fi
+  B16="python3 $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-also --no-sustain $WL"
+  UDASEG_SERIAL=1 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pf_$CFG -- $B16 > $OUT/${TAG}_pf_$CFG.log 2>&1 || exit 1
+  UDASEG_SERIAL=1 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pw_$CFG -- $B16 > $OUT/${TAG}_pw_$CFG.log 2>&1 || exit 1
+  python3 $ROOT/tools/pmc_traffic.py $(find $OUT/${TAG}_pf_$CFG -name "*counter_collection.csv" | head -1) \
+          $(find $OUT/${TAG}_pw_$CFG -name "*counter_collection.csv" | head -1) $OUT/${TAG}_bf16_${CFG}_pmc_traffic.json "$TXT" > $OUT/${TAG}_bf16_${CFG}_pmc_traffic.txt || exit 1
+  UDASEG_SERIAL=1 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA --kernel-trace --output-format csv \
+          -d $OUT/${TAG}_pm_$CFG -- $B16 > $OUT/${TAG}_pm_$CFG.log 2>&1 || exit 1
+  python3 $ROOT/tools/pmc_mfma.py $(find $OUT/${TAG}_pm_$CFG -name "*counter_collection.csv" | head -1) $OUT/${TAG}_bf16_${CFG}_pmc_mfma_util.json || exit 1
+  UDASEG_SERIAL=1 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $OUT/${TAG}_pl2_$CFG -- $B16 > $OUT/${TAG}_pl2_$CFG.log 2>&1
+  python3 $ROOT/tools/pmc_l2.py $(find $OUT/${TAG}_pl2_$CFG -name "*counter_collection.csv" | head -1) $OUT/${TAG}_bf16_${CFG}_pmc_l2.json
+  rm -rf $OUT/${TAG}_pf_$CFG $OUT/${TAG}_pw_$CFG $OUT/${TAG}_pm_$CFG $OUT/${TAG}_pl2_$CFG
+  echo "bf16 pmc $CFG done"
+done
 rm -rf $OUT/${TAG}_prof_bf16_cfg3 $OUT/${TAG}_prof_bf16_cfg5
 rm -rf $OUT/${TAG}_prof_serial $OUT/${TAG}_prof_ovl $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write $OUT/${TAG}_pmc_mfma
 ls -la $OUT/${TAG}_*

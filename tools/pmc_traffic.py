@@ -1,7 +1,7 @@
 """Reduce two rocprofv3 PMC passes (--pmc FETCH_SIZE, --pmc WRITE_SIZE; separate runs, as MI355X_MICROARCH.md prescribes)
 to HBM bytes per launch for every kernel symbol.
 
-    python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json>
+    python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> [workload text]
 
 Corrections (guide, section HBM): counter values are KiB; on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a wide
 (16 B/lane) coalesced read stream, so the read side is doubled; WRITE_SIZE is exact for 16-B-per-lane stores and float
@@ -41,7 +41,8 @@ def main():
         fetch_kib, write_kib = f_tot.get(k, 0.0) / nf, w_tot.get(k, 0.0) / nw
         out[k] = {"launches": f_cnt.get(k, 0), "fetch_kib_raw": round(fetch_kib, 1), "write_kib": round(write_kib, 1),
                   "hbm_bytes_per_launch": int((2 * fetch_kib + write_kib) * 1024)}
-    json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), r18-Unet 8x3x512x512 fp32 train step, "
+    what = sys.argv[4] if len(sys.argv) > 4 else "r18-Unet 8x3x512x512 fp32 train step"
+    json.dump({"note": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), {what}, "
                        "per-launch averages; read side x2 (gfx950 FETCH_SIZE under-count), KiB -> bytes",
                "kernels": out}, open(sys.argv[3], "w"), indent=1)
     for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:12]:

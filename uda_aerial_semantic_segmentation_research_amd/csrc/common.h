@@ -174,6 +174,19 @@ constexpr int PROF_NKERNELS = 24;
 int kprof_id(const char* rocprof_symbol);   // id of a kernel symbol outside the fixed table (registered on first use)
 hipEvent_t kprof_begin(hipStream_t s);
 void kprof_end(int kid, hipEvent_t a, hipStream_t s, double flops);
+// RAII form for the bandwidth-bound kernels: `work` carries their ALGORITHMIC BYTES (bench.py reports TB/s for symbols that do
+// not start with "conv").  Costs one static-int test per call when profiling is off.
+struct KTimer {
+  int* kid;
+  hipStream_t s;
+  hipEvent_t ev;
+  double work;
+  KTimer(int* k, const char* rocprof_symbol, hipStream_t st, double w) : kid(k), s(st), work(w) {
+    if (*kid < 0) *kid = kprof_id(rocprof_symbol);
+    ev = kprof_begin(s);
+  }
+  ~KTimer() { kprof_end(*kid, ev, s, work); }
+};
 void prof_begin(int family, hipStream_t s);
 void prof_suspend(int on);
 void prof_end(int family, hipStream_t s, double flops, int kind, const udaseg_conv_desc* d);

@@ -575,6 +575,8 @@ extern "C" int udaseg_bn_apply_bf16(const void* y, const double* sums, const flo
   UDASEG_CHECK_ARG(y && sums && gamma && beta && z, "bn_apply_bf16: NULL pointer");
   const int64_t n8 = pixels * (c / 8);
   const StreamShape s = stream_shape(n8, c / 8);
+  static int kid_bn_apply_bf16_kernel = -1;
+  KTimer kt_bn_apply_bf16_kernel(&kid_bn_apply_bf16_kernel, "bn_apply_bf16_kernel", as_stream(stream), (double)pixels * c * 2.0 * (residual ? 3.0 : 2.0));
   hipLaunchKernelGGL(bn_apply_bf16_kernel, dim3(s.grid), dim3(s.bs), (size_t)2 * c * sizeof(float), as_stream(stream),
                      (const f32x4*)y, sums, gamma, beta, (const f32x4*)residual, (f32x4*)z, n8, s.c4, pixels, eps, momentum,
                      running_mean, running_var, save_mean, save_rstd, act, slope);
@@ -590,6 +592,8 @@ extern "C" int udaseg_bn_bwd_reduce_bf16(const void* dz, const void* z, const vo
   UDASEG_CHECK_ARG(dz && y && save_mean && save_rstd && bsums && (act == UDASEG_ACT_NONE || z), "bn_bwd_reduce_bf16: NULL pointer");
   const int64_t n8 = pixels * (c / 8);
   const StreamShape s = stream_shape(n8, c / 8, REDUCE_MAX_BLOCKS);
+  static int kid_bn_bwd_reduce_bf16_kernel = -1;
+  KTimer kt_bn_bwd_reduce_bf16_kernel(&kid_bn_bwd_reduce_bf16_kernel, "bn_bwd_reduce_bf16_kernel", as_stream(stream), (double)pixels * c * 2.0 * (act != UDASEG_ACT_NONE ? 3.0 : 2.0));
   hipLaunchKernelGGL(bn_bwd_reduce_bf16_kernel, dim3(s.grid), dim3(s.bs), 0, as_stream(stream), (const f32x4*)dz,
                      (const f32x4*)z, (const f32x4*)y, save_mean, save_rstd, n8, s.c4, bsums, act, slope);
   UDASEG_LAUNCH_CHECK("bn_bwd_reduce_bf16 launch");
@@ -607,6 +611,8 @@ extern "C" int udaseg_bn_bwd_apply_bf16(const void* dz, const void* z, const voi
   UDASEG_CHECK_ARG((size_t)5 * c * sizeof(float) <= 65536, "bn_bwd_apply_bf16: too many channels");
   const int64_t n8 = pixels * (c / 8);
   const StreamShape s = stream_shape(n8, c / 8);
+  static int kid_bwa = -1;
+  KTimer kt_bwa(&kid_bwa, "bn_bwd_apply_bf16_kernel", as_stream(stream), (double)pixels * c * 2.0 * ((act != UDASEG_ACT_NONE ? 4.0 : 3.0) + (dres ? 1.0 : 0.0)));
   hipLaunchKernelGGL(bn_bwd_apply_bf16_kernel, dim3(s.grid), dim3(s.bs), (size_t)5 * c * sizeof(float), as_stream(stream),
                      (const f32x4*)dz, (const f32x4*)z, (const f32x4*)y, save_mean, save_rstd, gamma, bsums, (f32x4*)dy,
                      (f32x4*)dres, dgamma, dbeta, n8, s.c4, pixels, act, slope, accumulate_dy, accumulate_dres, accumulate_param,
@@ -626,6 +632,8 @@ extern "C" int udaseg_bn_bwd_apply_recompute_bf16(const void* dz, const void* y,
   UDASEG_CHECK_ARG((size_t)7 * c * sizeof(float) <= 65536, "bn_bwd_apply_recompute_bf16: too many channels");
   const int64_t n8 = pixels * (c / 8);
   const StreamShape s = stream_shape(n8, c / 8);
+  static int kid_bwr = -1;
+  KTimer kt_bwr(&kid_bwr, "bn_bwd_apply_bf16_kernel", as_stream(stream), (double)pixels * c * 2.0 * 3.0);
   hipLaunchKernelGGL(bn_bwd_apply_bf16_kernel, dim3(s.grid), dim3(s.bs), (size_t)7 * c * sizeof(float), as_stream(stream),
                      (const f32x4*)dz, (const f32x4*)nullptr, (const f32x4*)y, save_mean, save_rstd, gamma, bsums, (f32x4*)dy,
                      (f32x4*)nullptr, dgamma, dbeta, n8, s.c4, pixels, act, slope, 0, 0, 0, fwd_scale, fwd_shift);
