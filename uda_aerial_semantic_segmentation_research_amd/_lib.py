@@ -112,6 +112,7 @@ SIGNATURES = {
     "udaseg_bn_bwd_apply_recompute_bf16": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _P]),
     "udaseg_conv2d_wgrad_bnin_bf16": (_I, [_D, _P, _P, _P, _I, _F, _P, _P, _I, _P]),
     "udaseg_frag_elems": (_L, [_I, _I, _I]),
+    "udaseg_set_stats_scratch": (_I, [_P, C.c_size_t]),
     "udaseg_pack_frag_batched_bf16": (_I, [_P, _P, _P, _P, _I, _P]),
     "udaseg_conv_frag_ok": (_I, [_D, _I, _I]),
     "udaseg_conv_frag_preferred": (_I, [_D, _I, _I]),

@@ -43,6 +43,9 @@ struct HaloArgs {
   int out_f32, act;
   float slope;
   double* stats;        // [R][2][co] f64: BatchNorm statistics of the output, or the bnb_* sums
+  float* sscr;          // launches of > 1024 blocks: fp32 partial sums [HALO_SCR_REPLICAS][2][co] (zeroed scratch), folded into `stats`
+                        // by halo_stats_fold_kernel -- 8192 blocks on 16 replicas put 512 same-address f64 atomics (~0.1 us each,
+                        // serialised at the memory side) on every accumulator of a 16-channel layer: the atomics WERE the launch
   // BatchNorm-backward reductions of the layer behind a data gradient (see IgemmArgs::bnb_* in conv_igemm.hip)
   const void* bnb_y;
   const float* bnb_mean;
@@ -65,6 +68,7 @@ extern unsigned long long* g_timeline;
 extern int g_timeline_blocks;
 
 constexpr int HALO_STATS_REPLICAS = 16;   // == udaseg_bn_replicas()
+constexpr int HALO_SCR_REPLICAS = 256;
 
 template <int KS, int CK, int WM, int WN, int RPW, int TW>
 struct HaloCfg {
@@ -110,6 +114,24 @@ __device__ __forceinline__ float halfwave_sum(float x) {
   x += dpp_mov<0x121, 0xf>(0.f, x);   // row_ror:1   -> every lane holds its row's total
   x += dpp_mov<0x142, 0xa>(0.f, x);   // row_bcast:15 into rows 1 and 3 (rows 0 and 2 add 0)
   return x;
+}
+// The same reduction over N values at once with the add and the lane movement in ONE instruction (v_add_f32_dpp; hipcc emits
+// v_mov_b32_dpp + v_add_f32 for the form above).  Step-major order: two dependent DPP operations on a register are N
+// instructions apart, which covers the two wait states a DPP read needs behind a VALU write of its source (the compiler
+// does not see into the asm).
+template <int N>
+__device__ __forceinline__ void halfwave_sum_n(float (&x)[N]) {
+  static_assert(N >= 4, "spacing of dependent DPP operations");
+#pragma unroll
+  for (int v = 0; v < N; ++v) asm volatile("v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf" : "+v"(x[v]));
+#pragma unroll
+  for (int v = 0; v < N; ++v) asm volatile("v_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf" : "+v"(x[v]));
+#pragma unroll
+  for (int v = 0; v < N; ++v) asm volatile("v_add_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf" : "+v"(x[v]));
+#pragma unroll
+  for (int v = 0; v < N; ++v) asm volatile("v_add_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf" : "+v"(x[v]));
+#pragma unroll
+  for (int v = 0; v < N; ++v) asm volatile("v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(x[v]));
 }
 
 template <int KS, int CK, int WM, int WN, int RPW, int TW>
@@ -350,8 +372,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_halo_bf16_kernel(const H
           sB[4 * g + e] = __builtin_fmaf(q, q, sB[4 * g + e]);
         }
       }
+      if (a.act != UDASEG_ACT_NONE) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) val[e] = act_apply(val[e], a.act, a.slope);
+        for (int e = 0; e < 4; ++e) val[e] = act_apply(val[e], a.act, a.slope);
+      }
       if (a.accumulate) {     // host-checked: bf16 output, no split
         const unsigned ooff = cv ? (pixoff * (unsigned)ldc + (unsigned)(c0 - csub)) * 2u : 0x80000000u;
         const u32x2 old = __builtin_amdgcn_raw_buffer_load_b64(rs_y, (int)ooff, 0, 0);
@@ -407,11 +431,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_halo_bf16_kernel(const H
     // per-channel totals: 32 lanes of a half-wave hold the same channels -> DPP reduction over lane bits 0..4, then the waves
     // that share a channel block fold through LDS (the halo is free: the K loop ended with a barrier), one f64 atomic per
     // (channel, statistic) per block into replica blockIdx % R
-#pragma unroll
-    for (int v = 0; v < 16; ++v) {
-      sA[v] = halfwave_sum(sA[v]);
-      sB[v] = halfwave_sum(sB[v]);
-    }
+    asm volatile("s_nop 1");      // the last VALU writes of sA / sB are at least two wait states behind
+    halfwave_sum_n(sA);
+    halfwave_sum_n(sB);
+    asm volatile("s_nop 1");      // ... and so are the ordinary reads of the DPP results
     float* red = reinterpret_cast<float*>(smem);   // [2][waves][32]
     if (lp == 31) {                                // lanes 31 and 63 hold the totals of their half-wave
 #pragma unroll
@@ -432,9 +455,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_halo_bf16_kernel(const H
           t1 += red[(m * WN + wc) * 32 + cl];
           t2 += red[C::NW * 32 + (m * WN + wc) * 32 + cl];
         }
-        double* rep = a.stats + (size_t)(blockIdx.x % HALO_STATS_REPLICAS) * 2 * a.co;
-        atomicAdd(rep + c, (double)t1);
-        atomicAdd(rep + a.co + c, (double)t2);
+        if (a.sscr != nullptr) {
+          float* rep = a.sscr + (size_t)(blockIdx.x % HALO_SCR_REPLICAS) * 2 * a.co;
+          atomicAdd(rep + c, t1);
+          atomicAdd(rep + a.co + c, t2);
+        } else {
+          double* rep = a.stats + (size_t)(blockIdx.x % HALO_STATS_REPLICAS) * 2 * a.co;
+          atomicAdd(rep + c, (double)t1);
+          atomicAdd(rep + a.co + c, (double)t2);
+        }
       }
     }
   }
@@ -480,6 +509,23 @@ __global__ void pack_frag_batched_bf16_kernel(const __bf16* __restrict__ w16, co
   }
 }
 
+// fp32 partial sums of a many-block launch -> the f64 accumulators (replica 0); leaves the scratch zeroed for the next launch
+__global__ void halo_stats_fold_kernel(float* __restrict__ sscr, int co, double* __restrict__ stats) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;      // index into [2][co]
+  if (i >= 2 * co) return;
+  float s = 0.f;
+#pragma unroll 8
+  for (int r = 0; r < HALO_SCR_REPLICAS; ++r) {
+    s += sscr[(size_t)r * 2 * co + i];
+    sscr[(size_t)r * 2 * co + i] = 0.f;
+  }
+  atomicAdd(stats + i, (double)s);
+}
+
+// one caller-owned, caller-zeroed fp32 scratch per device for those partial sums (udaseg_set_stats_scratch)
+static float* g_sscr[16] = {};
+static size_t g_sscr_bytes[16] = {};
+
 // ------------------------------------------------------------------------------------------------- host side
 template <int KS, int CK, int WM, int WN, int RPW, int TW>
 static int launch_halo_t(HaloArgs a, hipStream_t s, double flops) {
@@ -498,6 +544,13 @@ static int launch_halo_t(HaloArgs a, hipStream_t s, double flops) {
   const long long blocks = (long long)a.n * a.nty * a.ntx * a.ncb;
   if (blocks <= 0) return UDASEG_OK;
   a.timeline = (g_timeline && blocks <= g_timeline_blocks) ? g_timeline : nullptr;
+  a.sscr = nullptr;
+  if (a.stats != nullptr && blocks > 1024) {
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16 && g_sscr[dev] != nullptr &&
+        (size_t)HALO_SCR_REPLICAS * 2 * a.co * sizeof(float) <= g_sscr_bytes[dev])
+      a.sscr = g_sscr[dev];
+  }
   static int kid = -1;
   if (kid < 0) {
     char nm[96];
@@ -508,6 +561,10 @@ static int launch_halo_t(HaloArgs a, hipStream_t s, double flops) {
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::NT), C::LDS, s, a);
   kprof_end(kid, ev, s, flops);
   UDASEG_LAUNCH_CHECK("conv_halo_bf16 launch");
+  if (a.sscr != nullptr) {
+    hipLaunchKernelGGL(halo_stats_fold_kernel, dim3(cdiv(2 * a.co, 64)), dim3(64), 0, s, a.sscr, a.co, a.stats);
+    UDASEG_LAUNCH_CHECK("halo_stats_fold launch");
+  }
   return UDASEG_OK;
 }
 
@@ -589,6 +646,15 @@ int launch_halo(const udaseg_conv_desc* d, HaloArgs a, hipStream_t s, bool dgrad
 }  // namespace udaseg
 
 using namespace udaseg;
+
+extern "C" int udaseg_set_stats_scratch(void* ptr, size_t bytes) {
+  int dev = 0;
+  UDASEG_CHECK_ARG(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16, "set_stats_scratch: no current HIP device");
+  UDASEG_CHECK_ARG(ptr == nullptr || (reinterpret_cast<uintptr_t>(ptr) & 15) == 0, "set_stats_scratch: 16-byte alignment");
+  g_sscr[dev] = static_cast<float*>(ptr);
+  g_sscr_bytes[dev] = ptr ? bytes : 0;
+  return UDASEG_OK;
+}
 
 extern "C" int64_t udaseg_frag_elems(int n_out, int k_in, int ks) {
   if (n_out <= 0 || k_in <= 0 || ks <= 0) return 0;

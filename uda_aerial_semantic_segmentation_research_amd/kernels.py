@@ -24,9 +24,12 @@ def ensure_workspace(device, nbytes=16 << 20):
     key = str(device)
     if key not in _WORKSPACE:
         buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        with torch.cuda.device(device):          # the library binds the buffer to the CURRENT device
+        scr = torch.zeros(256 << 10, dtype=torch.uint8, device=device)     # zeroed once; the library keeps it zeroed
+        with torch.cuda.device(device):          # the library binds the buffers to the CURRENT device
             check(_lib.load().udaseg_set_workspace(buf.data_ptr(), nbytes), "set_workspace")
+            check(_lib.load().udaseg_set_stats_scratch(scr.data_ptr(), scr.numel()), "set_stats_scratch")
         _WORKSPACE[key] = buf
+        _WORKSPACE[key + "/stats"] = scr
     return _WORKSPACE[key]
 
 
