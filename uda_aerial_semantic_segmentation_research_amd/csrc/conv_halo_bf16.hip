@@ -257,8 +257,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_halo_bf16_kernel(const H
           const float sc0 = e < 2 ? s0[2 * e] : s1[2 * e - 4], sc1 = e < 2 ? s0[2 * e + 1] : s1[2 * e - 3];
           const float sh0 = e < 2 ? h0[2 * e] : h1[2 * e - 4], sh1 = e < 2 ? h0[2 * e + 1] : h1[2 * e - 3];
           float t0 = __builtin_fmaf(bf_lo(d[e]), sc0, sh0), t1 = __builtin_fmaf(bf_hi(d[e]), sc1, sh1);
-          t0 = act_apply(t0, a.in_act, a.in_slope);
-          t1 = act_apply(t1, a.in_act, a.in_slope);
+          if (a.in_act == UDASEG_ACT_LEAKY && a.in_slope == 0.f) {      // uniform: ReLU is one v_max
+            t0 = t0 > 0.f ? t0 : 0.f;
+            t1 = t1 > 0.f ? t1 : 0.f;
+          } else {
+            t0 = act_apply(t0, a.in_act, a.in_slope);
+            t1 = act_apply(t1, a.in_act, a.in_slope);
+          }
           d[e] = ok ? pack_bf16x2(t0, t1) : 0u;
         }
         stage[i] = d;
@@ -476,6 +481,273 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_halo_bf16_kernel(const H
   }
 }
 
+// ------------------------------------------------------------------------------------------------ streaming 1x1
+// 1x1 / stride 1 convolutions (r50's bottleneck projections, BASELINE cfg 5) are GEMMs over M = n*h*w contiguous pixel rows
+// with K = 64 .. 2048: at bf16 MFMA rates every one of them is HBM-bound (arithmetic intensity 50-200 FLOP/B against a machine
+// balance of ~400), and what the tile kernel above measured on them was latency, not bandwidth: one or two resident blocks per
+// CU, each loading, computing (0.7 us) and storing (6 us) strictly in turn -- 2.4 TB/s on the 64 -> 256 layer at 192^2.
+// This kernel is a PERSISTENT streamer: 8 waves per block, one block per CU, 256-pixel tiles of the flat pixel axis (no partial
+// tiles on 48- and 24-pixel-wide images), the next tile's rows requested before the current tile's epilogue so that loads,
+// MFMAs and the 16-byte stores of neighbouring tiles overlap; weights of a single-chunk layer (K <= 64) stay in LDS for the
+// block's whole life; the per-channel statistics of all of a block's tiles are summed in LDS and leave as one set of f64
+// atomics.  Same fragment packing, same accumulator layout and register-to-global epilogue as conv_halo_bf16_kernel.
+template <int CK, int WM, int WN>
+struct StreamCfg {
+  static constexpr int NT = 512, TP = 256;         // threads, pixels per tile
+  static constexpr int RPW = 8 / WM;               // 32-pixel row blocks per wave
+  static constexpr int OCT = CK / 8, STRIDE = CK * 2 + 16;
+  static constexpr int NPIECE = TP * OCT, NI = NPIECE / NT;
+  static constexpr int FPC = CK / 16, NW = 8;
+  static constexpr int NWI = (WN * FPC + NW - 1) / NW;
+  static constexpr int LDS_A = TP * STRIDE, LDS_W = WN * FPC * 1024, LDS_STATS = 2 * 32 * WN * 4;
+  static constexpr int LDS = LDS_A + LDS_W + LDS_STATS;
+  static_assert(WM * WN == 8 && NPIECE % NT == 0 && NI >= 1, "8 waves; whole staging passes");
+};
+
+template <int CK, int WM, int WN>
+__global__ __launch_bounds__(512, 2) void conv1x1_stream_bf16_kernel(const HaloArgs a) {
+  using C = StreamCfg<CK, WM, WN>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lp = lane & 31, lh = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  const int M = a.n * a.h * a.w;
+  const int ntiles = (M + C::TP - 1) / C::TP;
+  const int cb = (int)blockIdx.x % a.ncb, P = (int)gridDim.x / a.ncb, slot = (int)blockIdx.x / a.ncb;
+
+  // staging slots: piece = tid + i * 512 -> (tile pixel, octet); a tile's rows are one contiguous block of memory
+  const int oct = tid % C::OCT;
+  unsigned voffc[C::NI];
+#pragma unroll
+  for (int i = 0; i < C::NI; ++i) voffc[i] = (unsigned)((((tid + i * C::NT) / C::OCT) * a.ci + oct * 8) * 2);
+  __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wf), 0, (int)a.w_bytes, 0x00020000);
+
+  const int nblocks32 = (a.co + 31) >> 5;
+  int nb = cb * WN + wn;
+  const bool wave_live = nb < nblocks32;
+  if (!wave_live) nb = 0;
+  const int frag_per_nb = a.nk16;                  // 1x1: fragments of a 32-channel block = k16 steps
+  int wvoff[C::NWI];
+  const unsigned wlane16 = (unsigned)lane * 16u;
+#pragma unroll
+  for (int i = 0; i < C::NWI; ++i) {
+    const int q = wave + C::NW * i;
+    const int wq = q / C::FPC, k = q - wq * C::FPC;
+    const int nbq = cb * WN + wq;
+    wvoff[i] = (q < WN * C::FPC && nbq < nblocks32) ? (nbq * frag_per_nb + k) * 1024 : -1;
+  }
+  char* wlds = smem + C::LDS_A;
+  float* sred = reinterpret_cast<float*>(smem + C::LDS_A + C::LDS_W);
+  const int wrd = (wn * C::FPC) * 1024 + lane * 16;
+  const int pbase = ((wm * C::RPW * 32) + lp) * C::STRIDE + lh * 16;
+
+  const int nchunk = (a.ci + CK - 1) / CK;
+  u32x4 stage[C::NI], wstage[C::NWI];
+  unsigned okbits = 0;
+  auto load_chunk = [&](int tile, int c) {
+    const int cbeg = c * CK;
+    const unsigned kill = (cbeg + oct * 8 < a.ci) ? 0u : 0x80000000u;
+    const int soff = tile * C::TP * a.ci * 2 + cbeg * 2;
+    const int left = M - tile * C::TP;             // pixels of this tile that exist
+    okbits = 0;
+#pragma unroll
+    for (int i = 0; i < C::NI; ++i) {
+      const bool ok = (tid + i * C::NT) / C::OCT < left;
+      okbits |= (ok ? 1u : 0u) << i;
+      stage[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)((ok ? voffc[i] : 0x80000000u) | kill), soff, 0);
+    }
+  };
+  auto store_chunk = [&](int c) {
+    if (a.in_scale != nullptr) {
+      const int ch = c * CK + oct * 8;
+      const f32x4 s0 = *reinterpret_cast<const f32x4*>(a.in_scale + ch), s1 = *reinterpret_cast<const f32x4*>(a.in_scale + ch + 4);
+      const f32x4 h0 = *reinterpret_cast<const f32x4*>(a.in_shift + ch), h1 = *reinterpret_cast<const f32x4*>(a.in_shift + ch + 4);
+#pragma unroll
+      for (int i = 0; i < C::NI; ++i) {
+        u32x4 d = stage[i];
+        const bool ok = (okbits >> i) & 1u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float sc0 = e < 2 ? s0[2 * e] : s1[2 * e - 4], sc1 = e < 2 ? s0[2 * e + 1] : s1[2 * e - 3];
+          const float sh0 = e < 2 ? h0[2 * e] : h1[2 * e - 4], sh1 = e < 2 ? h0[2 * e + 1] : h1[2 * e - 3];
+          float t0 = __builtin_fmaf(bf_lo(d[e]), sc0, sh0), t1 = __builtin_fmaf(bf_hi(d[e]), sc1, sh1);
+          if (a.in_act == UDASEG_ACT_LEAKY && a.in_slope == 0.f) {      // uniform: ReLU is one v_max
+            t0 = t0 > 0.f ? t0 : 0.f;
+            t1 = t1 > 0.f ? t1 : 0.f;
+          } else {
+            t0 = act_apply(t0, a.in_act, a.in_slope);
+            t1 = act_apply(t1, a.in_act, a.in_slope);
+          }
+          d[e] = ok ? pack_bf16x2(t0, t1) : 0u;
+        }
+        stage[i] = d;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < C::NI; ++i)
+      *reinterpret_cast<u32x4*>(smem + ((tid + i * C::NT) / C::OCT) * C::STRIDE + oct * 16) = stage[i];
+  };
+  auto load_w = [&](int c) {
+    const int soff = c * C::FPC * 1024;
+#pragma unroll
+    for (int i = 0; i < C::NWI; ++i)
+      wstage[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wvoff[i] < 0 ? 0x80000000u : wlane16), wvoff[i] < 0 ? 0 : wvoff[i] + soff, 0);
+  };
+  auto store_w = [&]() {
+#pragma unroll
+    for (int i = 0; i < C::NWI; ++i) {
+      const int q = wave + C::NW * i;
+      if (i < C::NWI - 1 || q < WN * C::FPC) *reinterpret_cast<u32x4*>(wlds + q * 1024 + lane * 16) = wstage[i];
+    }
+  };
+
+  const int cbase = nb * 32;
+  __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)a.y_bytes, 0x00020000);
+  const bool want_stats = a.stats != nullptr && a.bnb_y == nullptr;
+  const bool want_bnb = a.bnb_y != nullptr;
+  __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(want_bnb ? a.bnb_y : a.x), 0,
+                                                                  (int)(want_bnb ? a.bnb_bytes : 0u), 0x00020000);
+  if ((want_stats || want_bnb) && tid < 2 * 32 * WN) sred[tid] = 0.f;     // visible after the first barrier below
+  const bool w_resident = nchunk == 1;             // single-chunk layers: the weights are staged once and stay in LDS
+
+  if (slot < ntiles) {
+    load_w(0);
+    load_chunk(slot, 0);
+  }
+  bool first = true;
+  for (int tile = slot; tile < ntiles; tile += P) {
+    // opaque copies: keep the epilogue's addresses from being hoisted out of the tile loop (and held in registers across it)
+    int lh_t = lh, cbase_t = cbase;
+    asm volatile("" : "+v"(lh_t), "+s"(cbase_t));
+    f32x16 acc[C::RPW];
+#pragma unroll
+    for (int r = 0; r < C::RPW; ++r)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[r][v] = 0.f;
+    for (int c = 0; c < nchunk; ++c) {
+      store_chunk(c);
+      if (!w_resident || first) store_w();
+      __syncthreads();
+      if (c + 1 < nchunk) {
+        load_w(c + 1);
+        load_chunk(tile, c + 1);
+      } else if (tile + P < ntiles) {          // the block's next tile: requested before this tile's MFMAs and epilogue
+        if (!w_resident) load_w(0);
+        load_chunk(tile + P, 0);
+      }
+#pragma unroll
+      for (int k = 0; k < C::FPC; ++k) {
+        const u32x4 bf = *reinterpret_cast<const u32x4*>(wlds + wrd + k * 1024);
+#pragma unroll
+        for (int r = 0; r < C::RPW; ++r) {
+          const u32x4 pf = *reinterpret_cast<const u32x4*>(smem + pbase + r * 32 * C::STRIDE + k * 32);
+          acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bf), __builtin_bit_cast(bf16x8, pf), acc[r], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+      first = false;
+    }
+
+    // ---- epilogue (layout as in conv_halo_bf16_kernel; the pixel index is flat)
+    float sA[16], sB[16];
+#pragma unroll
+    for (int v = 0; v < 16; ++v) sA[v] = sB[v] = 0.f;
+#pragma unroll
+    for (int r = 0; r < C::RPW; ++r) {
+      const int pix = tile * C::TP + (wm * C::RPW + r) * 32 + lp;
+      const bool pv = wave_live && pix < M;
+      const unsigned pixoff = (unsigned)pix;
+      unsigned dw[8];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c0 = cbase_t + 8 * g + 4 * lh_t;
+        const bool cv = pv && c0 < a.co;
+        float val[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) val[e] = acc[r][4 * g + e];
+        if (a.bias != nullptr) {
+          const f32x4 bq = *reinterpret_cast<const f32x4*>(a.bias + (c0 < a.co ? c0 : 0));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) val[e] += bq[e];
+        }
+        if (want_stats) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float q = cv ? val[e] : 0.f;
+            sA[4 * g + e] += q;
+            sB[4 * g + e] = __builtin_fmaf(q, q, sB[4 * g + e]);
+          }
+        }
+        if (a.act != UDASEG_ACT_NONE) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) val[e] = act_apply(val[e], a.act, a.slope);
+        }
+        if (a.accumulate) {
+          const unsigned ooff = cv ? (pixoff * (unsigned)a.co + (unsigned)c0) * 2u : 0x80000000u;
+          const u32x2 old = __builtin_amdgcn_raw_buffer_load_b64(rs_y, (int)ooff, 0, 0);
+          val[0] += bf_lo(old[0]); val[1] += bf_hi(old[0]); val[2] += bf_lo(old[1]); val[3] += bf_hi(old[1]);
+        }
+        dw[2 * g] = pack_bf16x2(val[0], val[1]);
+        dw[2 * g + 1] = pack_bf16x2(val[2], val[3]);
+        if (want_bnb) {
+          const unsigned poff = cv ? (pixoff * (unsigned)a.co + (unsigned)c0) * 2u : 0x80000000u;
+          const u32x2 yv = __builtin_amdgcn_raw_buffer_load_b64(rs_p, (int)poff, 0, 0);
+          const f32x4 mu = *reinterpret_cast<const f32x4*>(a.bnb_mean + (c0 < a.co ? c0 : 0));
+          const f32x4 rsd = *reinterpret_cast<const f32x4*>(a.bnb_rstd + (c0 < a.co ? c0 : 0));
+          const f32x4 gm = *reinterpret_cast<const f32x4*>(a.bnb_gamma + (c0 < a.co ? c0 : 0));
+          const f32x4 bt = *reinterpret_cast<const f32x4*>(a.bnb_beta + (c0 < a.co ? c0 : 0));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float yy = (e & 1) ? bf_hi(yv[e >> 1]) : bf_lo(yv[e >> 1]);
+            const float gr = (e & 1) ? bf_hi(dw[2 * g + (e >> 1)]) : bf_lo(dw[2 * g + (e >> 1)]);
+            const float sc = gm[e] * rsd[e], sh = bt[e] - mu[e] * sc;
+            const float gg = cv ? gr * act_grad(__builtin_fmaf(yy, sc, sh), a.bnb_act, a.bnb_slope) : 0.f;
+            sA[4 * g + e] += gg;
+            sB[4 * g + e] = __builtin_fmaf(gg, (yy - mu[e]) * rsd[e], sB[4 * g + e]);
+          }
+        }
+      }
+#pragma unroll
+      for (int gp = 0; gp < 2; ++gp) {
+        const u32x2 s0 = __builtin_amdgcn_permlane32_swap(dw[4 * gp], dw[4 * gp + 2], false, false);
+        const u32x2 s1 = __builtin_amdgcn_permlane32_swap(dw[4 * gp + 1], dw[4 * gp + 3], false, false);
+        const u32x4 d = {s0[0], s1[0], s0[1], s1[1]};
+        const int c8 = cbase_t + 8 * (2 * gp + lh_t);
+        const unsigned off = (pv && c8 < a.co) ? (pixoff * (unsigned)a.co + (unsigned)c8) * 2u : 0x80000000u;
+        __builtin_amdgcn_raw_buffer_store_b128(d, rs_y, (int)off, 0, 0);
+      }
+    }
+    if (want_stats || want_bnb) {
+      asm volatile("s_nop 1");
+      halfwave_sum_n(sA);
+      halfwave_sum_n(sB);
+      asm volatile("s_nop 1");
+      if (lp == 31 && wave_live) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int cl = wn * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh_t;
+          atomicAdd(&sred[cl], sA[v]);
+          atomicAdd(&sred[32 * WN + cl], sB[v]);
+        }
+      }
+    }
+  }
+
+  if (want_stats || want_bnb) {
+    __syncthreads();
+    if (tid < 32 * WN) {
+      const int c = cb * WN * 32 + tid;
+      if (c < a.co) {
+        double* rep = a.stats + (size_t)(blockIdx.x % HALO_STATS_REPLICAS) * 2 * a.co;
+        atomicAdd(rep + c, (double)sred[tid]);
+        atomicAdd(rep + a.co + c, (double)sred[32 * WN + tid]);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ fragment packing
 // Weights in MFMA-fragment order.  For a convolution with N produced and K gathered channels and a KS x KS window:
 //   packed[nb][dx][k16][dy][lane][j]  (nb < ceil(N/32), k16 < ceil(K/16), lane < 64, j < 8; bf16)
@@ -568,6 +840,61 @@ static int launch_halo_t(HaloArgs a, hipStream_t s, double flops) {
   return UDASEG_OK;
 }
 
+template <int CK, int WM, int WN>
+static int launch_stream_t(HaloArgs a, hipStream_t s, double flops) {
+  using C = StreamCfg<CK, WM, WN>;
+  auto kern = conv1x1_stream_bf16_kernel<CK, WM, WN>;
+  static bool attr_done = false;
+  if (!attr_done && C::LDS > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv1x1_stream_bf16)");
+    attr_done = true;
+  }
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hip_fail(hipGetLastError(), "hipGetDeviceProperties");
+    cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  a.ncb = cdiv(a.co, 32 * WN);
+  a.nk16 = (a.ci + 15) / 16;
+  const long long tiles = cdiv64((long long)a.n * a.h * a.w, C::TP);
+  if (tiles <= 0) return UDASEG_OK;
+  long long P = cus / a.ncb;                 // one 8-wave block per CU
+  if (P < 1) P = 1;
+  if (P > tiles) P = tiles;
+  static int kid = -1;
+  if (kid < 0) {
+    char nm[96];
+    snprintf(nm, sizeof(nm), "conv1x1_stream_bf16_kernel<%d, %d, %d>", CK, WM, WN);
+    kid = kprof_id(nm);
+  }
+  hipEvent_t ev = kprof_begin(s);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(P * a.ncb)), dim3(C::NT), C::LDS, s, a);
+  kprof_end(kid, ev, s, flops);
+  UDASEG_LAUNCH_CHECK("conv1x1_stream_bf16 launch");
+  return UDASEG_OK;
+}
+
+// The streamer takes the plain 1x1 launches: bf16 output, no fused decoder input, no split.
+static bool stream_applicable(const HaloArgs& a, int ks) {
+  static int off = -1;   // UDASEG_NO_STREAM=1: 1x1 layers stay on the tile kernel (A/B)
+  if (off < 0) off = getenv("UDASEG_NO_STREAM") != nullptr ? 1 : 0;
+  return !off && ks == 1 && !a.out_f32 && a.up_ca == 0 && a.split_n == 0 && a.ci % 16 == 0;
+}
+
+static int launch_stream(HaloArgs a, hipStream_t s, double flops) {
+  // 128 output channels per block at most: the 256-channel form (128 accumulator registers + the prefetched tile + the
+  // epilogue's sums) spills; a 256-channel layer reads its input twice instead, through L2
+  if (a.ci % 64 == 0) {
+    if (a.co > 64) return launch_stream_t<64, 2, 4>(a, s, flops);
+    return launch_stream_t<64, 4, 2>(a, s, flops);
+  }
+  if (a.co > 64) return launch_stream_t<16, 2, 4>(a, s, flops);
+  return launch_stream_t<16, 4, 2>(a, s, flops);
+}
+
 static int halo_cfg_override() {
   static int v = -1;   // tuning aid: UDASEG_HALO_CFG = 1..n forces one configuration (0 / unset: heuristic)
   if (v < 0) {
@@ -607,8 +934,10 @@ static int halo_choice(int ks, int h, int w, int n, int gathered, int produced, 
   if (ov > 0) return ov > 3 ? 3 : ov;
   const long long tiles = (long long)n * cdiv(h, 8) * cdiv(w, 32);
   if (ks == 1) {
-    if (!dgrad || produced <= gathered) return 0;
-    return produced >= 128 ? 3 : 2;
+    static int off = -1;       // UDASEG_NO_STREAM=1 (A/B): without the streaming kernel only the expanding gradients pay
+    if (off < 0) off = getenv("UDASEG_NO_STREAM") != nullptr ? 1 : 0;
+    if (off && (!dgrad || produced <= gathered)) return 0;
+    return produced >= 128 ? 3 : 2;      // every 1x1 / stride 1 layer: conv1x1_stream_bf16_kernel (launch_halo routes it)
   }
   if (produced <= 32) return 1;
   if (produced <= 64) return 2;
@@ -622,6 +951,7 @@ int launch_halo(const udaseg_conv_desc* d, HaloArgs a, hipStream_t s, bool dgrad
   // chunk: 32 channels (64 for the 1x1 kernels) when that divides the gathered channels and both sources of a fused input
   int ck = 32;
   if (a.ci % 32 != 0 || (a.up_ca > 0 && (a.up_ca % 32 != 0 || (a.ci - a.up_ca) % 32 != 0))) ck = 16;
+  if (stream_applicable(a, d->kh)) return launch_stream(a, s, flops);
   int choice = halo_choice(d->kh, a.h, a.w, a.n, a.ci, a.co, dgrad);
   if (choice == 0) choice = a.co <= 32 ? 1 : (a.co <= 64 ? 2 : 3);     // called although not preferred (tests, UDASEG_FRAG=2)
   if (d->kh == 3) {

@@ -54,6 +54,11 @@ struct WgradArgs {
   const float* in_shift;
   int in_act;
   float in_slope;
+  // bf16 kernel: 1-D grid of tiles * splits blocks, remapped so that every (co tile, tap / channel tile) block of ONE pixel
+  // split runs on the same XCD (blocks b and b + 8 share one): the nine tap tiles of a 3x3 layer gather the same x rows and
+  // the same dy rows, and spread over eight L2s each XCD fetched its own copy -- 181 MB per launch at the fabric for 34 MB of
+  // operands (PMC, profiles/r03_bf16_cfg3_pmc_traffic.txt), which at bf16 rates IS the launch time.  0: two-dimensional grid.
+  int xcd_tiles, xcd_splits;
 };
 
 constexpr int WBK = 32;  // pixels per K-tile
@@ -302,10 +307,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradArgs a)
   const int grp = lane >> 4, cb = 16 * (grp & 1), hk = grp >> 1, tq = (lane & 15) >> 2, tp = lane & 3;
 
   const int ntj = (a.J + BNW - 1) / BNW;
-  const int co0 = (blockIdx.x / ntj) * BMW;
-  const int j0 = (blockIdx.x % ntj) * BNW;
-  const int kbeg = blockIdx.y * a.kchunk;
+  int tile_id = blockIdx.x, split_id = blockIdx.y;
+  if (a.xcd_tiles > 0) {        // see WgradArgs::xcd_tiles
+    const int L = blockIdx.x, xcd = L & 7, idx = L >> 3;
+    split_id = xcd + 8 * (idx / a.xcd_tiles);
+    tile_id = idx % a.xcd_tiles;
+  }
+  const int co0 = (tile_id / ntj) * BMW;
+  const int j0 = (tile_id % ntj) * BNW;
+  const int kbeg = split_id * a.kchunk;
   const int kend = min(a.M, kbeg + a.kchunk);
+  if (kbeg >= a.M) return;          // an empty split of a rounded-up split count (block-uniform, before any barrier)
 
   const int aq = tid % AQ, arow = tid / AQ;
   const int a_co = co0 + aq * 8;
@@ -334,6 +346,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradArgs a)
   const int nkt = (kend - kbeg + WBKB - 1) / WBKB;
   // producer's BatchNorm + activation on the gathered operand (WgradArgs::in_scale): this thread's 8 channels are fixed
   const bool xform = a.in_scale != nullptr;
+  const bool x_relu = a.in_act == UDASEG_ACT_LEAKY && a.in_slope == 0.f;
   float x_sc[8], x_sh[8];
   unsigned x_ok = 0;          // bit p: pass p of the tile in the registers is inside the image
   if (xform) {
@@ -453,8 +466,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradArgs a)
           const unsigned w = wv[e];
           float t0 = __builtin_fmaf(__builtin_bit_cast(float, w << 16), x_sc[2 * e], x_sh[2 * e]);
           float t1 = __builtin_fmaf(__builtin_bit_cast(float, w & 0xffff0000u), x_sc[2 * e + 1], x_sh[2 * e + 1]);
-          t0 = act_apply(t0, a.in_act, a.in_slope);
-          t1 = act_apply(t1, a.in_act, a.in_slope);
+          if (x_relu) {               // uniform: ReLU is one v_max (the general form is compare + multiply + select)
+            t0 = t0 > 0.f ? t0 : 0.f;
+            t1 = t1 > 0.f ? t1 : 0.f;
+          } else {
+            t0 = act_apply(t0, a.in_act, a.in_slope);
+            t1 = act_apply(t1, a.in_act, a.in_slope);
+          }
           dv[e] = ok ? ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)t0) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)t1) << 16))
                      : 0u;
         }
@@ -542,6 +560,16 @@ static int launch_wgrad(WgradArgs a, int accumulate, hipStream_t s, bool bf16 = 
   const int ktile = bf16 ? WBKB : WBK;
   int kchunk = cdiv(cdiv(a.M, splits), ktile) * ktile;
   splits = cdiv(a.M, kchunk);
+  if (bf16 && splits >= 16 && tiles > 1 && splits % 8 != 0) {
+    // the XCD-aware block order (WgradArgs::xcd_tiles) needs a multiple of 8 splits: take the nearest one that still tiles M
+    // (a split may come out empty when M / ktile is not divisible: its block returns at once)
+    const int s8 = ((splits + 4) / 8) * 8;
+    const int kc = cdiv(cdiv(a.M, s8), ktile) * ktile;
+    if ((long long)kc * (s8 - 8) < a.M) {     // at most the last few splits are empty
+      kchunk = kc;
+      splits = s8;
+    }
+  }
   a.kchunk = kchunk;
   a.use_atomic = (splits > 1 || accumulate) ? 1 : 0;
   if (a.use_atomic && !accumulate) {
@@ -553,6 +581,16 @@ static int launch_wgrad(WgradArgs a, int accumulate, hipStream_t s, bool bf16 = 
     if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(dw)");
   }
   dim3 grid((unsigned)tiles, (unsigned)splits), block(256);
+  a.xcd_tiles = a.xcd_splits = 0;
+  if (bf16 && splits % 8 == 0 && tiles > 1) {
+    static int no_remap = -1;      // UDASEG_WGRAD_NO_XCD=1: A/B
+    if (no_remap < 0) no_remap = getenv("UDASEG_WGRAD_NO_XCD") != nullptr ? 1 : 0;
+    if (!no_remap) {
+      a.xcd_tiles = tiles;
+      a.xcd_splits = splits;
+      grid = dim3((unsigned)(tiles * splits), 1u);
+    }
+  }
   hipEvent_t ev = kprof_begin(s);
   if (bf16) {
     constexpr int b_rows16 = 256 / (BNW / 8);

@@ -40,7 +40,12 @@ FRAG_POLICY = "always" if os.environ.get("UDASEG_FRAG") == "2" else "auto"
 
 # bf16 storage: BatchNorm + activation of a layer whose ONLY consumer is a convolution on the bf16-first kernels is not written at
 # all -- the consumer applies it while it stages its input (UDASEG_FUSE_BN_APPLY=0: always the stand-alone bn_apply pass)
-FUSE_BN_APPLY = os.environ.get("UDASEG_FUSE_BN_APPLY", "1") != "0"
+FUSE_BN_APPLY = os.environ.get("UDASEG_FUSE_BN_APPLY", "2") != "0"
+# Default "2": only in front of 1x1 consumers.  The weight gradient of a 3x3 consumer gathers every input element once per tap
+# (in different blocks), so the transform is evaluated nine times per element there and costs more than the pass it saves
+# (measured, profiles/r03_bn_fusion_ab.txt: cfg 3 / cfg 5 images/s off 987.8 / 395.3, everywhere ("1") 990.7 / 397.9, 1x1
+# consumers only 993.5 / 399.3; wgrad 256 -> 256 at 48^2 92 -> 136 us with the transform in its gather).
+FUSE_BN_APPLY_1X1_ONLY = os.environ.get("UDASEG_FUSE_BN_APPLY", "2") == "2"
 
 
 _SIDE_STREAMS = {}   # device -> the one side HIP stream the weight gradients of every network on that device run on
@@ -499,7 +504,7 @@ class Plan:
         makes this layer's BatchNorm-backward sums, which then need no activation either)."""
         if not (FUSE_BN_APPLY and FUSE_BN_REDUCE and self.frag and consumer is not None and residual is None and act != ACT_NONE):
             return False
-        if consumer.stride != 1 or consumer.cin_p != c or c % 16 != 0:
+        if consumer.stride != 1 or consumer.cin_p != c or c % 16 != 0 or (FUSE_BN_APPLY_1X1_ONLY and consumer.k != 1):
             return False
         d2 = K.conv_desc(n, ho, wo, c, consumer.cout_p, consumer.k, 1, consumer.pad)
         return self.wfrag(consumer, d2) is not None and self.wfrag(consumer, d2, dgrad=True) is not None
