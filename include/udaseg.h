@@ -343,10 +343,10 @@ int udaseg_pack_dgrad_batched_bf16(const float* arena, void* packed, const int* 
  *      network in one launch: table[i] = {mode (0 forward from w16 / 1 data gradient from wt16), source element offset,
  *      destination element offset, N, K, ks} (int32 x 6, device memory). ---- */
 int64_t udaseg_frag_elems(int n_out, int k_in, int ks);
-/* Optional caller-owned fp32 scratch (bound to the current device; the caller ZEROES it once, the library leaves it zeroed after
+/* Optional caller-owned f64 scratch (bound to the current device; the caller ZEROES it once, the library leaves it zeroed after
  * every use): launches of more than 1024 blocks put their per-channel statistics there (256 replicas) and a fold kernel adds
  * them into `stats` -- otherwise hundreds of same-address f64 atomics per accumulator bound the low-channel full-resolution
- * layers.  Needs 256 * 2 * co * 4 bytes for a layer with co output channels (256 KiB covers co <= 128); NULL unbinds. */
+ * layers.  Needs 256 * 2 * co * 8 bytes for a layer with co output channels (256 KiB covers co <= 64); NULL unbinds. */
 int udaseg_set_stats_scratch(void* ptr, size_t bytes);
 int udaseg_pack_frag_batched_bf16(const void* w16, const void* wt16, void* packed, const int* table, int entries, void* stream);
 /* ---- a BatchNorm + activation that is never written (single-consumer layers, bf16): the producer's statistics are finalised

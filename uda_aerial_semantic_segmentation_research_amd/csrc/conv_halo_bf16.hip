@@ -43,7 +43,7 @@ struct HaloArgs {
   int out_f32, act;
   float slope;
   double* stats;        // [R][2][co] f64: BatchNorm statistics of the output, or the bnb_* sums
-  float* sscr;          // launches of > 1024 blocks: fp32 partial sums [HALO_SCR_REPLICAS][2][co] (zeroed scratch), folded into `stats`
+  double* sscr;         // launches of > 1024 blocks: f64 partial sums [HALO_SCR_REPLICAS][2][co] (zeroed scratch), folded into `stats`
                         // by halo_stats_fold_kernel -- 8192 blocks on 16 replicas put 512 same-address f64 atomics (~0.1 us each,
                         // serialised at the memory side) on every accumulator of a 16-channel layer: the atomics WERE the launch
   // BatchNorm-backward reductions of the layer behind a data gradient (see IgemmArgs::bnb_* in conv_igemm.hip)
@@ -460,10 +460,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_halo_bf16_kernel(const H
           t1 += red[(m * WN + wc) * 32 + cl];
           t2 += red[C::NW * 32 + (m * WN + wc) * 32 + cl];
         }
-        if (a.sscr != nullptr) {
-          float* rep = a.sscr + (size_t)(blockIdx.x % HALO_SCR_REPLICAS) * 2 * a.co;
-          atomicAdd(rep + c, t1);
-          atomicAdd(rep + a.co + c, t2);
+        if (a.sscr != nullptr) {     // f64 like the accumulators themselves: the order of the adds must not show (the forward
+          double* rep = a.sscr + (size_t)(blockIdx.x % HALO_SCR_REPLICAS) * 2 * a.co;     // is bitwise reproducible)
+          atomicAdd(rep + c, (double)t1);
+          atomicAdd(rep + a.co + c, (double)t2);
         } else {
           double* rep = a.stats + (size_t)(blockIdx.x % HALO_STATS_REPLICAS) * 2 * a.co;
           atomicAdd(rep + c, (double)t1);
@@ -499,7 +499,7 @@ struct StreamCfg {
   static constexpr int NPIECE = TP * OCT, NI = NPIECE / NT;
   static constexpr int FPC = CK / 16, NW = 8;
   static constexpr int NWI = (WN * FPC + NW - 1) / NW;
-  static constexpr int LDS_A = TP * STRIDE, LDS_W = WN * FPC * 1024, LDS_STATS = 2 * 32 * WN * 4;
+  static constexpr int LDS_A = TP * STRIDE, LDS_W = WN * FPC * 1024, LDS_STATS = NW * 2 * 32 * 4;   // one slot per wave
   static constexpr int LDS = LDS_A + LDS_W + LDS_STATS;
   static_assert(WM * WN == 8 && NPIECE % NT == 0 && NI >= 1, "8 waves; whole staging passes");
 };
@@ -609,7 +609,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_stream_bf16_kernel(const HaloA
   const bool want_bnb = a.bnb_y != nullptr;
   __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(want_bnb ? a.bnb_y : a.x), 0,
                                                                   (int)(want_bnb ? a.bnb_bytes : 0u), 0x00020000);
-  if ((want_stats || want_bnb) && tid < 2 * 32 * WN) sred[tid] = 0.f;     // visible after the first barrier below
+  if ((want_stats || want_bnb) && tid < C::NW * 2 * 32) sred[tid] = 0.f;     // visible after the first barrier below
   const bool w_resident = nchunk == 1;             // single-chunk layers: the weights are staged once and stay in LDS
 
   if (slot < ntiles) {
@@ -724,12 +724,14 @@ __global__ __launch_bounds__(512, 2) void conv1x1_stream_bf16_kernel(const HaloA
       halfwave_sum_n(sA);
       halfwave_sum_n(sB);
       asm volatile("s_nop 1");
+      // each wave adds into ITS OWN slot, tile after tile: a fixed order (an LDS atomic shared by the waves would make the
+      // forward statistics depend on which wave came first; the forward is bitwise reproducible)
       if (lp == 31 && wave_live) {
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
-          const int cl = wn * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh_t;
-          atomicAdd(&sred[cl], sA[v]);
-          atomicAdd(&sred[32 * WN + cl], sB[v]);
+          const int cl = (v & 3) + 8 * (v >> 2) + 4 * lh_t;
+          sred[(wave * 2 + 0) * 32 + cl] += sA[v];
+          sred[(wave * 2 + 1) * 32 + cl] += sB[v];
         }
       }
     }
@@ -738,11 +740,18 @@ __global__ __launch_bounds__(512, 2) void conv1x1_stream_bf16_kernel(const HaloA
   if (want_stats || want_bnb) {
     __syncthreads();
     if (tid < 32 * WN) {
-      const int c = cb * WN * 32 + tid;
+      const int wc = tid >> 5, cl = tid & 31;
+      const int c = (cb * WN + wc) * 32 + cl;
       if (c < a.co) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int m = 0; m < WM; ++m) {        // the waves that share this channel block, in wave order
+          t1 += sred[((m * WN + wc) * 2 + 0) * 32 + cl];
+          t2 += sred[((m * WN + wc) * 2 + 1) * 32 + cl];
+        }
         double* rep = a.stats + (size_t)(blockIdx.x % HALO_STATS_REPLICAS) * 2 * a.co;
-        atomicAdd(rep + c, (double)sred[tid]);
-        atomicAdd(rep + a.co + c, (double)sred[32 * WN + tid]);
+        atomicAdd(rep + c, (double)t1);
+        atomicAdd(rep + a.co + c, (double)t2);
       }
     }
   }
@@ -781,21 +790,21 @@ __global__ void pack_frag_batched_bf16_kernel(const __bf16* __restrict__ w16, co
   }
 }
 
-// fp32 partial sums of a many-block launch -> the f64 accumulators (replica 0); leaves the scratch zeroed for the next launch
-__global__ void halo_stats_fold_kernel(float* __restrict__ sscr, int co, double* __restrict__ stats) {
+// partial sums of a many-block launch -> the f64 accumulators (replica 0); leaves the scratch zeroed for the next launch
+__global__ void halo_stats_fold_kernel(double* __restrict__ sscr, int co, double* __restrict__ stats) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;      // index into [2][co]
   if (i >= 2 * co) return;
-  float s = 0.f;
+  double s = 0.0;
 #pragma unroll 8
   for (int r = 0; r < HALO_SCR_REPLICAS; ++r) {
     s += sscr[(size_t)r * 2 * co + i];
-    sscr[(size_t)r * 2 * co + i] = 0.f;
+    sscr[(size_t)r * 2 * co + i] = 0.0;
   }
-  atomicAdd(stats + i, (double)s);
+  atomicAdd(stats + i, s);
 }
 
 // one caller-owned, caller-zeroed fp32 scratch per device for those partial sums (udaseg_set_stats_scratch)
-static float* g_sscr[16] = {};
+static double* g_sscr[16] = {};
 static size_t g_sscr_bytes[16] = {};
 
 // ------------------------------------------------------------------------------------------------- host side
@@ -820,7 +829,7 @@ static int launch_halo_t(HaloArgs a, hipStream_t s, double flops) {
   if (a.stats != nullptr && blocks > 1024) {
     int dev = 0;
     if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16 && g_sscr[dev] != nullptr &&
-        (size_t)HALO_SCR_REPLICAS * 2 * a.co * sizeof(float) <= g_sscr_bytes[dev])
+        (size_t)HALO_SCR_REPLICAS * 2 * a.co * sizeof(double) <= g_sscr_bytes[dev])
       a.sscr = g_sscr[dev];
   }
   static int kid = -1;
@@ -981,7 +990,7 @@ extern "C" int udaseg_set_stats_scratch(void* ptr, size_t bytes) {
   int dev = 0;
   UDASEG_CHECK_ARG(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16, "set_stats_scratch: no current HIP device");
   UDASEG_CHECK_ARG(ptr == nullptr || (reinterpret_cast<uintptr_t>(ptr) & 15) == 0, "set_stats_scratch: 16-byte alignment");
-  g_sscr[dev] = static_cast<float*>(ptr);
+  g_sscr[dev] = static_cast<double*>(ptr);
   g_sscr_bytes[dev] = ptr ? bytes : 0;
   return UDASEG_OK;
 }
