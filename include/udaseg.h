@@ -364,6 +364,13 @@ int udaseg_bn_bwd_apply_recompute_bf16(const void* dz, const void* y, const floa
                                        const float* save_mean, const float* save_rstd, const float* gamma, const double* bsums,
                                        void* dy, float* dgamma, float* dbeta, int64_t pixels, int c, int act, float slope,
                                        void* stream);
+/* Weight gradient of a stride-1 3x3 / pad 1 convolution whose channel counts are multiples of 64, bf16 operands, fp32 dW
+ * ACCUMULATED onto (caller-zeroed arena): a block owns a 64 x 64 channel block of all nine taps and walks pixel tiles, x halo
+ * and dy tile staged once per tile; few long-lived blocks, one set of atomics per block.  skip / up_ca: the two sources of a
+ * fused decoder input in ONE launch.  loss.backward() at reference src/models/train.py:343. */
+int udaseg_conv2d_wgrad_halo_bf16_ok(const udaseg_conv_desc* d, int up_ca);
+int udaseg_conv2d_wgrad_halo_bf16(const udaseg_conv_desc* d, const void* x, const void* skip, int up_ca, const void* dy, float* dw,
+                                  void* stream);
 int udaseg_conv2d_wgrad_bnin_bf16(const udaseg_conv_desc* d, const void* x, const float* in_scale, const float* in_shift, int in_act,
                                   float in_slope, const void* dy, float* dw, int accumulate, void* stream);
 /* 1 when the convolution (dgrad = 0: forward, gathers ci and produces co; dgrad = 1: its data gradient; up_ca > 0: forward on the

@@ -298,3 +298,42 @@ def test_network_with_and_without_unwritten_activations(K, monkeypatch):
     assert ((ga - gb).abs().max() / gb.abs().max()).item() < 1e-5
     for k, v in outs[True][3].items():          # BatchNorm running statistics updated identically
         assert torch.equal(v, outs[False][3][k]), k
+
+
+@pytest.mark.parametrize("n,h,w,ci,co", [(2, 16, 32, 64, 64), (1, 24, 40, 128, 64), (8, 64, 64, 64, 64), (1, 9, 33, 64, 128),
+                                          (3, 8, 32, 192, 64)])
+def test_wgrad_halo(K, n, h, w, ci, co):
+    """Halo-resident bf16 weight gradient (64 x 64 channel block of all nine taps per block, pixel tiles walked by few
+    long-lived blocks) against torch's fp32 CPU gradient on the bf16-rounded operands, and against the per-tap split-K kernel."""
+    g = torch.Generator().manual_seed(n + h + ci + co)
+    x = rb(torch.randn(n, ci, h, w, generator=g))
+    dy = rb(torch.randn(n, co, h, w, generator=g))
+    wr = torch.zeros(co, ci, 3, 3, requires_grad=True)
+    F.conv2d(x, wr, None, padding=1).backward(dy)
+    d = K.conv_desc(n, h, w, ci, co, 3, 1, 1)
+    assert K.conv2d_wgrad_halo_ok(d) and not K.conv2d_wgrad_halo_ok(K.conv_desc(n, h, w, 32, co, 3, 1, 1))
+    dw = torch.full((co, 3, 3, ci), 0.25, device="cuda")
+    K.conv2d_wgrad_halo(d, nhwc(x), None, nhwc(dy), dw)
+    close(dw.cpu().permute(0, 3, 1, 2), wr.grad + 0.25, "halo wgrad (accumulated onto 0.25)", 1e-4)
+    dw2 = torch.full((co, 3, 3, ci), 0.25, device="cuda")
+    K.conv2d_wgrad(d, nhwc(x), nhwc(dy), dw2, True)
+    close(dw.cpu(), dw2.cpu(), "halo wgrad vs split-K kernel", 2e-5)
+
+
+@pytest.mark.parametrize("n,h,w,ca,cb,co", [(2, 8, 16, 64, 64, 64), (1, 6, 18, 128, 64, 64)])
+def test_wgrad_halo_over_fused_upsample_concat(K, n, h, w, ca, cb, co):
+    g = torch.Generator().manual_seed(ca + cb + co + h)
+    a = rb(torch.randn(n, ca, h, w, generator=g))
+    skip = rb(torch.randn(n, cb, 2 * h, 2 * w, generator=g))
+    cat = torch.cat([F.interpolate(a, scale_factor=2.0, mode="nearest"), skip], 1)
+    dy = rb(torch.randn(n, co, 2 * h, 2 * w, generator=g))
+    d = K.conv_desc(n, 2 * h, 2 * w, ca + cb, co, 3, 1, 1)
+    assert K.conv2d_wgrad_halo_ok(d, ca)
+    dw_mat = torch.zeros(co, 3, 3, ca + cb, device="cuda")
+    K.conv2d_wgrad_halo(d, nhwc(cat), None, nhwc(dy), dw_mat)
+    dw = torch.zeros_like(dw_mat)
+    K.conv2d_wgrad_halo(d, nhwc(a), nhwc(skip), nhwc(dy), dw, up=True)
+    close(dw.cpu(), dw_mat.cpu(), "fused-input halo wgrad vs materialised", 2e-6)
+    wr = torch.zeros(co, ca + cb, 3, 3, requires_grad=True)
+    F.conv2d(cat, wr, None, padding=1).backward(dy)
+    close(dw.cpu().permute(0, 3, 1, 2), wr.grad, "fused-input halo wgrad vs torch", 1e-4)

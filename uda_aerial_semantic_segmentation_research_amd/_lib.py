@@ -110,6 +110,8 @@ SIGNATURES = {
     "udaseg_pack_dgrad_batched_bf16": (_I, [_P, _P, _P, _I, _P]),
     "udaseg_bn_finalize": (_I, [_P, _P, _P, _L, _I, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
     "udaseg_bn_bwd_apply_recompute_bf16": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _P]),
+    "udaseg_conv2d_wgrad_halo_bf16_ok": (_I, [_D, _I]),
+    "udaseg_conv2d_wgrad_halo_bf16": (_I, [_D, _P, _P, _I, _P, _P, _P]),
     "udaseg_conv2d_wgrad_bnin_bf16": (_I, [_D, _P, _P, _P, _I, _F, _P, _P, _I, _P]),
     "udaseg_frag_elems": (_L, [_I, _I, _I]),
     "udaseg_set_stats_scratch": (_I, [_P, C.c_size_t]),

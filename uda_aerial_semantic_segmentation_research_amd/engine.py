@@ -48,6 +48,11 @@ FUSE_BN_APPLY = os.environ.get("UDASEG_FUSE_BN_APPLY", "2") != "0"
 FUSE_BN_APPLY_1X1_ONLY = os.environ.get("UDASEG_FUSE_BN_APPLY", "2") == "2"
 
 
+# bf16 storage: weight gradients of the stride-1 3x3 layers with channel counts that are multiples of 64 on the halo-resident
+# kernel (few long-lived blocks, x halo and dy staged once per tile); UDASEG_WGRAD_HALO=0: per-tap split-K kernel everywhere
+USE_WGRAD_HALO = os.environ.get("UDASEG_WGRAD_HALO", "1") != "0"
+
+
 _SIDE_STREAMS = {}   # device -> the one side HIP stream the weight gradients of every network on that device run on
 _ARENA_OWNERS = {}   # parameter-arena storage pointer -> weakref of the ArenaModule that owns it
 
@@ -625,9 +630,12 @@ class Plan:
             wst = self.st
         if isinstance(x, UpCat):
             gw = self.gw(conv)
-            K.conv2d_wgrad_part(d, x.a, 0, True, dy, gw, True, wst)
-            if x.skip is not None:
-                K.conv2d_wgrad_part(d, x.skip, x.a.shape[-1], False, dy, gw, True, wst)
+            if self.bf16 and USE_WGRAD_HALO and x.skip is not None and K.conv2d_wgrad_halo_ok(d, x.a.shape[-1]):
+                K.conv2d_wgrad_halo(d, x.a, x.skip, dy, gw, up=True, st=wst)      # both sources in one launch
+            else:
+                K.conv2d_wgrad_part(d, x.a, 0, True, dy, gw, True, wst)
+                if x.skip is not None:
+                    K.conv2d_wgrad_part(d, x.skip, x.a.shape[-1], False, dy, gw, True, wst)
             d_up, d_skip = dx
             assert not dx_acc and conv.bias is None
             wfd = self.wfrag(conv, d, dgrad=True)
@@ -640,6 +648,8 @@ class Plan:
             return
         if isinstance(x, LazyAct):
             K.conv2d_wgrad_bnin(d, x.y, x.scale, x.shift, x.act, x.slope, dy, self.gw(conv), True, wst)
+        elif self.bf16 and USE_WGRAD_HALO and K.conv2d_wgrad_halo_ok(d):
+            K.conv2d_wgrad_halo(d, x, None, dy, self.gw(conv), st=wst)
         else:
             K.conv2d_wgrad(d, x, dy, self.gw(conv), True, wst)
         if conv.bias is not None:

@@ -181,6 +181,17 @@ def bn_bwd_apply_recompute(dz, y, fwd_scale, fwd_shift, save_mean, save_rstd, ga
           "bn_bwd_apply_recompute_bf16")
 
 
+def conv2d_wgrad_halo_ok(d, up_ca=0):
+    return bool(_lib.load().udaseg_conv2d_wgrad_halo_bf16_ok(_byref(d), up_ca))
+
+
+def conv2d_wgrad_halo(d, x, skip, dy, dw, up=False, st=None):
+    """dW += weight gradient of a stride-1 3x3 layer (channel counts multiples of 64), bf16: halo-resident kernel.  up: x is the
+    half-resolution source of a fused decoder input, skip the other one."""
+    check(_lib.load().udaseg_conv2d_wgrad_halo_bf16(_byref(d), x.data_ptr(), _ptr(skip), x.shape[-1] if up else 0, dy.data_ptr(),
+                                                     dw.data_ptr(), st if st is not None else stream()), "conv2d_wgrad_halo_bf16")
+
+
 def conv2d_wgrad_bnin(d, y_prev, in_scale, in_shift, in_act, in_slope, dy, dw, accumulate=False, st=None):
     """Weight gradient whose gathered operand is act(fma(y_prev, in_scale, in_shift)) (never written), bf16."""
     check(_lib.load().udaseg_conv2d_wgrad_bnin_bf16(_byref(d), y_prev.data_ptr(), in_scale.data_ptr(), in_shift.data_ptr(), in_act,
