@@ -64,11 +64,49 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
+// Fold per-thread V-channel partials over the rows of a block, then one atomic per channel per block with CONSECUTIVE LANES ON
+// CONSECUTIVE CHANNELS: one atomic instruction then covers 64 adjacent words (4-8 cache lines).  (The first form had the owner
+// thread of a channel group issue its V atomics itself -- lanes V words apart, every instruction touching 64 lines: the
+// memory-side atomic units see requests per line, and bn_bwd_reduce's time followed its block count, 2.2 ms per r50 step at
+// 512 blocks, 4.5 ms at 2048: profiles/r03_bn_reduce_atomics.txt.)  Thread g owns channel group g % cq; bs % cq == 0 when
+// cq < bs (stream_shape), so rows r = q0, q0 + cq, ... of the block share group q0.  red: bs * V words of LDS.
+template <int V, typename T>
+__device__ __forceinline__ void block_fold_atomic(const T (&v)[V], T* __restrict__ dst, int cq, T* __restrict__ red) {
+  const int tid = threadIdx.x, bs = blockDim.x;
+#pragma unroll
+  for (int e = 0; e < V; ++e) red[tid * V + e] = v[e];
+  __syncthreads();
+  if (cq >= bs) {       // every thread alone on its channels: the block's groups are base .. base + bs - 1 (mod cq)
+    const int base = (int)(((int64_t)blockIdx.x * bs) % cq);
+    for (int j = tid; j < bs * V; j += bs) {
+      int qq = base + j / V;
+      if (qq >= cq) qq -= cq;
+      atomicAdd(dst + qq * V + (j % V), red[j]);
+    }
+  } else {
+    const int C = cq * V;
+    for (int t = tid; t < C; t += bs) {
+      T s = 0;
+      for (int r = t / V; r < bs; r += cq) s += red[r * V + (t % V)];
+      atomicAdd(dst + t, s);
+    }
+  }
+  __syncthreads();
+}
+
 // Per-channel f64 accumulators are replicated BN_REPLICAS times ([R][2][C]); block b adds into replica b % R and the
 // consumer sums the replicas.  Same-address memory-side atomics serialise (~100 ns each): 2048 blocks on one address
 // cost ~130 us per launch (measured, profiles/r01_kernel_stats_first.csv); 512 blocks over 16 replicas = 32 per address.
 constexpr int BN_REPLICAS = 16;
 constexpr int REDUCE_MAX_BLOCKS = 512;
+static inline int reduce_max_blocks() {   // UDASEG_REDUCE_BLOCKS: measurement override of the cap above
+  static const int v = [] {
+    const char* e = getenv("UDASEG_REDUCE_BLOCKS");
+    const int x = e ? atoi(e) : 0;
+    return x > 0 ? x : REDUCE_MAX_BLOCKS;
+  }();
+  return v;
+}
 
 // dgrad weight repack w[co][t][ci] -> wt[ci][t][co] of one table row, as 32x32 tile transposes through LDS: 128-byte row
 // reads, 128-byte (fp32) / 64-byte (bf16) row writes.  (The element-wise form read 4 bytes per lane at a stride of a whole

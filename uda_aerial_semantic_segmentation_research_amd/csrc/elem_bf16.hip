@@ -26,23 +26,8 @@ struct d8 {
 };
 // fold per-thread 8-channel f64 partials over the block's rows, then f64 atomics (same scheme as norm_act.hip)
 __device__ __forceinline__ void block_fold_add8(const d8& v, double* dst, int c8, int q, d8* red) {
-  const int tid = threadIdx.x, bs = blockDim.x;
-  if (c8 >= bs) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) atomicAdd(dst + q * 8 + e, v.v[e]);
-    return;
-  }
-  red[tid] = v;
-  __syncthreads();
-  if (tid < c8) {
-    d8 s = {{0, 0, 0, 0, 0, 0, 0, 0}};
-    for (int r = tid; r < bs; r += c8)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) s.v[e] += red[r].v[e];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) atomicAdd(dst + q * 8 + e, s.v[e]);
-  }
-  __syncthreads();
+  (void)q;
+  block_fold_atomic<8, double>(v.v, dst, c8, reinterpret_cast<double*>(red));
 }
 
 // ------------------------------------------------------------------------------------------------ batch norm, bf16
@@ -303,7 +288,6 @@ __global__ void channel_sum_bf16_kernel(const f32x4* __restrict__ x, int64_t n8,
   __shared__ float red[256][8];
   const int64_t T = (int64_t)gridDim.x * blockDim.x;
   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int q = (int)(g % c8);
   float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (int64_t i = g; i < n8; i += T) {
     float v[8];
@@ -311,23 +295,7 @@ __global__ void channel_sum_bf16_kernel(const f32x4* __restrict__ x, int64_t n8,
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[e] += v[e];
   }
-  const int tid = threadIdx.x, bs = blockDim.x;
-  if (c8 >= bs) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) atomicAdd(out + q * 8 + e, s[e]);
-    return;
-  }
-#pragma unroll
-  for (int e = 0; e < 8; ++e) red[tid][e] = s[e];
-  __syncthreads();
-  if (tid < c8) {
-    float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int r = tid; r < bs; r += c8)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) a[e] += red[r][e];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) atomicAdd(out + q * 8 + e, a[e]);
-  }
+  block_fold_atomic<8, float>(s, out, c8, &red[0][0]);
 }
 
 // --------------------------------------------------------------------------------------------- layout / pool / resize
@@ -591,7 +559,7 @@ extern "C" int udaseg_bn_bwd_reduce_bf16(const void* dz, const void* z, const vo
   if (rc) return rc;
   UDASEG_CHECK_ARG(dz && y && save_mean && save_rstd && bsums && (act == UDASEG_ACT_NONE || z), "bn_bwd_reduce_bf16: NULL pointer");
   const int64_t n8 = pixels * (c / 8);
-  const StreamShape s = stream_shape(n8, c / 8, REDUCE_MAX_BLOCKS);
+  const StreamShape s = stream_shape(n8, c / 8, reduce_max_blocks());
   static int kid_bn_bwd_reduce_bf16_kernel = -1;
   KTimer kt_bn_bwd_reduce_bf16_kernel(&kid_bn_bwd_reduce_bf16_kernel, "bn_bwd_reduce_bf16_kernel", as_stream(stream), (double)pixels * c * 2.0 * (act != UDASEG_ACT_NONE ? 3.0 : 2.0));
   hipLaunchKernelGGL(bn_bwd_reduce_bf16_kernel, dim3(s.grid), dim3(s.bs), 0, as_stream(stream), (const f32x4*)dz,
@@ -667,7 +635,7 @@ static int channel_sum_bf16_impl(const void* x, int64_t pixels, int c, float* ou
   UDASEG_CHECK_ARG(x && out, "channel_sum_bf16: NULL pointer");
   hipStream_t st = as_stream(stream);
   const int64_t n8 = pixels * (c / 8);
-  StreamShape s = stream_shape(n8, c / 8, REDUCE_MAX_BLOCKS);
+  StreamShape s = stream_shape(n8, c / 8, reduce_max_blocks());
   if (s.grid <= CHSUM_DIRECT_BLOCKS) {
     if (!accumulate) {
       hipError_t e = hipMemsetAsync(out, 0, (size_t)c * sizeof(float), st);

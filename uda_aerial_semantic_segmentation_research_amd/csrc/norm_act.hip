@@ -17,24 +17,8 @@ struct d4 {
   double v[4];
 };
 __device__ __forceinline__ void block_fold_add(const d4& v, double* dst, int c4, int q, d4* red) {
-  const int tid = threadIdx.x, bs = blockDim.x;
-  if (c4 >= bs) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) atomicAdd(dst + q * 4 + e, v.v[e]);
-    return;
-  }
-  red[tid] = v;
-  __syncthreads();
-  if (tid < c4) {
-    d4 s = {{0, 0, 0, 0}};
-    for (int r = tid; r < bs; r += c4) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) s.v[e] += red[r].v[e];
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) atomicAdd(dst + q * 4 + e, s.v[e]);
-  }
-  __syncthreads();
+  (void)q;
+  block_fold_atomic<4, double>(v.v, dst, c4, reinterpret_cast<double*>(red));
 }
 
 __global__ void bn_stats_kernel(const f32x4* __restrict__ y, int64_t n4, int c4, double* __restrict__ sums) {
@@ -321,28 +305,10 @@ __global__ void channel_sum_kernel(const f32x4* __restrict__ x, int64_t n4, int 
   __shared__ float4 red[256];
   const int64_t T = (int64_t)gridDim.x * blockDim.x;
   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int q = (int)(g % c4);
   f32x4 s = {0, 0, 0, 0};
   for (int64_t i = g; i < n4; i += T) s += x[i];
-  const int tid = threadIdx.x, bs = blockDim.x;
-  if (c4 >= bs) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) atomicAdd(out + q * 4 + e, s[e]);
-    return;
-  }
-  red[tid] = make_float4(s[0], s[1], s[2], s[3]);
-  __syncthreads();
-  if (tid < c4) {
-    float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    for (int r = tid; r < bs; r += c4) {
-      const float4 t = red[r];
-      a0 += t.x; a1 += t.y; a2 += t.z; a3 += t.w;
-    }
-    atomicAdd(out + q * 4 + 0, a0);
-    atomicAdd(out + q * 4 + 1, a1);
-    atomicAdd(out + q * 4 + 2, a2);
-    atomicAdd(out + q * 4 + 3, a3);
-  }
+  const float sv[4] = {s[0], s[1], s[2], s[3]};
+  block_fold_atomic<4, float>(sv, out, c4, reinterpret_cast<float*>(red));
 }
 
 // Eval mode: fold BatchNorm into the preceding conv.  w'[co][j] = w[co][j] * gamma/sqrt(var+eps); b'[co] = beta +
@@ -375,7 +341,7 @@ extern "C" int udaseg_bn_stats(const float* y, int64_t pixels, int c, double* su
   if (rc) return rc;
   UDASEG_CHECK_ARG(y && sums, "bn_stats: NULL pointer");
   const int64_t n4 = pixels * (c / 4);
-  const StreamShape s = stream_shape(n4, c / 4, REDUCE_MAX_BLOCKS);
+  const StreamShape s = stream_shape(n4, c / 4, reduce_max_blocks());
   hipLaunchKernelGGL(bn_stats_kernel, dim3(s.grid), dim3(s.bs), 0, as_stream(stream), (const f32x4*)y, n4, s.c4, sums);
   UDASEG_LAUNCH_CHECK("bn_stats launch");
   return UDASEG_OK;
@@ -423,7 +389,7 @@ extern "C" int udaseg_bn_bwd_reduce(const float* dz, const float* z, const float
   UDASEG_CHECK_ARG(act == UDASEG_ACT_NONE || z || (gamma && beta),
                    "bn_bwd_reduce: an activation follows the norm: pass z, or gamma and beta to re-evaluate its argument");
   const int64_t n4 = pixels * (c / 4);
-  const StreamShape s = stream_shape(n4, c / 4, REDUCE_MAX_BLOCKS);
+  const StreamShape s = stream_shape(n4, c / 4, reduce_max_blocks());
   static int kid_br = -1;
   KTimer kt_br(&kid_br, "bn_bwd_reduce_kernel", as_stream(stream), (double)pixels * c * 4.0 * (z ? 3.0 : 2.0));
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(s.grid), dim3(s.bs), 0, as_stream(stream), (const f32x4*)dz, (const f32x4*)z,
@@ -482,7 +448,7 @@ static int channel_sum_impl(const float* x, int64_t pixels, int c, float* out, i
   UDASEG_CHECK_ARG(x && out, "channel_sum: NULL pointer");
   hipStream_t st = as_stream(stream);
   const int64_t n4 = pixels * (c / 4);
-  StreamShape s = stream_shape(n4, c / 4, REDUCE_MAX_BLOCKS);
+  StreamShape s = stream_shape(n4, c / 4, reduce_max_blocks());
   if (s.grid <= CHSUM_DIRECT_BLOCKS) {
     if (!accumulate) {
       hipError_t e = hipMemsetAsync(out, 0, (size_t)c * sizeof(float), st);
