@@ -267,10 +267,12 @@ def roofline_leg(step, model, trainer, dtype, psteps=3, layer_table=False, pmc_t
             a[1] += fl
             a[2] += 1
     if layer_table:
-        print("kind  n  hi  wi   ci   co k s |  calls/step  ms/call   GFLOP   TFLOP/s", file=sys.stderr)
+        print("kind  n  hi  wi   ci   co k s |  calls/step  ms/call   GFLOP   TFLOP/s   alg MB   TB/s   ms/step", file=sys.stderr)
         for (kind, d), (ms, fl, cnt) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+            by = d[0] * d[1] * d[2] * d[3] * es + d[0] * d[4] * d[5] * d[6] * es + d[6] * d[7] * d[8] * d[3] * (4 if kind == 2 else es)
             print(f"{('fwd', 'dgrad', 'wgrad')[kind]:5s} {d[0]:2d} {d[1]:3d} {d[2]:3d} {d[3]:4d} {d[6]:4d} {d[7]} {d[9]} | "
-                  f"{cnt / psteps:5.1f} {ms / cnt:9.4f} {fl / cnt / 1e9:8.2f} {fl / ms / 1e9:8.1f}", file=sys.stderr)
+                  f"{cnt / psteps:5.1f} {ms / cnt:9.4f} {fl / cnt / 1e9:8.2f} {fl / ms / 1e9:8.1f} {by / 1e6:8.1f} "
+                  f"{by * cnt / ms / 1e9:6.2f} {ms / psteps:8.3f}", file=sys.stderr)
     allk = [k for k in K.prof_kernels() if k[3] > 0]
     K.prof_reset()
     kern = [k for k in allk if k[0].startswith("conv")]            # MFMA kernels: k[2] = FLOPs

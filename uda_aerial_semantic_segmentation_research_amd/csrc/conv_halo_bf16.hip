@@ -790,17 +790,34 @@ __global__ void pack_frag_batched_bf16_kernel(const __bf16* __restrict__ w16, co
   }
 }
 
-// partial sums of a many-block launch -> the f64 accumulators (replica 0); leaves the scratch zeroed for the next launch
-__global__ void halo_stats_fold_kernel(double* __restrict__ sscr, int co, double* __restrict__ stats) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;      // index into [2][co]
-  if (i >= 2 * co) return;
-  double s = 0.0;
-#pragma unroll 8
-  for (int r = 0; r < HALO_SCR_REPLICAS; ++r) {
-    s += sscr[(size_t)r * 2 * co + i];
-    sscr[(size_t)r * 2 * co + i] = 0.0;
+// partial sums of a many-block launch -> the f64 accumulators (replica 0); leaves the scratch zeroed for the next launch.
+// 16 accumulators x 16 replica groups per block: every thread has its 16 loads in flight at once and the groups fold through LDS
+// in a fixed order.  (One thread walking all 256 replicas of its accumulator took 18 us per launch, 0.27 ms of an r50 step.)
+constexpr int FOLD_W = 16, FOLD_G = 16;
+static_assert(HALO_SCR_REPLICAS % FOLD_G == 0, "replica groups");
+__global__ void __launch_bounds__(FOLD_W * FOLD_G) halo_stats_fold_kernel(double* __restrict__ sscr, int co, double* __restrict__ stats) {
+  __shared__ double part[FOLD_G][FOLD_W];
+  const int il = threadIdx.x % FOLD_W, g = threadIdx.x / FOLD_W;
+  const int i = blockIdx.x * FOLD_W + il;      // index into [2][co]
+  double v[HALO_SCR_REPLICAS / FOLD_G];
+  if (i < 2 * co) {
+#pragma unroll
+    for (int k = 0; k < HALO_SCR_REPLICAS / FOLD_G; ++k) v[k] = sscr[(size_t)(g + FOLD_G * k) * 2 * co + i];
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < HALO_SCR_REPLICAS / FOLD_G; ++k) {
+      s += v[k];
+      sscr[(size_t)(g + FOLD_G * k) * 2 * co + i] = 0.0;
+    }
+    part[g][il] = s;
   }
-  atomicAdd(stats + i, s);
+  __syncthreads();
+  if (g == 0 && i < 2 * co) {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < FOLD_G; ++k) s += part[k][il];
+    atomicAdd(stats + i, s);
+  }
 }
 
 // one caller-owned, caller-zeroed fp32 scratch per device for those partial sums (udaseg_set_stats_scratch)
@@ -843,7 +860,7 @@ static int launch_halo_t(HaloArgs a, hipStream_t s, double flops) {
   kprof_end(kid, ev, s, flops);
   UDASEG_LAUNCH_CHECK("conv_halo_bf16 launch");
   if (a.sscr != nullptr) {
-    hipLaunchKernelGGL(halo_stats_fold_kernel, dim3(cdiv(2 * a.co, 64)), dim3(64), 0, s, a.sscr, a.co, a.stats);
+    hipLaunchKernelGGL(halo_stats_fold_kernel, dim3(cdiv(2 * a.co, FOLD_W)), dim3(FOLD_W * FOLD_G), 0, s, a.sscr, a.co, a.stats);
     UDASEG_LAUNCH_CHECK("halo_stats_fold launch");
   }
   return UDASEG_OK;
@@ -940,7 +957,7 @@ bool halo_applicable(const udaseg_conv_desc* d, int gathered, int produced, int 
 //     192^2: 246 -> 126 us; the old kernel's one-K-tile launches), slower or equal in the forward direction.
 static int halo_choice(int ks, int h, int w, int n, int gathered, int produced, bool dgrad) {
   const int ov = halo_cfg_override();
-  if (ov > 0) return ov > 3 ? 3 : ov;
+  if (ov > 0) return ov > 6 ? 3 : ov;
   const long long tiles = (long long)n * cdiv(h, 8) * cdiv(w, 32);
   if (ks == 1) {
     static int off = -1;       // UDASEG_NO_STREAM=1 (A/B): without the streaming kernel only the expanding gradients pay
@@ -950,6 +967,20 @@ static int halo_choice(int ks, int h, int w, int n, int gathered, int produced, 
   }
   if (produced <= 32) return 1;
   if (produced <= 64) return 2;
+  {
+    // widths that 16 divides and 32 does not (r50 at 768^2: 48 x 48): 32-pixel-wide tiles compute a quarter of their columns
+    // outside the image; 8 x 16-pixel tiles x 64 channels instead (1.0 LDS reads per MFMA against 0.75, but no dead columns and
+    // twice the blocks on a launch that had ~1 per CU): r50 step 18.44 -> 18.13 ms; 16 x 16 tiles 18.24, x 128 channels 18.37
+    // (profiles/r03_halo_variants.txt).  UDASEG_HALO_W16 = 0 | 4 | 5 | 6 overrides.
+    static int w16 = -1;
+    if (w16 < 0) {
+      const char* e = getenv("UDASEG_HALO_W16");
+      w16 = e ? atoi(e) : 6;
+    }
+    if (w16 >= 4 && w16 <= 6 && gathered % 32 == 0 && w % 32 != 0 && w % 16 == 0 &&
+        (long long)n * cdiv(h, 8) * cdiv(w, 16) * cdiv(produced, 64) >= 256)
+      return w16;
+  }
   if (tiles * cdiv(produced, 128) >= 192) return 3;
   if (tiles * cdiv(produced, 64) >= 256) return 2;
   return 0;
@@ -963,6 +994,7 @@ int launch_halo(const udaseg_conv_desc* d, HaloArgs a, hipStream_t s, bool dgrad
   if (stream_applicable(a, d->kh)) return launch_stream(a, s, flops);
   int choice = halo_choice(d->kh, a.h, a.w, a.n, a.ci, a.co, dgrad);
   if (choice == 0) choice = a.co <= 32 ? 1 : (a.co <= 64 ? 2 : 3);     // called although not preferred (tests, UDASEG_FRAG=2)
+  if (choice > 3 && (d->kh != 3 || ck != 32)) choice = a.co <= 64 ? 2 : 3;
   if (d->kh == 3) {
     if (ck == 16) {
       if (choice == 1) return launch_halo_t<3, 16, 4, 1, 2, 32>(a, s, flops);
@@ -970,6 +1002,9 @@ int launch_halo(const udaseg_conv_desc* d, HaloArgs a, hipStream_t s, bool dgrad
     }
     if (choice == 1) return launch_halo_t<3, 32, 4, 1, 2, 32>(a, s, flops);
     if (choice == 3) return launch_halo_t<3, 32, 2, 4, 4, 32>(a, s, flops);
+    if (choice == 4) return launch_halo_t<3, 32, 2, 2, 4, 16>(a, s, flops);     // 16 x 16 pixels x 64 channels
+    if (choice == 5) return launch_halo_t<3, 32, 2, 4, 4, 16>(a, s, flops);     // 16 x 16 pixels x 128 channels
+    if (choice == 6) return launch_halo_t<3, 32, 2, 2, 2, 16>(a, s, flops);     //  8 x 16 pixels x 64 channels
     return launch_halo_t<3, 32, 2, 2, 4, 32>(a, s, flops);
   }
   // 1x1: two MFMAs per 16 channels -- long chunks, or the loop is all barriers
