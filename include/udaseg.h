@@ -393,6 +393,30 @@ int udaseg_conv2d_dgrad_frag_bf16(const udaseg_conv_desc* d, const void* dy, con
                                   const void* prev_y, const float* save_mean, const float* save_rstd, const float* gamma,
                                   const float* beta, int bn_act, float bn_slope, double* bsums, int accumulate, void* stream);
 
+/* ---- fp32 convolutions on the bf16 matrix pipe (csrc/conv_halo_f32x3.hip): fp32 NHWC tensors in and out, every operand split
+ *      exactly into three bf16 terms (x = bf16(x) + bf16(x - x0) + bf16(x - x0 - x1)), the six products with i + j <= 2 on
+ *      v_mfma_f32_32x32x16_bf16, fp32 accumulation -- one unit in the last place of each PRODUCT is left out, below the
+ *      rounding of the fp32 accumulation itself.  Stride-1 3x3 / pad 1 layers of smp.Unet (reference src/models/train.py:341,
+ *      343) in the fp32 configurations; replaces udaseg_conv2d_fwd_bnstats / _upcat / udaseg_conv2d_dgrad(_bnreduce / _split)
+ *      there.  UDASEG_F32_SPLIT=0 keeps every layer on the fp32-MFMA kernels.
+ *      Weights: three planes of the fragment packing above (plane stride udaseg_frag_elems(N, K, 3) bf16 elements), made by
+ *      udaseg_pack_frag_batched_f32x3 from the fp32 OHWI arena (mode 0) / the fp32 dgrad packing [ci][taps][co] (mode 1);
+ *      table rows as for udaseg_pack_frag_batched_bf16, dst offset = plane 0 of the entry's 3 * frag_elems block. ---- */
+int udaseg_pack_frag_batched_f32x3(const float* w32, const float* wt32, void* packed, const int* table, int entries, void* stream);
+/* can / should this (forward or data-gradient) launch take the split kernel?  preferred = the library's measured heuristic */
+int udaseg_conv_f32x3_ok(const udaseg_conv_desc* d, int dgrad, int up_ca);
+int udaseg_conv_f32x3_preferred(const udaseg_conv_desc* d, int dgrad, int up_ca);
+/* tests / tuning: 1 = 8 x 32 pixels x 32 channels per block, 2 = x 64 channels, for every launch; 0 = the heuristic again */
+int udaseg_f32x3_force_config(int cfg);
+/* y = act(conv(x) + bias); up_ca > 0: x is the half-resolution tensor of a fused decoder input cat([nearest_x2(x), skip]);
+ * stats != NULL: BatchNorm statistics of y ([R][2][co] f64, accumulated) */
+int udaseg_conv2d_fwd_f32x3(const udaseg_conv_desc* d, const float* x, const float* skip, int up_ca, const void* wfrag3,
+                            const float* bias, float* y, int act, float slope, double* stats, void* stream);
+/* dx (+)= conv_transpose(dy, w); split / prev_y / accumulate as udaseg_conv2d_dgrad_frag_bf16, on fp32 tensors */
+int udaseg_conv2d_dgrad_f32x3(const udaseg_conv_desc* d, const float* dy, const void* wfrag3_t, float* dx, float* dx2, int split,
+                              const float* prev_y, const float* save_mean, const float* save_rstd, const float* gamma,
+                              const float* beta, int bn_act, float bn_slope, double* bsums, int accumulate, void* stream);
+
 /* ---- diagnosis: while a device buffer of 6 * blocks u64 is registered, every implicit-GEMM launch of at most `blocks` blocks
  *      writes per block {entry, first tile load, end of K loop, exit} (100 MHz wall-clock ticks), HW_ID and XCC_ID into it
  *      (tools/igemm_timeline.py).  NULL switches it off.  Not for timed runs. ---- */

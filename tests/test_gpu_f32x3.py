@@ -1,0 +1,270 @@
+"""GPU parity of the fp32 convolutions on the bf16 matrix pipe (csrc/conv_halo_f32x3.hip: every fp32 operand split exactly into
+three bf16 terms, six MFMA products per operand pair, fp32 accumulation).
+
+The claim to pin: this is fp32-GRADE arithmetic.  Reference = torch's CPU convolution in float64 on the same fp32 operands; the
+split kernel's error against it is compared with the error of the fp32-MFMA kernel (conv_igemm.hip, v_mfma_f32_32x32x2_f32) on
+the same launch: norm-wise no worse than 1.25 x that + 2^-24, worst element within 2.5 x and below 3e-6 of the output's largest
+magnitude outright.
+Covered: forward (bias, activation, BatchNorm statistics), data gradient (flipped packing, accumulation, split destinations,
+BatchNorm-backward sums of the producer), the fused decoder input, ragged tiles, channel tails, both tile configurations, operands
+spanning 40 binades (the split is exact whatever the exponent), and the exactness of the split itself.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+f32, f64, bf = torch.float32, torch.float64, torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def K():
+    from uda_aerial_semantic_segmentation_research_amd import _lib, kernels
+    _lib.require_gpu()
+    kernels.ensure_workspace(torch.device("cuda", 0))
+    return kernels
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().to("cuda", f32)
+
+
+def nchw(t):
+    return t.detach().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def err(got, ref64):
+    """worst element, relative to the tensor's largest magnitude"""
+    assert got.shape == ref64.shape, (got.shape, ref64.shape)
+    assert torch.isfinite(got).all()
+    return ((got.double() - ref64).abs().max() / ref64.abs().max().clamp_min(1e-300)).item()
+
+
+def err2(got, ref64):
+    return ((got.double() - ref64).norm() / ref64.norm()).item()
+
+
+def grade(got, nat, ref64, what, cap=3e-6):
+    """fp32 grade: the split kernel's error against f64 next to the fp32-MFMA kernel's on the same launch -- norm-wise (the
+    stable statistic) within 1.25 x, the worst element (one sample of the tail) within 2.5 x, and small outright."""
+    e2, n2, em, nm = err2(got, ref64), err2(nat, ref64), err(got, ref64), err(nat, ref64)
+    print(f"{what}: l2 split {e2:.3e} fp32-MFMA {n2:.3e} | worst element split {em:.3e} fp32-MFMA {nm:.3e}")
+    assert e2 <= 1.25 * n2 + 2.0 ** -24, f"{what}: split kernel {e2:.3e} against fp32-MFMA kernel {n2:.3e} (l2)"
+    assert em <= 2.5 * nm + 2.0 ** -23 and em <= cap, f"{what}: worst element {em:.3e} against {nm:.3e}"
+
+
+def pack3(K, wt):
+    """wt: [co][ci][3][3] fp32 -> (forward planes, data-gradient planes) through the batched packer."""
+    co, ci, k, _ = wt.shape
+    w32 = wt.permute(0, 2, 3, 1).contiguous().cuda()            # OHWI
+    wt32 = wt.permute(1, 2, 3, 0).contiguous().cuda()           # [ci][kh][kw][co]
+    nf, nd = 3 * K.frag_elems(co, ci, k), 3 * K.frag_elems(ci, co, k)
+    packed = torch.full((nf + nd,), float("nan"), device="cuda", dtype=bf)
+    table = torch.tensor([[0, 0, 0, co, ci, k], [1, 0, nf, ci, co, k]], dtype=torch.int32, device="cuda")
+    K.pack_frag_batched(w32, wt32, packed, table)
+    assert torch.isfinite(packed.float()).all()                 # every element of the three planes was written
+    return packed[:nf], packed[nf:], w32, wt32
+
+
+def test_three_term_split_is_exact(K):
+    """plane0 + plane1 + plane2 == the fp32 weight, bit for bit, across 60 binades (read back through the packing's layout)."""
+    g = torch.Generator().manual_seed(5)
+    co, ci = 32, 16
+    wt = torch.randn(co, ci, 3, 3, generator=g) * torch.exp2(torch.randint(-30, 30, (co, ci, 3, 3), generator=g).float())
+    wf, _, w32, _ = pack3(K, wt)
+    nf = K.frag_elems(co, ci, 3)
+    planes = wf.view(3, nf).float().cpu().double()
+    total = planes.sum(0).view(1, 3, 1, 3, 64, 8)               # [nb][dx][k16][dy][lane][j]
+    lane = torch.arange(64)
+    n_idx, k_half = lane % 32, lane // 32
+    w = wt.double()
+    for dx in range(3):
+        for dy in range(3):
+            got = total[0, dx, 0, dy]                            # [lane][j] = W[n = lane % 32][dy][dx][k = 8 * (lane // 32) + j]
+            want = torch.stack([w[n_idx[l], 8 * k_half[l]:8 * k_half[l] + 8, dy, dx] for l in range(64)])
+            assert torch.equal(got, want), (dx, dy)
+    # magnitudes: |plane1| <= 2^-8 |w|, |plane2| <= 2^-16 |w| (round to nearest: half a unit of the term above)
+    p = wf.view(3, nf).float().cpu().abs()
+    assert (p[1] <= p[0] * 2.0 ** -8 * 1.01).all() and (p[2] <= p[0] * 2.0 ** -16 * 1.01 + 1e-45).all()
+
+
+CASES = [
+    (2, 16, 32, 64, 64), (1, 8, 32, 256, 256), (2, 64, 64, 64, 64), (1, 24, 40, 32, 16), (1, 24, 24, 16, 24),
+    (1, 12, 20, 192, 64), (2, 32, 32, 32, 32), (1, 10, 14, 16, 16), (2, 20, 36, 128, 128), (1, 9, 33, 48, 40),
+    (1, 5, 70, 32, 96), (1, 16, 48, 512, 128), (1, 40, 40, 24, 8), (8, 32, 32, 256, 256),
+]
+
+
+@pytest.fixture
+def force_cfg(K):
+    from uda_aerial_semantic_segmentation_research_amd import _lib
+    lib = _lib.load()
+    yield lambda c: lib.udaseg_f32x3_force_config(c)
+    lib.udaseg_f32x3_force_config(0)
+
+
+@pytest.mark.parametrize("case", CASES, ids=[("n%d_%dx%d_ci%d_co%d" % c) for c in CASES])
+@pytest.mark.parametrize("cfg", [0, 1, 2], ids=["heuristic", "32ch_blocks", "64ch_blocks"])
+def test_conv_f32x3_fwd_dgrad_fp32_grade(K, case, cfg, force_cfg):
+    n, h, w, ci, co = case
+    force_cfg(cfg)
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(n, ci, h, w, generator=g)
+    wt = torch.randn(co, ci, 3, 3, generator=g) / math.sqrt(ci * 9)
+    bias = torch.randn(co, generator=g)
+    xr = x.double().requires_grad_(True)
+    y_ref = F.conv2d(xr, wt.double(), bias.double(), padding=1)
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy.double())
+    d = K.conv_desc(n, h, w, ci, co, 3, 1, 1)
+    assert K.conv_frag_ok(d, f32=True) and K.conv_frag_ok(d, dgrad=True, f32=True)
+    wf, wfd, w32, wt32 = pack3(K, wt)
+    xd, R = nhwc(x), K.bn_replicas()
+    y = torch.full((n, h, w, co), float("nan"), device="cuda", dtype=f32)
+    st = torch.zeros(R * 2 * co, dtype=f64, device="cuda")
+    K.conv2d_fwd_frag(d, xd, None, wf, bias.cuda(), y, stats=st)
+    y_nat = torch.empty_like(y)
+    K.conv2d_fwd(d, xd, w32, bias.cuda(), y_nat, 0, 0.0, False)
+    grade(nchw(y), nchw(y_nat), y_ref.detach(), "forward")
+    tot = st.view(R, 2, co).sum(0).cpu()
+    yd = y_ref.detach().permute(0, 2, 3, 1).reshape(-1, co)
+    assert (tot[0] - yd.sum(0)).abs().max().item() <= 1e-5 * yd.abs().sum(0).max().item(), "fused sum"
+    assert ((tot[1] - (yd * yd).sum(0)).abs().max() / (yd * yd).sum(0).max()).item() <= 1e-5, "fused sum of squares"
+    # activation in the epilogue
+    y2 = torch.full_like(y, float("nan"))
+    K.conv2d_fwd_frag(d, xd, None, wf, bias.cuda(), y2, act=1, slope=0.2)
+    assert err(nchw(y2), F.leaky_relu(y_ref.detach(), 0.2)) <= 3e-6
+    # data gradient
+    dyd = nhwc(dy)
+    dx = torch.full((n, h, w, ci), float("nan"), device="cuda", dtype=f32)
+    K.conv2d_dgrad_frag(d, dyd, wfd, dx)
+    dx_nat = torch.empty_like(dx)
+    K.conv2d_dgrad(d, dyd, wt32, dx_nat, False)
+    grade(nchw(dx), nchw(dx_nat), xr.grad, "data gradient")
+    # accumulation onto an existing gradient
+    base = torch.randn(n, ci, h, w, generator=g)
+    dxa = nhwc(base)
+    K.conv2d_dgrad_frag(d, dyd, wfd, dxa, accumulate=True)
+    assert err(nchw(dxa), xr.grad + base.double()) <= 3e-6
+
+
+def test_wide_dynamic_range_operands(K):
+    """Operands spread over 40 binades per tensor: the split is exact at every exponent, so the error stays at fp32 grade
+    relative to the f64 result (a bf16 or a two-term computation would be off by 2^-8 / 2^-16)."""
+    g = torch.Generator().manual_seed(77)
+    n, h, w, ci, co = 1, 16, 32, 64, 64
+    x = torch.randn(n, ci, h, w, generator=g) * torch.exp2(torch.randint(-20, 20, (n, ci, h, w), generator=g).float())
+    wt = torch.randn(co, ci, 3, 3, generator=g) * torch.exp2(torch.randint(-20, 20, (co, ci, 3, 3), generator=g).float())
+    y_ref = F.conv2d(x.double(), wt.double(), padding=1)
+    d = K.conv_desc(n, h, w, ci, co, 3, 1, 1)
+    wf, _, w32, _ = pack3(K, wt)
+    y = torch.empty((n, h, w, co), device="cuda", dtype=f32)
+    K.conv2d_fwd_frag(d, nhwc(x), None, wf, None, y)
+    y_nat = torch.empty_like(y)
+    K.conv2d_fwd(d, nhwc(x), w32, None, y_nat, 0, 0.0, False)
+    # element-wise against the magnitude of each output's own terms: sum |x||w|
+    scale = F.conv2d(x.double().abs(), wt.double().abs(), padding=1)
+    e = ((nchw(y).double() - y_ref).abs() / scale).max().item()
+    e_nat = ((nchw(y_nat).double() - y_ref).abs() / scale).max().item()
+    print(f"wide range: split {e:.3e} fp32-MFMA {e_nat:.3e} (per-output, relative to sum |x||w|)")
+    assert e <= 1.5 * e_nat + 2.0 ** -23 and e <= 2e-6
+
+
+@pytest.mark.parametrize("n,h,w,c1,c2,act,slope", [(4, 64, 64, 64, 64, 1, 0.0), (2, 32, 32, 256, 128, 1, 0.0),
+                                                    (3, 9, 7, 40, 64, 1, 0.2), (2, 24, 24, 16, 32, 1, 0.0)])
+def test_dgrad_with_bn_backward_reductions(K, n, h, w, c1, c2, act, slope):
+    """The epilogue's BatchNorm-backward sums of the producing layer == the fp32-MFMA kernel's fused sums on the same launch
+    (udaseg_conv2d_dgrad_bnreduce) and == the definition in f64."""
+    g = torch.Generator().manual_seed(n * 1000 + h + c1)
+    R = K.bn_replicas()
+    wt = torch.randn(c2, c1, 3, 3, generator=g) / math.sqrt(c1 * 9)
+    dy = torch.randn(n, c2, h, w, generator=g)
+    prev_y = torch.randn(n, h, w, c1, generator=g)
+    mean, var = prev_y.reshape(-1, c1).mean(0), prev_y.reshape(-1, c1).var(0, unbiased=False)
+    rstd = (var + 1e-5).rsqrt()
+    gamma, beta = torch.rand(c1, generator=g) + 0.5, torch.randn(c1, generator=g) * 0.3
+    d = K.conv_desc(n, h, w, c1, c2, 3, 1, 1)
+    _, wfd, _, wt32 = pack3(K, wt)
+    dyd = nhwc(dy)
+    dx = torch.full((n, h, w, c1), float("nan"), device="cuda", dtype=f32)
+    bs = torch.zeros(R * 2 * c1, dtype=f64, device="cuda")
+    K.conv2d_dgrad_frag(d, dyd, wfd, dx, bn=(prev_y.cuda(), mean.cuda(), rstd.cuda(), gamma.cuda(), beta.cuda(), act, slope, bs))
+    dx_plain = torch.empty_like(dx)
+    K.conv2d_dgrad_frag(d, dyd, wfd, dx_plain)
+    assert torch.equal(dx, dx_plain)                            # the sums do not disturb the gradient
+    # definition, in f64, from the gradient the kernel stored
+    gz = dx.cpu().double().reshape(-1, c1)
+    yy = prev_y.double().reshape(-1, c1)
+    sc = (gamma * rstd).double()
+    arg = yy * sc + (beta.double() - mean.double() * sc)
+    mask = torch.where(arg > 0, torch.ones_like(arg), torch.full_like(arg, slope))
+    gg = gz * mask
+    s1, s2 = gg.sum(0), (gg * (yy - mean.double()) * rstd.double()).sum(0)
+    tot = bs.view(R, 2, c1).sum(0).cpu()
+    assert ((tot[0] - s1).abs().max() / s1.abs().max()).item() <= 1e-5
+    assert ((tot[1] - s2).abs().max() / s2.abs().max()).item() <= 1e-5
+
+
+@pytest.mark.parametrize("n,h,w,ca,cs,co", [(2, 16, 32, 64, 32, 64), (1, 20, 36, 32, 32, 32), (2, 32, 64, 32, 0, 16),
+                                            (1, 8, 64, 512, 256, 256)])
+def test_fused_decoder_input_and_split_gradient(K, n, h, w, ca, cs, co):
+    """cat([nearest_x2(a), skip]) gathered while the halo is staged; the data gradient split over the two sources."""
+    g = torch.Generator().manual_seed(ca + cs + co)
+    a = torch.randn(n, ca, h // 2, w // 2, generator=g)
+    skip = torch.randn(n, cs, h, w, generator=g) if cs else None
+    ci = ca + cs
+    wt = torch.randn(co, ci, 3, 3, generator=g) / math.sqrt(ci * 9)
+    up = F.interpolate(a, scale_factor=2, mode="nearest")
+    xin = (torch.cat([up, skip], 1) if cs else up).double().requires_grad_(True)
+    y_ref = F.conv2d(xin, wt.double(), padding=1)
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy.double())
+    d = K.conv_desc(n, h, w, ci, co, 3, 1, 1)
+    assert K.conv_frag_ok(d, up_ca=ca, f32=True)
+    wf, wfd, _, _ = pack3(K, wt)
+    y = torch.full((n, h, w, co), float("nan"), device="cuda", dtype=f32)
+    K.conv2d_fwd_frag(d, nhwc(a), nhwc(skip) if cs else None, wf, None, y, up=True)
+    assert err(nchw(y), y_ref.detach()) <= 3e-6
+    d_up = torch.full((n, h, w, ca), float("nan"), device="cuda", dtype=f32)
+    d_skip = torch.full((n, h, w, cs), float("nan"), device="cuda", dtype=f32) if cs else None
+    K.conv2d_dgrad_frag(d, nhwc(dy), wfd, d_up, d_skip)
+    assert err(nchw(d_up), xin.grad[:, :ca]) <= 3e-6
+    if cs:
+        assert err(nchw(d_skip), xin.grad[:, ca:]) <= 3e-6
+
+
+def test_network_step_matches_fp32_mfma_path(K, monkeypatch):
+    """One r18-Unet training step with the split kernels against the same step on the fp32-MFMA kernels: logits and loss agree to
+    fp32 rounding noise.  Gradients: two different fp32 evaluations of the forward disagree on the SIGN of a few pre-activations
+    within rounding distance of zero, and each such ReLU-mask flip moves one gradient element by its full size (measured with
+    tools: one flip in 98304 elements = 4e-3 of the tensor's norm; the per-call data gradients themselves agree to 1e-6) -- so
+    the last layers (behind no flipped mask) are compared tightly and the whole gradient by direction."""
+    from uda_aerial_semantic_segmentation_research_amd import engine
+    from uda_aerial_semantic_segmentation_research_amd.losses import CrossEntropyLoss
+    from uda_aerial_semantic_segmentation_research_amd.unet import Unet
+    monkeypatch.setattr(engine, "FRAG_POLICY", "always")
+    torch.manual_seed(3)
+    x = torch.randn(2, 3, 64, 96, device="cuda")
+    yl = torch.randint(0, 23, (2, 64, 96), device="cuda")
+    outs = []
+    for split in (True, False):
+        monkeypatch.setattr(engine, "USE_F32_SPLIT", split)
+        torch.manual_seed(11)
+        net = Unet("resnet18", encoder_weights=None, in_channels=3, classes=23).cuda().train()
+        assert (getattr(net, "_frag_arena", None) is not None) == split
+        logits = net(x)
+        loss = CrossEntropyLoss()(logits, yl)
+        loss.backward()
+        outs.append((logits.detach().clone(), loss.item(), {k: p.grad.detach().clone() for k, p in net.named_parameters()}))
+    (la, lossa, ga), (lb, lossb, gb) = outs
+    e_logits = ((la - lb).abs().max() / lb.abs().max()).item()
+    fa, fb = torch.cat([v.flatten() for v in ga.values()]).double(), torch.cat([v.flatten() for v in gb.values()]).double()
+    cos = (fa @ fb / (fa.norm() * fb.norm())).item()
+    e_head = max(((ga[k] - gb[k]).norm() / gb[k].norm()).item() for k in ga if k.startswith("segmentation_head"))
+    print(f"split vs fp32-MFMA network step: logits {e_logits:.3e} loss {abs(lossa - lossb):.3e} head grads {e_head:.3e} "
+          f"1 - cos(all grads) {1 - cos:.3e}")
+    assert e_logits <= 2e-5 and abs(lossa - lossb) <= 1e-5 * abs(lossb)
+    assert e_head <= 1e-5 and cos >= 0.9995

@@ -460,16 +460,20 @@ def test_bn_backward_reductions_in_the_dgrad_epilogue(pkg):
     x, y, _ = synthetic_batch(8, 256, 256, seed=6)
     xd, yd = x.cuda(), y.cuda()
     calls = {"fused": 0, "reduce": 0}
-    orig_f, orig_r = K.conv2d_dgrad_bnreduce, K.bn_bwd_reduce
+    orig_f, orig_r, orig_h = K.conv2d_dgrad_bnreduce, K.bn_bwd_reduce, K.conv2d_dgrad_frag
 
     def count_f(*a, **k):
         calls["fused"] += 1
         return orig_f(*a, **k)
 
+    def count_h(*a, **k):          # the halo-resident data gradient (fp32: three-term split) with the sums in its epilogue
+        calls["fused"] += int(k.get("bn") is not None)
+        return orig_h(*a, **k)
+
     def count_r(*a, **k):
         calls["reduce"] += 1
         return orig_r(*a, **k)
-    K.conv2d_dgrad_bnreduce, K.bn_bwd_reduce = count_f, count_r
+    K.conv2d_dgrad_bnreduce, K.bn_bwd_reduce, K.conv2d_dgrad_frag = count_f, count_r, count_h
     out = {}
     try:
         for fused in (False, True):
@@ -480,7 +484,7 @@ def test_bn_backward_reductions_in_the_dgrad_epilogue(pkg):
             out[fused] = (net._grad_arena.clone(), dict(calls))
     finally:
         E.FUSE_BN_REDUCE = True
-        K.conv2d_dgrad_bnreduce, K.bn_bwd_reduce = orig_f, orig_r
+        K.conv2d_dgrad_bnreduce, K.bn_bwd_reduce, K.conv2d_dgrad_frag = orig_f, orig_r, orig_h
     assert out[False][1]["fused"] == 0 and out[False][1]["reduce"] == 30
     assert out[True][1]["fused"] >= 4 and out[True][1]["fused"] + out[True][1]["reduce"] == 30, out[True][1]
     e = ((out[True][0] - out[False][0]).abs().max() / out[False][0].abs().max()).item()

@@ -120,6 +120,12 @@ SIGNATURES = {
     "udaseg_conv_frag_preferred": (_I, [_D, _I, _I]),
     "udaseg_conv2d_fwd_frag_bf16": (_I, [_D, _P, _P, _I, _P, _P, _P, _P, _I, _F, _P, _I, _I, _F, _P, _P]),
     "udaseg_conv2d_dgrad_frag_bf16": (_I, [_D, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _F, _P, _I, _P]),
+    "udaseg_pack_frag_batched_f32x3": (_I, [_P, _P, _P, _P, _I, _P]),
+    "udaseg_conv_f32x3_ok": (_I, [_D, _I, _I]),
+    "udaseg_f32x3_force_config": (_I, [_I]),
+    "udaseg_conv_f32x3_preferred": (_I, [_D, _I, _I]),
+    "udaseg_conv2d_fwd_f32x3": (_I, [_D, _P, _P, _I, _P, _P, _P, _I, _F, _P, _P]),
+    "udaseg_conv2d_dgrad_f32x3": (_I, [_D, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _F, _P, _I, _P]),
     "udaseg_set_workspace": (_I, [_P, C.c_size_t]),
     "udaseg_workspace_bytes": (C.c_size_t, [_P]),
     "udaseg_debug_set_timeline": (_I, [_P, _I]),

@@ -22,12 +22,10 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "halo_common.h"
 
 namespace udaseg {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct HaloArgs {
   const void* x;        // gathered tensor [n][h][w][cx] bf16, or the HALF-resolution tensor a [n][h/2][w/2][up_ca] (up_ca > 0)
@@ -67,8 +65,6 @@ struct HaloArgs {
 extern unsigned long long* g_timeline;
 extern int g_timeline_blocks;
 
-constexpr int HALO_STATS_REPLICAS = 16;   // == udaseg_bn_replicas()
-constexpr int HALO_SCR_REPLICAS = 256;
 
 template <int KS, int CK, int WM, int WN, int RPW, int TW>
 struct HaloCfg {
@@ -91,48 +87,6 @@ struct HaloCfg {
   static constexpr int LDS = LDS_HALO + LDS_W;     // (the statistics reduction reuses the halo region: 2 * NW * 32 floats)
   static_assert(LDS_HALO >= 2 * NW * 32 * 4 && LDS_HALO % 16 == 0, "reduction scratch fits the halo region");
 };
-
-__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
-  return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)a) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)b) << 16);
-}
-__device__ __forceinline__ float bf_lo(unsigned d) { return __builtin_bit_cast(float, d << 16); }
-__device__ __forceinline__ float bf_hi(unsigned d) { return __builtin_bit_cast(float, d & 0xffff0000u); }
-
-// Sum over the 32 lanes of a half-wave (lane bits 0..4), in the vector ALU: four rotations inside each 16-lane row, then lane 15
-// of rows 0 / 2 is broadcast into rows 1 / 3 -- the totals of the low / high half-wave end up in lanes 16..31 / 48..63.
-// (The first version used five __shfl_xor steps = ds_bpermute: 320 LDS crossbar operations per wave per tile; the in-kernel
-// timeline showed the epilogue at 6.5 us of a 15 us block, profiles/r03_halo_timeline.txt.)
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_mov(float old, float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL,
-                                                               ROW_MASK, 0xf, false));
-}
-__device__ __forceinline__ float halfwave_sum(float x) {
-  x += dpp_mov<0x128, 0xf>(0.f, x);   // row_ror:8
-  x += dpp_mov<0x124, 0xf>(0.f, x);   // row_ror:4
-  x += dpp_mov<0x122, 0xf>(0.f, x);   // row_ror:2
-  x += dpp_mov<0x121, 0xf>(0.f, x);   // row_ror:1   -> every lane holds its row's total
-  x += dpp_mov<0x142, 0xa>(0.f, x);   // row_bcast:15 into rows 1 and 3 (rows 0 and 2 add 0)
-  return x;
-}
-// The same reduction over N values at once with the add and the lane movement in ONE instruction (v_add_f32_dpp; hipcc emits
-// v_mov_b32_dpp + v_add_f32 for the form above).  Step-major order: two dependent DPP operations on a register are N
-// instructions apart, which covers the two wait states a DPP read needs behind a VALU write of its source (the compiler
-// does not see into the asm).
-template <int N>
-__device__ __forceinline__ void halfwave_sum_n(float (&x)[N]) {
-  static_assert(N >= 4, "spacing of dependent DPP operations");
-#pragma unroll
-  for (int v = 0; v < N; ++v) asm volatile("v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf" : "+v"(x[v]));
-#pragma unroll
-  for (int v = 0; v < N; ++v) asm volatile("v_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf" : "+v"(x[v]));
-#pragma unroll
-  for (int v = 0; v < N; ++v) asm volatile("v_add_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf" : "+v"(x[v]));
-#pragma unroll
-  for (int v = 0; v < N; ++v) asm volatile("v_add_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf" : "+v"(x[v]));
-#pragma unroll
-  for (int v = 0; v < N; ++v) asm volatile("v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(x[v]));
-}
 
 template <int KS, int CK, int WM, int WN, int RPW, int TW>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_halo_bf16_kernel(const HaloArgs a) {
@@ -824,6 +778,18 @@ __global__ void __launch_bounds__(FOLD_W * FOLD_G) halo_stats_fold_kernel(double
 static double* g_sscr[16] = {};
 static size_t g_sscr_bytes[16] = {};
 
+double* halo_stats_scratch(int co) {
+  int dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16 && g_sscr[dev] != nullptr &&
+      (size_t)HALO_SCR_REPLICAS * 2 * co * sizeof(double) <= g_sscr_bytes[dev])
+    return g_sscr[dev];
+  return nullptr;
+}
+
+void launch_halo_stats_fold(double* sscr, int co, double* stats, hipStream_t s) {
+  hipLaunchKernelGGL(halo_stats_fold_kernel, dim3(cdiv(2 * co, FOLD_W)), dim3(FOLD_W * FOLD_G), 0, s, sscr, co, stats);
+}
+
 // ------------------------------------------------------------------------------------------------- host side
 template <int KS, int CK, int WM, int WN, int RPW, int TW>
 static int launch_halo_t(HaloArgs a, hipStream_t s, double flops) {
@@ -843,12 +809,7 @@ static int launch_halo_t(HaloArgs a, hipStream_t s, double flops) {
   if (blocks <= 0) return UDASEG_OK;
   a.timeline = (g_timeline && blocks <= g_timeline_blocks) ? g_timeline : nullptr;
   a.sscr = nullptr;
-  if (a.stats != nullptr && blocks > 1024) {
-    int dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16 && g_sscr[dev] != nullptr &&
-        (size_t)HALO_SCR_REPLICAS * 2 * a.co * sizeof(double) <= g_sscr_bytes[dev])
-      a.sscr = g_sscr[dev];
-  }
+  if (a.stats != nullptr && blocks > 1024) a.sscr = halo_stats_scratch(a.co);
   static int kid = -1;
   if (kid < 0) {
     char nm[96];
@@ -860,7 +821,7 @@ static int launch_halo_t(HaloArgs a, hipStream_t s, double flops) {
   kprof_end(kid, ev, s, flops);
   UDASEG_LAUNCH_CHECK("conv_halo_bf16 launch");
   if (a.sscr != nullptr) {
-    hipLaunchKernelGGL(halo_stats_fold_kernel, dim3(cdiv(2 * a.co, FOLD_W)), dim3(FOLD_W * FOLD_G), 0, s, a.sscr, a.co, a.stats);
+    launch_halo_stats_fold(a.sscr, a.co, a.stats, s);
     UDASEG_LAUNCH_CHECK("halo_stats_fold launch");
   }
   return UDASEG_OK;

@@ -1,0 +1,603 @@
+// fp32 convolutions on the bf16 matrix pipe (round 3): stride-1 3x3 / pad 1 convolutions, forward and data gradient, NHWC fp32
+// storage in and out, every operand split EXACTLY into three bf16 terms, six v_mfma_f32_32x32x16_bf16 products per operand pair,
+// fp32 accumulation (gfx950).
+//
+// Replaces, for the fp32 configurations (BASELINE cfg 1 / 2 / 4: the headline), conv_igemm.hip's v_mfma_f32_32x32x2_f32 path on
+// the layers torch.nn.functional.conv2d / its autograd reach from smp.Unet.forward (reference src/models/train.py:341,343).
+//
+// Why: CDNA4's fp32 MFMA peak is 157 TFLOP/s, its dense bf16 peak 2.5 PFLOP/s -- a 32x32x16 block of products costs 512 cycles
+// of a SIMD's matrix pipe as fp32 and 32 as bf16.  An fp32 number has a 24-bit significand, a bf16 number 8 bits with the same
+// exponent range, so  x = x0 + x1 + x2  with x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1)  holds EXACTLY (both
+// subtractions are exact in fp32; outside overflow / the subnormal range).  Then
+//   a * b = sum_{i,j} a_i b_j ,   |a_i b_j| <= 2^(-8 (i + j)) |a b| ,
+// and the six products with i + j <= 2 leave out a1 b2 + a2 b1 + a2 b2 <= 2^-23 |a b| (1 + 2^-9): ONE fp32 unit in the last
+// place of the product, below what the fp32 accumulation rounds away at every step anyway (tests/test_gpu_f32x3.py measures
+// this kernel and the fp32-MFMA kernel against an f64 convolution: same error).  Six bf16 MFMAs = 192 cycles against 512: the
+// matrix pipe does the same fp32-grade arithmetic 2.7 times faster, and the 3x3 layers stop being bound by it alone.
+//
+// Structure (the halo scheme of conv_halo_bf16.hip, re-balanced for 6x the MFMA work per staged byte):
+//   * a block owns TH x 32 output pixels x 32 WN channels; the (TH+2) x 34 input halo of a 16-channel chunk is loaded ONCE as
+//     fp32, split in registers and written to three bf16 planes in LDS (32-byte pixel rows, the two 16-byte K halves swapped
+//     on every other group of 8 pixels: conflict-free ds_read_b128 without padding);
+//   * the weights arrive pre-split and pre-packed in MFMA-fragment order (udaseg_pack_frag_batched_f32x3: three planes of the
+//     bf16 kernel's packing) and pass through a double-buffered LDS stage one (dx) group ahead of their use;
+//   * operands swapped as in the bf16 kernel (weights = MFMA A, pixels = MFMA B): an accumulator lane holds 4 consecutive
+//     channels of one pixel and stores them as one 16-byte fp32 piece straight from registers;
+//   * the fused decoder input, the split data gradient, BatchNorm statistics of the output, BatchNorm-backward sums of the
+//     producer (data gradient) and accumulation into the destination are the bf16 kernel's options, on fp32 tensors.
+// inf / values within 2^-8 of FLT_MAX: x0 rounds to inf and the remainders become NaN -- such activations are already lost.
+#include <stdlib.h>
+
+#include "common.h"
+#include "halo_common.h"
+
+namespace udaseg {
+
+struct F3Args {
+  const float* x;       // gathered tensor (forward: input; data gradient: dy), or the half-resolution `a` of a fused decoder input
+  const float* x2;      // fused decoder input: the skip tensor (channels [up_ca, ci)), or nullptr when the input is nearest_x2(a)
+  const void* wf;       // [3][frag_elems] bf16: the three split planes, each packed[nb][dx][k16][dy][lane][8]
+  const float* bias;
+  float* y;             // produced tensor; split_n > 0: channels [0, split_n) here, the rest in y2
+  float* y2;
+  int n, h, w, ci, co;  // ci = gathered channels, co = produced channels of THIS launch
+  int up_ca, split_n, accumulate, act;
+  float slope;
+  double* stats;        // [R][2][co] f64: BatchNorm statistics of the output, or the bnb_* sums
+  double* sscr;         // launches of > 1024 blocks: f64 partial sums (see HaloArgs::sscr)
+  const float* bnb_y;   // data gradient: conv output of the producing conv+BN+activation layer -> its BatchNorm-backward sums
+  const float* bnb_mean;
+  const float* bnb_rstd;
+  const float* bnb_gamma;
+  const float* bnb_beta;
+  int bnb_act;
+  float bnb_slope;
+  int ntx, nty, ncb, nk16;
+  unsigned x_bytes, x2_bytes, w_plane_bytes, y_bytes, y2_bytes, bnb_bytes;
+};
+
+template <int WM, int WN, int RPW>
+struct F3Cfg {
+  static constexpr int NT = 64 * WM * WN;
+  static constexpr int TH = WM * RPW, TW = 32;
+  static constexpr int HR = TH + 2, HWD = TW + 2;
+  static constexpr int PLANE = HR * HWD * 32;           // one bf16 plane of a 16-channel halo chunk
+  static constexpr int LDS_HALO = 3 * PLANE;
+  static constexpr int NPIECE = HR * HWD * 2;           // (halo pixel, 8-channel octet)
+  static constexpr int NI = (NPIECE + NT - 1) / NT;
+  static constexpr int S = RPW + 2;                     // halo rows a wave reads per (dx) group
+  static constexpr int NW = WM * WN;
+  static constexpr int NFG = WN * 9;                    // weight fragments of a (chunk, dx) group: [wn][dy][plane]
+  static constexpr int NWI = (NFG + NW - 1) / NW;
+  static constexpr int LDS_WBUF = NFG * 1024;
+  static constexpr int LDS = LDS_HALO + 2 * LDS_WBUF;
+  static_assert(LDS_HALO >= 2 * NW * 32 * 4, "reduction scratch fits the halo region");
+};
+
+// x = p0 + p1 + p2 exactly, eight values at a time (two 16-byte fp32 pieces -> three bf16x8 fragments pieces)
+__device__ __forceinline__ void split3(const u32x4 lo, const u32x4 hi, u32x4& p0, u32x4& p1, u32x4& p2) {
+  const f32x4 lf = __builtin_bit_cast(f32x4, lo), hf = __builtin_bit_cast(f32x4, hi);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float a = e < 2 ? lf[2 * e] : hf[2 * e - 4];
+    float b = e < 2 ? lf[2 * e + 1] : hf[2 * e - 3];
+    const unsigned h = pack_bf16x2(a, b);
+    a -= bf_lo(h);
+    b -= bf_hi(h);
+    const unsigned m = pack_bf16x2(a, b);
+    a -= bf_lo(m);
+    b -= bf_hi(m);
+    p0[e] = h;
+    p1[e] = m;
+    p2[e] = pack_bf16x2(a, b);
+  }
+}
+
+template <int WM, int WN, int RPW>
+__global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_f32x3_kernel(const F3Args a) {
+  using C = F3Cfg<WM, WN, RPW>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lp = lane & 31, lh = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+
+  // ---- block -> (image, tile, channel block); XCD-aware as in conv_halo_bf16_kernel
+  int bid = blockIdx.x;
+  {
+    const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int cb = bid % a.ncb;
+  int t = bid / a.ncb;
+  const int tx = t % a.ntx;
+  t /= a.ntx;
+  const int ty = t % a.nty;
+  const int img = t / a.nty;
+  const int y0 = ty * C::TH, x0 = tx * C::TW;
+  const int H = a.h, W = a.w;
+
+  // ---- staging slots: piece = tid + i * NT -> (halo pixel, octet of the 16-channel chunk)
+  const int oct = tid & 1;
+  unsigned voff[C::NI], voff2[C::NI], soffl[C::NI];
+  const bool UPC = a.up_ca > 0;
+  const int cx = UPC ? a.up_ca : a.ci, cx2 = a.ci - a.up_ca;
+#pragma unroll
+  for (int i = 0; i < C::NI; ++i) {
+    const int piece = tid + i * C::NT;
+    const int pix = piece >> 1;
+    const int hy = pix / C::HWD, hx = pix - hy * C::HWD;
+    const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+    const bool ok = piece < C::NPIECE && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+    if (UPC) {
+      voff[i] = ok ? (unsigned)((((img * (H >> 1) + (iy >> 1)) * (W >> 1) + (ix >> 1)) * cx + oct * 8) * 4) : 0x80000000u;
+      voff2[i] = ok ? (unsigned)((((img * H + iy) * W + ix) * cx2 + oct * 8) * 4) : 0x80000000u;
+    } else {
+      voff[i] = ok ? (unsigned)((((img * H + iy) * W + ix) * cx + oct * 8) * 4) : 0x80000000u;
+      voff2[i] = 0x80000000u;
+    }
+    // LDS slot of the piece: 32-byte pixel rows, the K halves swapped where bit 3 of the halo column is set
+    soffl[i] = (unsigned)(pix * 32 + ((oct ^ ((hx >> 3) & 1)) * 16));
+  }
+  __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_x2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(UPC && a.x2 ? a.x2 : a.x), 0,
+                                                                   (int)(UPC && a.x2 ? a.x2_bytes : 0u), 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wf), 0, (int)(3u * a.w_plane_bytes), 0x00020000);
+
+  // ---- this wave's channel block
+  const int nblocks32 = (a.co + 31) >> 5;
+  int nb = cb * WN + wn;
+  const bool wave_live = nb < nblocks32;
+  if (!wave_live) nb = 0;
+
+  // ---- weight staging: the WN x 3 (dy) x 3 (plane) fragments of a (chunk, dx) group, 1 KB each, loaded by the waves round-robin
+  const int frag_per_nb = 3 * a.nk16 * 3;          // fragments of one 32-channel block in a plane
+  int wbase[C::NWI];
+  const unsigned wlane16 = (unsigned)lane * 16u;
+#pragma unroll
+  for (int i = 0; i < C::NWI; ++i) {
+    const int q = wave + C::NW * i;                // slot of the group: ((wq * 3 + dy) * 3 + plane)
+    const int wq = q / 9, rem = q - wq * 9;
+    const int dy = rem / 3, pl = rem - dy * 3;
+    const int nbq = cb * WN + wq;
+    const bool live = q < C::NFG && nbq < nblocks32;
+    wbase[i] = live ? (int)(pl * a.w_plane_bytes) + (nbq * frag_per_nb + dy) * 1024 : -1;
+  }
+  char* wlds = smem + C::LDS_HALO;
+  const int wrd = (wn * 9) * 1024 + lane * 16;
+
+  // pixel fragment address per dx: lane pixel lp of a row, K half lh (swapped where bit 3 of the halo column is set)
+  int poff[3];
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx) {
+    const int hx = lp + dx;
+    poff[dx] = (wm * RPW * C::HWD + hx) * 32 + ((lh ^ ((hx >> 3) & 1)) * 16);
+  }
+
+  f32x16 acc[RPW];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[r][v] = 0.f;
+
+  const int nchunk = (a.ci + 15) >> 4;
+  u32x4 stage[C::NI][2];
+  auto load_chunk = [&](int c) {
+    const int cbeg = c * 16;
+    const bool second = UPC && cbeg >= a.up_ca;
+    const int soff = (second ? cbeg - a.up_ca : cbeg) * 4;
+    const unsigned kill = (cbeg + oct * 8 < a.ci) ? 0u : 0x80000000u;     // channel tail: zeros, not the next pixel
+    if (second) {
+#pragma unroll
+      for (int i = 0; i < C::NI; ++i) {
+        stage[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_x2, (int)(voff2[i] | kill), soff, 0);
+        stage[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_x2, (int)(voff2[i] | kill), soff + 16, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < C::NI; ++i) {
+        stage[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(voff[i] | kill), soff, 0);
+        stage[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(voff[i] | kill), soff + 16, 0);
+      }
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int i = 0; i < C::NI; ++i) {
+      if (i < C::NI - 1 || tid + i * C::NT < C::NPIECE) {
+        u32x4 p0, p1, p2;
+        split3(stage[i][0], stage[i][1], p0, p1, p2);
+        *reinterpret_cast<u32x4*>(smem + soffl[i]) = p0;
+        *reinterpret_cast<u32x4*>(smem + C::PLANE + soffl[i]) = p1;
+        *reinterpret_cast<u32x4*>(smem + 2 * C::PLANE + soffl[i]) = p2;
+      }
+    }
+  };
+  u32x4 wstage[C::NWI];
+  auto load_w = [&](int c, int dx) {
+    const int soff = (dx * a.nk16 + c) * 3 * 1024;
+#pragma unroll
+    for (int i = 0; i < C::NWI; ++i)
+      wstage[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wbase[i] < 0 ? 0x80000000u : wlane16), wbase[i] < 0 ? 0 : wbase[i] + soff, 0);
+  };
+  auto store_w = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < C::NWI; ++i) {
+      const int q = wave + C::NW * i;
+      if (i < C::NWI - 1 || q < C::NFG) *reinterpret_cast<u32x4*>(wlds + buf * C::LDS_WBUF + q * 1024 + lane * 16) = wstage[i];
+    }
+  };
+
+  load_w(0, 0);
+  load_chunk(0);
+  int gbuf = 0;
+  for (int c = 0; c < nchunk; ++c) {
+    store_chunk();
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      store_w(gbuf);
+      __syncthreads();               // this group's weights (and, at dx == 0, the chunk's halo) are visible
+      if (dx < 2) load_w(c, dx + 1);
+      else if (c + 1 < nchunk) load_w(c + 1, 0);
+      if (dx == 0 && c + 1 < nchunk) load_chunk(c + 1);
+      const char* wb = wlds + gbuf * C::LDS_WBUF + wrd;
+      u32x4 bf[3][3];
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) bf[dy][pl] = *reinterpret_cast<const u32x4*>(wb + (dy * 3 + pl) * 1024);
+#pragma unroll
+      for (int s = 0; s < C::S; ++s) {
+        u32x4 pf[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          pf[pl] = *reinterpret_cast<const u32x4*>(smem + pl * C::PLANE + poff[dx] + s * C::HWD * 32);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          const int r = s - dy;
+          if (r >= 0 && r < RPW) {
+            // smallest terms first; weight piece i x pixel piece j, i + j <= 2
+#pragma unroll
+            for (int ij = 2; ij >= 0; --ij)
+#pragma unroll
+              for (int i = 0; i <= ij; ++i)
+                acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bf[dy][i]),
+                                                                 __builtin_bit_cast(bf16x8, pf[ij - i]), acc[r], 0, 0, 0);
+          }
+        }
+      }
+      gbuf ^= 1;
+    }
+    __syncthreads();                 // every wave is done with the halo before the next chunk overwrites it
+  }
+
+  // ---- epilogue.  acc[r][v] of lane (lp, lh): channel nb*32 + (v&3) + 8*(v>>2) + 4*lh of pixel (row wm*RPW + r, column lp)
+  const int cbase = nb * 32;
+  float* yb = a.y;
+  int ldc = a.co, csub = 0;
+  unsigned ybytes = a.y_bytes;
+  if (a.split_n > 0) {
+    if (cbase >= a.split_n) { yb = a.y2; ldc = a.co - a.split_n; csub = a.split_n; ybytes = a.y2_bytes; }
+    else ldc = a.split_n;
+  }
+  __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(yb, 0, (int)ybytes, 0x00020000);
+  const bool want_stats = a.stats != nullptr && a.bnb_y == nullptr;
+  const bool want_bnb = a.bnb_y != nullptr;
+  __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(want_bnb ? a.bnb_y : a.x), 0,
+                                                                  (int)(want_bnb ? a.bnb_bytes : 0u), 0x00020000);
+  float sA[16], sB[16];
+#pragma unroll
+  for (int v = 0; v < 16; ++v) sA[v] = sB[v] = 0.f;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int c0 = cbase + 8 * g + 4 * lh;          // this lane's 4 consecutive channels of group g
+    const bool cok = wave_live && c0 < a.co;
+    f32x4 bq = {0.f, 0.f, 0.f, 0.f}, sc = bq, sh = bq, mu = bq, rsd = bq;
+    if (a.bias != nullptr && cok) bq = *reinterpret_cast<const f32x4*>(a.bias + c0);
+    if (want_bnb && cok) {
+      mu = *reinterpret_cast<const f32x4*>(a.bnb_mean + c0);
+      rsd = *reinterpret_cast<const f32x4*>(a.bnb_rstd + c0);
+      const f32x4 gm = *reinterpret_cast<const f32x4*>(a.bnb_gamma + c0), bt = *reinterpret_cast<const f32x4*>(a.bnb_beta + c0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        sc[e] = gm[e] * rsd[e];                     // as bn_apply forms them
+        sh[e] = bt[e] - mu[e] * sc[e];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      const int oy = y0 + wm * RPW + r, ox = x0 + lp;
+      const bool cv = cok && oy < H && ox < W;
+      const unsigned pixoff = (unsigned)((img * H + oy) * W + ox);
+      float val[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) val[e] = acc[r][4 * g + e] + bq[e];
+      if (want_stats) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float q = cv ? val[e] : 0.f;
+          sA[4 * g + e] += q;
+          sB[4 * g + e] = __builtin_fmaf(q, q, sB[4 * g + e]);
+        }
+      }
+      if (a.act != UDASEG_ACT_NONE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) val[e] = act_apply(val[e], a.act, a.slope);
+      }
+      const unsigned off = cv ? (pixoff * (unsigned)ldc + (unsigned)(c0 - csub)) * 4u : 0x80000000u;
+      if (a.accumulate) {
+        // (whole-vector cast: an element-wise bit_cast of the loaded vector compiled to ONE dword load feeding all four adds)
+        const f32x4 old = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_y, (int)off, 0, 0));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) val[e] += old[e];
+      }
+      u32x4 d;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d[e] = __builtin_bit_cast(unsigned, val[e]);
+      __builtin_amdgcn_raw_buffer_store_b128(d, rs_y, (int)off, 0, 0);
+      if (want_bnb) {
+        const unsigned poffb = cv ? (pixoff * (unsigned)a.co + (unsigned)c0) * 4u : 0x80000000u;
+        const f32x4 yv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_p, (int)poffb, 0, 0));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float yy = yv[e];
+          const float gg = cv ? val[e] * act_grad(__builtin_fmaf(yy, sc[e], sh[e]), a.bnb_act, a.bnb_slope) : 0.f;
+          sA[4 * g + e] += gg;
+          sB[4 * g + e] = __builtin_fmaf(gg, (yy - mu[e]) * rsd[e], sB[4 * g + e]);
+        }
+      }
+    }
+  }
+
+  if (want_stats || want_bnb) {
+    asm volatile("s_nop 1");
+    halfwave_sum_n(sA);
+    halfwave_sum_n(sB);
+    asm volatile("s_nop 1");
+    float* red = reinterpret_cast<float*>(smem);   // [2][waves][32]; the K loop ended with a barrier
+    if (lp == 31) {
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int cl = (v & 3) + 8 * (v >> 2) + 4 * lh;
+        red[wave * 32 + cl] = wave_live ? sA[v] : 0.f;
+        red[C::NW * 32 + wave * 32 + cl] = wave_live ? sB[v] : 0.f;
+      }
+    }
+    __syncthreads();
+    if (tid < 32 * WN) {
+      const int wc = tid >> 5, cl = tid & 31;
+      const int c = (cb * WN + wc) * 32 + cl;
+      if (c < a.co) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int m = 0; m < WM; ++m) {
+          t1 += red[(m * WN + wc) * 32 + cl];
+          t2 += red[C::NW * 32 + (m * WN + wc) * 32 + cl];
+        }
+        double* rep = a.sscr != nullptr ? a.sscr + (size_t)(blockIdx.x % HALO_SCR_REPLICAS) * 2 * a.co
+                                        : a.stats + (size_t)(blockIdx.x % HALO_STATS_REPLICAS) * 2 * a.co;
+        atomicAdd(rep + c, (double)t1);
+        atomicAdd(rep + a.co + c, (double)t2);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ fragment packing
+// Three planes of conv_halo_bf16.hip's packing, from fp32 sources:  plane[p][nb][dx][k16][dy][lane][j] = piece p of
+// Wsrc[n = 32 nb + (lane & 31)][tap][k = 16 k16 + 8 (lane >> 5) + j].  Wsrc is [N][9][K] fp32: the OHWI weights (forward) or the
+// dgrad packing [ci][taps][co] with the window flipped (data gradient).
+// table row (int32 x 6): {mode, src element offset, dst element offset (plane 0), N, K, KS = 3}; plane stride = frag_elems(N, K, 3)
+__global__ void pack_frag_batched_f32x3_kernel(const float* __restrict__ w32, const float* __restrict__ wt32,
+                                               __bf16* __restrict__ packed, const int* __restrict__ table) {
+  const int* e = table + 6 * blockIdx.y;
+  const int mode = e[0], N = e[3], K = e[4], KS = e[5];
+  const float* src = (mode ? wt32 : w32) + e[1];
+  __bf16* dst = packed + e[2];
+  const int T = KS * KS, nb = (N + 31) >> 5, nk16 = (K + 15) >> 4;
+  const long long total = (long long)nb * KS * nk16 * KS * 64;     // one 16-byte item per (fragment, lane) per plane
+  const long long plane = total * 8;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int lane = (int)(i & 63);
+    long long f = i >> 6;
+    const int dy = (int)(f % KS);
+    f /= KS;
+    const int kk = (int)(f % nk16);
+    f /= nk16;
+    const int dx = (int)(f % KS);
+    const int b = (int)(f / KS);
+    const int n = b * 32 + (lane & 31), k0 = kk * 16 + 8 * (lane >> 5);
+    const int tap = mode ? T - 1 - (dy * KS + dx) : dy * KS + dx;
+    u32x4 lo = {0u, 0u, 0u, 0u}, hi = lo;
+    if (n < N && k0 < K) {
+      const float* s = src + ((size_t)n * T + tap) * K + k0;
+      lo = *reinterpret_cast<const u32x4*>(s);                      // K is a multiple of 4 (fp32 channel padding)
+      if (k0 + 4 < K) hi = *reinterpret_cast<const u32x4*>(s + 4);
+    }
+    u32x4 p0, p1, p2;
+    split3(lo, hi, p0, p1, p2);
+    *reinterpret_cast<u32x4*>(dst + i * 8) = p0;
+    *reinterpret_cast<u32x4*>(dst + plane + i * 8) = p1;
+    *reinterpret_cast<u32x4*>(dst + 2 * plane + i * 8) = p2;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- host side
+template <int WM, int WN, int RPW>
+static int launch_f3_t(F3Args a, hipStream_t s, double flops) {
+  using C = F3Cfg<WM, WN, RPW>;
+  auto kern = conv3x3_f32x3_kernel<WM, WN, RPW>;
+  static bool attr_done = false;
+  if (!attr_done && C::LDS > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv3x3_f32x3)");
+    attr_done = true;
+  }
+  a.ntx = cdiv(a.w, C::TW);
+  a.nty = cdiv(a.h, C::TH);
+  a.ncb = cdiv(a.co, 32 * WN);
+  a.nk16 = (a.ci + 15) / 16;
+  const long long blocks = (long long)a.n * a.nty * a.ntx * a.ncb;
+  if (blocks <= 0) return UDASEG_OK;
+  a.sscr = nullptr;
+  if (a.stats != nullptr && blocks > 1024) a.sscr = halo_stats_scratch(a.co);
+  static int kid = -1;
+  if (kid < 0) {
+    char nm[96];
+    snprintf(nm, sizeof(nm), "conv3x3_f32x3_kernel<%d, %d, %d>", WM, WN, RPW);
+    kid = kprof_id(nm);
+  }
+  hipEvent_t ev = kprof_begin(s);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::NT), C::LDS, s, a);
+  kprof_end(kid, ev, s, flops);
+  UDASEG_LAUNCH_CHECK("conv3x3_f32x3 launch");
+  if (a.sscr != nullptr) {
+    launch_halo_stats_fold(a.sscr, a.co, a.stats, s);
+    UDASEG_LAUNCH_CHECK("halo_stats_fold launch");
+  }
+  return UDASEG_OK;
+}
+
+static int f3_enabled() {
+  static int v = -1;   // UDASEG_F32_SPLIT=0: every fp32 layer stays on the fp32-MFMA kernels (A/B, cross-check)
+  if (v < 0) {
+    const char* e = getenv("UDASEG_F32_SPLIT");
+    v = (e && atoi(e) == 0) ? 0 : 1;
+  }
+  return v;
+}
+
+// gathered / produced: channel counts of the launch (for a data gradient: co / ci)
+static bool f3_applicable(const udaseg_conv_desc* d, int gathered, int produced, int up_ca) {
+  if (!f3_enabled()) return false;
+  if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1) return false;
+  if (gathered % 8 != 0 || produced % 4 != 0) return false;
+  if (up_ca > 0 && (up_ca % 16 != 0 || (gathered - up_ca) % 16 != 0 || d->hi % 2 != 0 || d->wi % 2 != 0)) return false;
+  const long long px = (long long)d->n * d->hi * d->wi;
+  if (px * gathered * 4 >= (1LL << 31) || px * produced * 4 >= (1LL << 31)) return false;     // buffer descriptors: 2 GiB
+  return true;
+}
+
+// 0: leave the layer to the fp32-MFMA kernels; 1: 8 x 32 pixels x 32 channels per block; 2: x 64 channels
+static int g_f3_force = -1;   // udaseg_f32x3_force_config / UDASEG_F3_CFG = 1 | 2: one configuration for every launch
+static int f3_choice(int h, int w, int n, int gathered, int produced) {
+  if (g_f3_force < 0) {
+    const char* e = getenv("UDASEG_F3_CFG");
+    g_f3_force = e ? atoi(e) : 0;
+  }
+  if (g_f3_force == 1 || g_f3_force == 2) return g_f3_force;
+  if (w < 32) return 0;                             // 16-pixel-wide images: half of every 32-pixel tile row is outside
+  const long long tiles = (long long)n * cdiv(h, 8) * cdiv(w, 32);
+  if (produced <= 32) return 1;
+  return tiles * cdiv(produced, 64) >= 256 ? 2 : 1;
+}
+
+static int launch_f3(F3Args a, hipStream_t s, double flops) {
+  int choice = f3_choice(a.h, a.w, a.n, a.ci, a.co);
+  if (choice == 0) choice = a.co <= 32 ? 1 : 2;
+  if (choice == 1) return launch_f3_t<4, 1, 2>(a, s, flops);
+  return launch_f3_t<2, 2, 4>(a, s, flops);
+}
+
+}  // namespace udaseg
+
+using namespace udaseg;
+
+extern "C" int udaseg_pack_frag_batched_f32x3(const float* w32, const float* wt32, void* packed, const int* table, int entries,
+                                              void* stream) {
+  UDASEG_CHECK_ARG(packed && table && entries > 0 && (w32 || wt32), "pack_frag_batched_f32x3: NULL pointer / no entries");
+  hipLaunchKernelGGL(pack_frag_batched_f32x3_kernel, dim3(64, (unsigned)entries), dim3(256), 0, as_stream(stream), w32, wt32,
+                     static_cast<__bf16*>(packed), table);
+  UDASEG_LAUNCH_CHECK("pack_frag_batched_f32x3 launch");
+  return UDASEG_OK;
+}
+
+extern "C" int udaseg_f32x3_force_config(int cfg) {
+  UDASEG_CHECK_ARG(cfg >= 0 && cfg <= 2, "f32x3_force_config: 0 (heuristic), 1 (32-channel blocks) or 2 (64-channel blocks)");
+  g_f3_force = cfg;
+  return UDASEG_OK;
+}
+
+extern "C" int udaseg_conv_f32x3_ok(const udaseg_conv_desc* d, int dgrad, int up_ca) {
+  if (!d) return 0;
+  return f3_applicable(d, dgrad ? d->co : d->ci, dgrad ? d->ci : d->co, up_ca) ? 1 : 0;
+}
+
+extern "C" int udaseg_conv_f32x3_preferred(const udaseg_conv_desc* d, int dgrad, int up_ca) {
+  if (!udaseg_conv_f32x3_ok(d, dgrad, up_ca)) return 0;
+  return f3_choice(d->hi, d->wi, d->n, dgrad ? d->co : d->ci, dgrad ? d->ci : d->co) != 0 ? 1 : 0;
+}
+
+static int f3_common(const udaseg_conv_desc* d, F3Args& a, const char* who) {
+  UDASEG_CHECK_ARG(d != nullptr, "%s: conv desc is NULL", who);
+  UDASEG_CHECK_ARG(d->n > 0 && d->hi > 0 && d->wi > 0 && d->ho == d->hi && d->wo == d->wi && d->ci > 0 && d->co > 0,
+                   "%s: stride-1 'same' convolutions only (hi=%d wi=%d ho=%d wo=%d)", who, d->hi, d->wi, d->ho, d->wo);
+  a.n = d->n; a.h = d->hi; a.w = d->wi;
+  return UDASEG_OK;
+}
+
+extern "C" int udaseg_conv2d_fwd_f32x3(const udaseg_conv_desc* d, const float* x, const float* skip, int up_ca, const void* wfrag3,
+                                       const float* bias, float* y, int act, float slope, double* stats, void* stream) {
+  F3Args a = {};
+  int rc = f3_common(d, a, "conv2d_fwd_f32x3");
+  if (rc) return rc;
+  UDASEG_CHECK_ARG(x && wfrag3 && y, "conv2d_fwd_f32x3: NULL pointer");
+  UDASEG_CHECK_ARG(up_ca >= 0 && up_ca <= d->ci && (up_ca == 0 ? skip == nullptr : (up_ca == d->ci) == (skip == nullptr)),
+                   "conv2d_fwd_f32x3: up_ca=%d of ci=%d channels, skip %s", up_ca, d->ci, skip ? "given" : "NULL");
+  if (!f3_applicable(d, d->ci, d->co, up_ca)) {
+    set_error("conv2d_fwd_f32x3: geometry not supported (ask udaseg_conv_f32x3_ok first)");
+    return UDASEG_E_UNSUPPORTED;
+  }
+  const long long px = (long long)d->n * d->hi * d->wi;
+  a.x = x; a.x2 = skip; a.wf = wfrag3; a.bias = bias; a.y = y;
+  a.ci = d->ci; a.co = d->co; a.up_ca = up_ca;
+  a.act = act; a.slope = slope; a.stats = stats;
+  a.x_bytes = (unsigned)(up_ca > 0 ? (long long)d->n * (d->hi / 2) * (d->wi / 2) * up_ca * 4 : px * d->ci * 4);
+  a.x2_bytes = (unsigned)(up_ca > 0 ? px * (d->ci - up_ca) * 4 : 0);
+  a.w_plane_bytes = (unsigned)(udaseg_frag_elems(d->co, d->ci, 3) * 2);
+  a.y_bytes = (unsigned)(px * d->co * 4);
+  hipStream_t st = as_stream(stream);
+  prof_begin(0, st);
+  rc = launch_f3(a, st, udaseg_conv_flops(d));
+  prof_end(0, st, udaseg_conv_flops(d), 0, d);
+  return rc;
+}
+
+extern "C" int udaseg_conv2d_dgrad_f32x3(const udaseg_conv_desc* d, const float* dy, const void* wfrag3_t, float* dx, float* dx2,
+                                         int split, const float* prev_y, const float* save_mean, const float* save_rstd,
+                                         const float* gamma, const float* beta, int bn_act, float bn_slope, double* bsums,
+                                         int accumulate, void* stream) {
+  F3Args a = {};
+  int rc = f3_common(d, a, "conv2d_dgrad_f32x3");
+  if (rc) return rc;
+  UDASEG_CHECK_ARG(dy && wfrag3_t && dx, "conv2d_dgrad_f32x3: NULL pointer");
+  UDASEG_CHECK_ARG(split == 0 ? dx2 == nullptr : (dx2 != nullptr && split > 0 && split < d->ci && split % 32 == 0),
+                   "conv2d_dgrad_f32x3: split=%d of ci=%d channels (a multiple of 32 inside the range, with dx2)", split, d->ci);
+  const bool bn = prev_y != nullptr;
+  UDASEG_CHECK_ARG(!bn || (save_mean && save_rstd && gamma && beta && bsums && split == 0 && !accumulate),
+                   "conv2d_dgrad_f32x3: the BatchNorm-backward sums need mean, rstd, gamma, beta, bsums, one destination, no accumulation");
+  UDASEG_CHECK_ARG(!(accumulate && split != 0), "conv2d_dgrad_f32x3: accumulation needs a single destination");
+  if (!f3_applicable(d, d->co, d->ci, 0)) {
+    set_error("conv2d_dgrad_f32x3: geometry not supported (ask udaseg_conv_f32x3_ok first)");
+    return UDASEG_E_UNSUPPORTED;
+  }
+  const long long px = (long long)d->n * d->hi * d->wi;
+  a.x = dy; a.wf = wfrag3_t; a.y = dx; a.y2 = dx2;
+  a.ci = d->co; a.co = d->ci; a.split_n = split; a.accumulate = accumulate;
+  a.act = UDASEG_ACT_NONE;
+  if (bn) {
+    a.bnb_y = prev_y; a.bnb_mean = save_mean; a.bnb_rstd = save_rstd; a.bnb_gamma = gamma; a.bnb_beta = beta;
+    a.bnb_act = bn_act; a.bnb_slope = bn_slope; a.stats = bsums;
+    a.bnb_bytes = (unsigned)(px * d->ci * 4);
+  }
+  a.x_bytes = (unsigned)(px * d->co * 4);
+  a.w_plane_bytes = (unsigned)(udaseg_frag_elems(d->ci, d->co, 3) * 2);
+  a.y_bytes = (unsigned)(px * (split > 0 ? split : d->ci) * 4);
+  a.y2_bytes = (unsigned)(split > 0 ? px * (d->ci - split) * 4 : 0);
+  hipStream_t st = as_stream(stream);
+  prof_begin(0, st);
+  rc = launch_f3(a, st, udaseg_conv_flops(d));
+  prof_end(0, st, udaseg_conv_flops(d), 1, d);
+  return rc;
+}

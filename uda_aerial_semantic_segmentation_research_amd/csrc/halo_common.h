@@ -1,0 +1,61 @@
+// Pieces shared by the halo-resident convolution kernels (conv_halo_bf16.hip, conv_halo_f32x3.hip).
+#pragma once
+#include "common.h"
+
+namespace udaseg {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int HALO_STATS_REPLICAS = 16;   // == udaseg_bn_replicas()
+constexpr int HALO_SCR_REPLICAS = 256;
+
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+  return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)a) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)b) << 16);
+}
+__device__ __forceinline__ float bf_lo(unsigned d) { return __builtin_bit_cast(float, d << 16); }
+__device__ __forceinline__ float bf_hi(unsigned d) { return __builtin_bit_cast(float, d & 0xffff0000u); }
+
+// Sum over the 32 lanes of a half-wave (lane bits 0..4), in the vector ALU: four rotations inside each 16-lane row, then lane 15
+// of rows 0 / 2 is broadcast into rows 1 / 3 -- the totals of the low / high half-wave end up in lanes 16..31 / 48..63.
+// (The first version used five __shfl_xor steps = ds_bpermute: 320 LDS crossbar operations per wave per tile; the in-kernel
+// timeline showed the epilogue at 6.5 us of a 15 us block, profiles/r03_halo_timeline.txt.)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov(float old, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL,
+                                                               ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float halfwave_sum(float x) {
+  x += dpp_mov<0x128, 0xf>(0.f, x);   // row_ror:8
+  x += dpp_mov<0x124, 0xf>(0.f, x);   // row_ror:4
+  x += dpp_mov<0x122, 0xf>(0.f, x);   // row_ror:2
+  x += dpp_mov<0x121, 0xf>(0.f, x);   // row_ror:1   -> every lane holds its row's total
+  x += dpp_mov<0x142, 0xa>(0.f, x);   // row_bcast:15 into rows 1 and 3 (rows 0 and 2 add 0)
+  return x;
+}
+// The same reduction over N values at once with the add and the lane movement in ONE instruction (v_add_f32_dpp; hipcc emits
+// v_mov_b32_dpp + v_add_f32 for the form above).  Step-major order: two dependent DPP operations on a register are N
+// instructions apart, which covers the two wait states a DPP read needs behind a VALU write of its source (the compiler
+// does not see into the asm).
+template <int N>
+__device__ __forceinline__ void halfwave_sum_n(float (&x)[N]) {
+  static_assert(N >= 4, "spacing of dependent DPP operations");
+#pragma unroll
+  for (int v = 0; v < N; ++v) asm volatile("v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf" : "+v"(x[v]));
+#pragma unroll
+  for (int v = 0; v < N; ++v) asm volatile("v_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf" : "+v"(x[v]));
+#pragma unroll
+  for (int v = 0; v < N; ++v) asm volatile("v_add_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf" : "+v"(x[v]));
+#pragma unroll
+  for (int v = 0; v < N; ++v) asm volatile("v_add_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf" : "+v"(x[v]));
+#pragma unroll
+  for (int v = 0; v < N; ++v) asm volatile("v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(x[v]));
+}
+
+// f64 partial-sum scratch of launches with more than 1024 blocks (udaseg_set_stats_scratch): the current device's, when it holds
+// HALO_SCR_REPLICAS x 2 x co doubles, else nullptr; and the launch that folds it into the [R][2][co] accumulators
+double* halo_stats_scratch(int co);
+void launch_halo_stats_fold(double* sscr, int co, double* stats, hipStream_t s);
+
+}  // namespace udaseg

@@ -36,6 +36,10 @@ USE_FRAG_KERNELS = os.environ.get("UDASEG_FRAG", "1") != "0"
 # "auto": a layer takes them where the library's measured heuristic prefers them (udaseg_conv_frag_preferred); "always": wherever
 # they are supported (UDASEG_FRAG=2; network-level tests at small sizes, where "auto" would leave most layers on the old kernel)
 FRAG_POLICY = "always" if os.environ.get("UDASEG_FRAG") == "2" else "auto"
+# fp32 storage: the stride-1 3x3 convolutions run on the bf16 matrix pipe with every operand split exactly into three bf16
+# terms (csrc/conv_halo_f32x3.hip: six products per operand pair, fp32 accumulation, one unit in the last place of a PRODUCT
+# left out).  UDASEG_F32_SPLIT=0 keeps them on the fp32-MFMA kernels (A/B; tests flip the module attribute to cross-check).
+USE_F32_SPLIT = os.environ.get("UDASEG_F32_SPLIT", "1") != "0"
 
 
 # bf16 storage: BatchNorm + activation of a layer whose ONLY consumer is a convolution on the bf16-first kernels is not written at
@@ -270,16 +274,18 @@ class ArenaModule(nn.Module):
         # bf16 storage: MFMA-fragment packings of the stride-1 3x3 / 1x1 convolutions for the bf16-first kernels
         # (csrc/conv_halo_bf16.hip), refreshed once per step by one batched launch per direction
         self._frag_off, self._frag_fwd_table, self._frag_bwd_table, self._frag_arena = {}, None, None, None
-        if self.compute_dtype == torch.bfloat16 and USE_FRAG_KERNELS:
+        f32 = self.compute_dtype == torch.float32
+        planes = 3 if f32 else 1          # fp32: the three split planes of every packing
+        if (USE_FRAG_KERNELS and self.compute_dtype == torch.bfloat16) or (USE_F32_SPLIT and f32):
             foff, frows, brows = 0, [], []
             for m in self.modules():
-                if isinstance(m, ConvP) and m.stride == 1 and ((m.k == 3 and m.pad == 1) or (m.k == 1 and m.pad == 0)):
-                    nf = K.frag_elems(m.cout_p, m.cin_p, m.k)
+                if isinstance(m, ConvP) and m.stride == 1 and ((m.k == 3 and m.pad == 1) or (m.k == 1 and m.pad == 0 and not f32)):
+                    nf = planes * K.frag_elems(m.cout_p, m.cin_p, m.k)
                     frows.append([0, self._idx[(id(m), "weight")][0], foff, m.cout_p, m.cin_p, m.k])
                     ent = [foff, nf, None, 0]
                     foff += nf
                     if m.needs_dgrad:
-                        nd = K.frag_elems(m.cin_p, m.cout_p, m.k)
+                        nd = planes * K.frag_elems(m.cin_p, m.cout_p, m.k)
                         brows.append([1, self._wt_off[id(m)], foff, m.cin_p, m.cout_p, m.k])
                         ent[2], ent[3] = foff, nd
                         foff += nd
@@ -393,9 +399,9 @@ class Plan:
         self.bf16 = self.adt == torch.bfloat16
         # bf16 storage: one cast of the whole fp32 master arena per forward (same offsets / physical shapes)
         self.w16 = K.cast_to_bf16(net._arena, st=self.st) if self.bf16 else None
-        self.frag = training and self.bf16 and getattr(net, "_frag_arena", None) is not None
+        self.frag = training and getattr(net, "_frag_arena", None) is not None      # bf16 kernels / fp32 three-term split
         if self.frag:
-            K.pack_frag_batched(self.w16, None, net._frag_arena, net._frag_fwd_table, self.st)
+            K.pack_frag_batched(self.w16 if self.bf16 else net._arena, None, net._frag_arena, net._frag_fwd_table, self.st)
         nbn = net._nbn
         self.dev = dev
         if training:
@@ -458,7 +464,7 @@ class Plan:
             return None
         ent = self.net._frag_off.get(id(conv))
         ok = K.conv_frag_ok if FRAG_POLICY == "always" else K.conv_frag_preferred
-        if ent is None or (dgrad and ent[2] is None) or not ok(d, dgrad, up_ca):
+        if ent is None or (dgrad and ent[2] is None) or not ok(d, dgrad, up_ca, f32=not self.bf16):
             return None
         o, n = (ent[2], ent[3]) if dgrad else (ent[0], ent[1])
         return self.net._frag_arena[o:o + n]
@@ -507,7 +513,8 @@ class Plan:
         """May BatchNorm + activation of this [n, ho, wo, c] output stay unwritten?  Only when its single consumer runs on the
         bf16-first kernels in BOTH directions (the forward applies the transform while staging; the data gradient's epilogue
         makes this layer's BatchNorm-backward sums, which then need no activation either)."""
-        if not (FUSE_BN_APPLY and FUSE_BN_REDUCE and self.frag and consumer is not None and residual is None and act != ACT_NONE):
+        if not (FUSE_BN_APPLY and FUSE_BN_REDUCE and self.frag and self.bf16 and consumer is not None and residual is None
+                and act != ACT_NONE):
             return False
         if consumer.stride != 1 or consumer.cin_p != c or c % 16 != 0 or (FUSE_BN_APPLY_1X1_ONLY and consumer.k != 1):
             return False

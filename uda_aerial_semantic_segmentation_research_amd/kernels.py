@@ -204,24 +204,41 @@ def frag_elems(n_out, k_in, ks):
     return int(_lib.load().udaseg_frag_elems(n_out, k_in, ks))
 
 
-def pack_frag_batched(w16, wt16, packed, table, st=None):
-    """Fragment-pack every listed convolution in one launch (table rows: mode, src offset, dst offset, N, K, ks; int32 x 6)."""
-    check(_lib.load().udaseg_pack_frag_batched_bf16(_ptr(w16), _ptr(wt16), packed.data_ptr(), table.data_ptr(), table.shape[0],
+def pack_frag_batched(w, wt, packed, table, st=None):
+    """Fragment-pack every listed convolution in one launch (table rows: mode, src offset, dst offset, N, K, ks; int32 x 6).
+    bf16 sources: one plane (csrc/conv_halo_bf16.hip); fp32 sources: the three split planes (csrc/conv_halo_f32x3.hip)."""
+    src = w if w is not None else wt
+    if src.dtype == torch.float32:
+        check(_lib.load().udaseg_pack_frag_batched_f32x3(_ptr(w), _ptr(wt), packed.data_ptr(), table.data_ptr(), table.shape[0],
+                                                          st if st is not None else stream()), "pack_frag_batched_f32x3")
+        return
+    check(_lib.load().udaseg_pack_frag_batched_bf16(_ptr(w), _ptr(wt), packed.data_ptr(), table.data_ptr(), table.shape[0],
                                                      st if st is not None else stream()), "pack_frag_batched_bf16")
 
 
-def conv_frag_ok(d, dgrad=False, up_ca=0):
+def conv_frag_ok(d, dgrad=False, up_ca=0, f32=False):
+    if f32:
+        return bool(_lib.load().udaseg_conv_f32x3_ok(_byref(d), int(dgrad), up_ca))
     return bool(_lib.load().udaseg_conv_frag_ok(_byref(d), int(dgrad), up_ca))
 
 
-def conv_frag_preferred(d, dgrad=False, up_ca=0):
+def conv_frag_preferred(d, dgrad=False, up_ca=0, f32=False):
     """Supported AND expected to beat the shared implicit-GEMM kernel for this shape (the library's measured heuristic)."""
+    if f32:
+        return bool(_lib.load().udaseg_conv_f32x3_preferred(_byref(d), int(dgrad), up_ca))
     return bool(_lib.load().udaseg_conv_frag_preferred(_byref(d), int(dgrad), up_ca))
 
 
 def conv2d_fwd_frag(d, x, skip, wfrag, bias, y, act=ACT_NONE, slope=0.0, stats=None, in_scale=None, in_shift=None, in_act=ACT_NONE,
                     in_slope=0.0, up=False, st=None):
-    """bf16-first forward convolution (csrc/conv_halo_bf16.hip).  up: x is the half-resolution tensor of a fused decoder input."""
+    """Halo-resident forward convolution on the bf16 matrix pipe: bf16 tensors (csrc/conv_halo_bf16.hip) or fp32 tensors with
+    the three-term split (csrc/conv_halo_f32x3.hip).  up: x is the half-resolution tensor of a fused decoder input."""
+    if x.dtype == torch.float32:
+        assert in_scale is None and y.dtype == torch.float32
+        check(_lib.load().udaseg_conv2d_fwd_f32x3(_byref(d), x.data_ptr(), _ptr(skip), x.shape[-1] if up else 0, wfrag.data_ptr(),
+                                                   _ptr(bias), y.data_ptr(), act, slope, _ptr(stats),
+                                                   st if st is not None else stream()), "conv2d_fwd_f32x3")
+        return
     check(_lib.load().udaseg_conv2d_fwd_frag_bf16(_byref(d), x.data_ptr(), _ptr(skip), x.shape[-1] if up else 0, wfrag.data_ptr(),
                                                    _ptr(bias), _ptr(in_scale), _ptr(in_shift), in_act, in_slope, y.data_ptr(),
                                                    int(y.dtype == torch.float32), act, slope, _ptr(stats),
@@ -229,13 +246,15 @@ def conv2d_fwd_frag(d, x, skip, wfrag, bias, y, act=ACT_NONE, slope=0.0, stats=N
 
 
 def conv2d_dgrad_frag(d, dy, wfrag_t, dx, dx2=None, bn=None, accumulate=False, st=None):
-    """bf16-first data gradient.  dx2: second destination of a split gradient (channels [dx.shape[-1], ci)).
+    """Halo-resident data gradient (bf16 tensors, or fp32 tensors with the three-term split).  dx2: second destination of a
+    split gradient (channels [dx.shape[-1], ci)).
     bn = (prev_y, save_mean, save_rstd, gamma, beta, act, slope, bsums): BatchNorm-backward reductions of the layer behind."""
     py, mu, rs, ga, be, act, slope, bs = bn if bn is not None else (None, None, None, None, None, ACT_NONE, 0.0, None)
-    check(_lib.load().udaseg_conv2d_dgrad_frag_bf16(_byref(d), dy.data_ptr(), wfrag_t.data_ptr(), dx.data_ptr(), _ptr(dx2),
-                                                     dx.shape[-1] if dx2 is not None else 0, _ptr(py), _ptr(mu), _ptr(rs), _ptr(ga),
-                                                     _ptr(be), act, slope, _ptr(bs), int(accumulate),
-                                                     st if st is not None else stream()), "conv2d_dgrad_frag_bf16")
+    fn, name = ((_lib.load().udaseg_conv2d_dgrad_f32x3, "conv2d_dgrad_f32x3") if dy.dtype == torch.float32
+                else (_lib.load().udaseg_conv2d_dgrad_frag_bf16, "conv2d_dgrad_frag_bf16"))
+    check(fn(_byref(d), dy.data_ptr(), wfrag_t.data_ptr(), dx.data_ptr(), _ptr(dx2), dx.shape[-1] if dx2 is not None else 0,
+             _ptr(py), _ptr(mu), _ptr(rs), _ptr(ga), _ptr(be), act, slope, _ptr(bs), int(accumulate),
+             st if st is not None else stream()), name)
 
 
 def pack_dgrad_weights(d, w, w_t, st=None):
