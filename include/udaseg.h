@@ -417,6 +417,13 @@ int udaseg_conv2d_dgrad_f32x3(const udaseg_conv_desc* d, const float* dy, const 
                               const float* prev_y, const float* save_mean, const float* save_rstd, const float* gamma,
                               const float* beta, int bn_act, float bn_slope, double* bsums, int accumulate, void* stream);
 
+/* dW[co][9][ci] += weight gradient of a stride-1 3x3 layer with channel counts that are multiples of 64, fp32 x / dy with the
+ * same three-term split (csrc/conv_wgrad.hip: conv_wgrad_halo_f32x3_kernel; the blocking of udaseg_conv2d_wgrad_halo_bf16).
+ * up_ca > 0: x is the half-resolution tensor of a fused decoder input, skip the other source. */
+int udaseg_conv2d_wgrad_halo_f32x3_ok(const udaseg_conv_desc* d, int up_ca);
+int udaseg_conv2d_wgrad_halo_f32x3(const udaseg_conv_desc* d, const float* x, const float* skip, int up_ca, const float* dy,
+                                   float* dw, void* stream);
+
 /* ---- diagnosis: while a device buffer of 6 * blocks u64 is registered, every implicit-GEMM launch of at most `blocks` blocks
  *      writes per block {entry, first tile load, end of K loop, exit} (100 MHz wall-clock ticks), HW_ID and XCC_ID into it
  *      (tools/igemm_timeline.py).  NULL switches it off.  Not for timed runs. ---- */

@@ -47,12 +47,12 @@ def err2(got, ref64):
     return ((got.double() - ref64).norm() / ref64.norm()).item()
 
 
-def grade(got, nat, ref64, what, cap=3e-6):
+def grade(got, nat, ref64, what, cap=3e-6, k2=1.25):
     """fp32 grade: the split kernel's error against f64 next to the fp32-MFMA kernel's on the same launch -- norm-wise (the
-    stable statistic) within 1.25 x, the worst element (one sample of the tail) within 2.5 x, and small outright."""
+    stable statistic) within k2 x, the worst element (one sample of the tail) within 2.5 x, and small outright."""
     e2, n2, em, nm = err2(got, ref64), err2(nat, ref64), err(got, ref64), err(nat, ref64)
     print(f"{what}: l2 split {e2:.3e} fp32-MFMA {n2:.3e} | worst element split {em:.3e} fp32-MFMA {nm:.3e}")
-    assert e2 <= 1.25 * n2 + 2.0 ** -24, f"{what}: split kernel {e2:.3e} against fp32-MFMA kernel {n2:.3e} (l2)"
+    assert e2 <= k2 * n2 + 2.0 ** -24, f"{what}: split kernel {e2:.3e} against fp32-MFMA kernel {n2:.3e} (l2)"
     assert em <= 2.5 * nm + 2.0 ** -23 and em <= cap, f"{what}: worst element {em:.3e} against {nm:.3e}"
 
 
@@ -268,3 +268,42 @@ def test_network_step_matches_fp32_mfma_path(K, monkeypatch):
           f"1 - cos(all grads) {1 - cos:.3e}")
     assert e_logits <= 2e-5 and abs(lossa - lossb) <= 1e-5 * abs(lossb)
     assert e_head <= 1e-5 and cos >= 0.9995
+
+
+@pytest.mark.parametrize("n,h,w,ci,co", [(2, 16, 32, 64, 64), (1, 10, 40, 128, 64), (2, 32, 32, 64, 128), (3, 9, 70, 64, 64),
+                                         (8, 32, 32, 256, 256)])
+def test_wgrad_halo_f32x3_fp32_grade(K, n, h, w, ci, co):
+    """Weight gradient on the halo-resident split kernel against f64, next to the fp32-MFMA split-K kernel on the same launch;
+    accumulation onto an existing gradient."""
+    g = torch.Generator().manual_seed(n + h + w + ci + co)
+    x = torch.randn(n, ci, h, w, generator=g)
+    dy = torch.randn(n, co, h, w, generator=g)
+    wt = torch.zeros(co, ci, 3, 3, dtype=f64, requires_grad=True)
+    F.conv2d(x.double(), wt, padding=1).backward(dy.double())
+    ref = wt.grad.permute(0, 2, 3, 1).contiguous()              # OHWI
+    d = K.conv_desc(n, h, w, ci, co, 3, 1, 1)
+    assert K.conv2d_wgrad_halo_ok(d, f32=True)
+    base = torch.randn(co, 3, 3, ci, generator=g)
+    dw = base.clone().cuda()
+    K.conv2d_wgrad_halo(d, nhwc(x), None, nhwc(dy), dw)
+    dw_nat = torch.zeros(co, 3, 3, ci, device="cuda")
+    K.conv2d_wgrad(d, nhwc(x), nhwc(dy), dw_nat, False)
+    # sums over 8192 pixels and more: measured 1.0 - 1.45 x the fp32-MFMA kernel's error (5.1e-7 against 3.6e-7 at K = 8192)
+    grade(dw.cpu() - base, dw_nat.cpu(), ref, "weight gradient", cap=5e-6, k2=1.6)
+
+
+def test_wgrad_halo_f32x3_fused_decoder_input(K):
+    n, h, w, ca, cs, co = 2, 16, 64, 128, 64, 64
+    g = torch.Generator().manual_seed(9)
+    a = torch.randn(n, ca, h // 2, w // 2, generator=g)
+    skip = torch.randn(n, cs, h, w, generator=g)
+    dy = torch.randn(n, co, h, w, generator=g)
+    xin = torch.cat([F.interpolate(a, scale_factor=2, mode="nearest"), skip], 1).double()
+    wt = torch.zeros(co, ca + cs, 3, 3, dtype=f64, requires_grad=True)
+    F.conv2d(xin, wt, padding=1).backward(dy.double())
+    ref = wt.grad.permute(0, 2, 3, 1).contiguous()
+    d = K.conv_desc(n, h, w, ca + cs, co, 3, 1, 1)
+    assert K.conv2d_wgrad_halo_ok(d, ca, f32=True)
+    dw = torch.zeros(co, 3, 3, ca + cs, device="cuda")
+    K.conv2d_wgrad_halo(d, nhwc(a), nhwc(skip), nhwc(dy), dw, up=True)
+    assert err2(dw.cpu(), ref) <= 1e-6 and err(dw.cpu(), ref) <= 5e-6

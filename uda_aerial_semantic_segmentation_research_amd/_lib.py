@@ -121,6 +121,8 @@ SIGNATURES = {
     "udaseg_conv2d_fwd_frag_bf16": (_I, [_D, _P, _P, _I, _P, _P, _P, _P, _I, _F, _P, _I, _I, _F, _P, _P]),
     "udaseg_conv2d_dgrad_frag_bf16": (_I, [_D, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _F, _P, _I, _P]),
     "udaseg_pack_frag_batched_f32x3": (_I, [_P, _P, _P, _P, _I, _P]),
+    "udaseg_conv2d_wgrad_halo_f32x3_ok": (_I, [_D, _I]),
+    "udaseg_conv2d_wgrad_halo_f32x3": (_I, [_D, _P, _P, _I, _P, _P, _P]),
     "udaseg_conv_f32x3_ok": (_I, [_D, _I, _I]),
     "udaseg_f32x3_force_config": (_I, [_I]),
     "udaseg_conv_f32x3_preferred": (_I, [_D, _I, _I]),

@@ -74,25 +74,6 @@ struct F3Cfg {
   static_assert(LDS_HALO >= 2 * NW * 32 * 4, "reduction scratch fits the halo region");
 };
 
-// x = p0 + p1 + p2 exactly, eight values at a time (two 16-byte fp32 pieces -> three bf16x8 fragments pieces)
-__device__ __forceinline__ void split3(const u32x4 lo, const u32x4 hi, u32x4& p0, u32x4& p1, u32x4& p2) {
-  const f32x4 lf = __builtin_bit_cast(f32x4, lo), hf = __builtin_bit_cast(f32x4, hi);
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    float a = e < 2 ? lf[2 * e] : hf[2 * e - 4];
-    float b = e < 2 ? lf[2 * e + 1] : hf[2 * e - 3];
-    const unsigned h = pack_bf16x2(a, b);
-    a -= bf_lo(h);
-    b -= bf_hi(h);
-    const unsigned m = pack_bf16x2(a, b);
-    a -= bf_lo(m);
-    b -= bf_hi(m);
-    p0[e] = h;
-    p1[e] = m;
-    p2[e] = pack_bf16x2(a, b);
-  }
-}
-
 template <int WM, int WN, int RPW>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_f32x3_kernel(const F3Args a) {
   using C = F3Cfg<WM, WN, RPW>;

@@ -27,6 +27,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "halo_common.h"
 
 namespace udaseg {
 
@@ -813,6 +814,210 @@ int launch_wgrad_halo(const udaseg_conv_desc* d, const void* x, const void* x2, 
   return UDASEG_OK;
 }
 
+// --------------------------------------------------------------------------- halo weight gradient, fp32 on the bf16 matrix pipe
+// The same blocking for fp32 tensors with the exact three-term split of conv_halo_f32x3.hip: x halo and dy tile are loaded as
+// fp32, split in registers into three bf16 planes each in LDS; per (16-pixel K step, tap) the six products with i + j <= 2.
+// Against the bf16 kernel above the LDS traffic per MFMA halves (three plane reads feed six MFMAs), which is what bounded it;
+// the tile shrinks to TR x 32 pixels so that three planes of halo + dy fit the 160 KB.  dW is fp32 either way.
+struct WgradHaloF3Args {
+  const float* x;     // [n][h][w][cx] fp32, or the half-resolution a [n][h/2][w/2][up_ca] of a fused decoder input
+  const float* x2;    // fused decoder input: the skip tensor [n][h][w][ci - up_ca]
+  const float* dy;    // [n][h][w][co]
+  float* dw;          // [co][9][ci] fp32, accumulated onto
+  int n, h, w, ci, co, up_ca;
+  int ntx, nty, ntiles, ncib, pairs, P;
+  unsigned x_bytes, x2_bytes, dy_bytes;
+};
+
+template <int TR>
+struct WF3 {
+  static constexpr int HR = TR + 2, HWD = 34, TP = TR * 32;
+  static constexpr int LD = 96;                        // elements per LDS pixel row (see WH_LD)
+  static constexpr int XPL = HR * HWD * LD, DPL = TP * LD;     // elements per plane
+  static constexpr int NX = (HR * HWD * 8 + 255) / 256, ND = TP * 8 / 256;
+  static constexpr int LDS = 3 * (XPL + DPL) * 2;
+};
+
+template <int TR>
+__global__ __launch_bounds__(256, 1) void conv_wgrad_halo_f32x3_kernel(const WgradHaloF3Args a) {
+  using C = WF3<TR>;
+  extern __shared__ __attribute__((aligned(16))) char whs3[];
+  unsigned short* Xs = reinterpret_cast<unsigned short*>(whs3);                         // [3][HR * 34][LD]
+  unsigned short* Ds = Xs + 3 * C::XPL;                                                  // [3][TP][LD]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, lh = lane >> 5;
+  const int grp = lane >> 4, cb = 16 * (grp & 1), hk = grp >> 1, tq = (lane & 15) >> 2, tp = lane & 3;
+  const int wco = wave >> 1, wci = wave & 1;
+  const int pair = (int)blockIdx.x % a.pairs, split = (int)blockIdx.x / a.pairs;
+  const int cob = pair / a.ncib, cib = pair % a.ncib;
+  const int H = a.h, W = a.w;
+
+  const bool UPC = a.up_ca > 0;
+  const bool second = UPC && cib * 64 >= a.up_ca;
+  const int cx = UPC ? (second ? a.ci - a.up_ca : a.up_ca) : a.ci;
+  const int c0 = second ? cib * 64 - a.up_ca : cib * 64;
+  const bool half_res = UPC && !second;
+  __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(second ? a.x2 : a.x), 0,
+                                                                  (int)(second ? a.x2_bytes : a.x_bytes), 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, (int)a.dy_bytes, 0x00020000);
+
+  const int oct = tid & 7;
+  u32x4 sx[C::NX][2], sd[C::ND][2];
+  auto load_tile = [&](int tile) {
+    const int tx = tile % a.ntx;
+    const int t2 = tile / a.ntx;
+    const int ty = t2 % a.nty, img = t2 / a.nty;
+    const int y0 = ty * TR, x0 = tx * 32;
+#pragma unroll
+    for (int i = 0; i < C::NX; ++i) {
+      const int pix = (tid + i * 256) >> 3;
+      const int hy = pix / C::HWD, hx = pix - hy * C::HWD;
+      const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+      const bool ok = pix < C::HR * C::HWD && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      const int p = half_res ? (img * (H >> 1) + (iy >> 1)) * (W >> 1) + (ix >> 1) : (img * H + iy) * W + ix;
+      const unsigned off = ok ? (unsigned)((p * cx + c0 + oct * 8) * 4) : 0x80000000u;
+      sx[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)off, 0, 0);
+      sx[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)off, 16, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < C::ND; ++i) {
+      const int pix = (tid + i * 256) >> 3;
+      const int oy = y0 + (pix >> 5), ox = x0 + (pix & 31);
+      const bool ok = oy < H && ox < W;
+      const unsigned off = ok ? (unsigned)((((img * H + oy) * W + ox) * a.co + cob * 64 + oct * 8) * 4) : 0x80000000u;
+      sd[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_d, (int)off, 0, 0);
+      sd[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_d, (int)off, 16, 0);
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < C::NX; ++i) {
+      const int pix = (tid + i * 256) >> 3;
+      if (i < C::NX - 1 || pix < C::HR * C::HWD) {
+        u32x4 p0, p1, p2;
+        split3(sx[i][0], sx[i][1], p0, p1, p2);
+        unsigned short* q = Xs + pix * C::LD + oct * 8;
+        *reinterpret_cast<u32x4*>(q) = p0;
+        *reinterpret_cast<u32x4*>(q + C::XPL) = p1;
+        *reinterpret_cast<u32x4*>(q + 2 * C::XPL) = p2;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < C::ND; ++i) {
+      u32x4 p0, p1, p2;
+      split3(sd[i][0], sd[i][1], p0, p1, p2);
+      unsigned short* q = Ds + ((tid + i * 256) >> 3) * C::LD + oct * 8;
+      *reinterpret_cast<u32x4*>(q) = p0;
+      *reinterpret_cast<u32x4*>(q + C::DPL) = p1;
+      *reinterpret_cast<u32x4*>(q + 2 * C::DPL) = p2;
+    }
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+
+  const int a_lane = (8 * hk + tq) * C::LD + wco * 32 + cb + 4 * tp;
+  const int b_lane = (8 * hk + tq) * C::LD + wci * 32 + cb + 4 * tp;
+
+  if (split < a.ntiles) load_tile(split);
+  for (int tile = split; tile < a.ntiles; tile += a.P) {
+    store_tile();
+    __syncthreads();
+    if (tile + a.P < a.ntiles) load_tile(tile + a.P);
+#pragma unroll 2
+    for (int ks = 0; ks < 2 * TR; ++ks) {
+      const int r = ks >> 1, hf = ks & 1;
+      bf16x8w af[3];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) af[pl] = tr_fragment(Ds + pl * C::DPL + (r * 32 + 16 * hf) * C::LD + a_lane, C::LD);
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          bf16x8w bf[3];
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl)
+            bf[pl] = tr_fragment(Xs + pl * C::XPL + ((r + dy) * C::HWD + 16 * hf + dx) * C::LD + b_lane, C::LD);
+#pragma unroll
+          for (int ij = 2; ij >= 0; --ij)
+#pragma unroll
+            for (int i = 0; i <= ij; ++i)
+              acc[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[ij - i], acc[dy * 3 + dx], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+
+  const int ci_g = cib * 64 + wci * 32 + lr;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int co_g = cob * 64 + wco * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
+      atomicAdd(a.dw + ((size_t)co_g * 9 + t) * a.ci + ci_g, acc[t][v]);
+    }
+}
+
+bool wgrad_halo_f3_applicable(const udaseg_conv_desc* d, int up_ca) {
+  static int off = -1;   // UDASEG_F32_SPLIT=0 / UDASEG_NO_WGRAD_HALO=1: the fp32-MFMA split-K kernel everywhere
+  if (off < 0) {
+    const char* e = getenv("UDASEG_F32_SPLIT");
+    off = ((e && atoi(e) == 0) || getenv("UDASEG_NO_WGRAD_HALO") != nullptr) ? 1 : 0;
+  }
+  if (off || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1) return false;
+  if (d->ci % 64 != 0 || d->co % 64 != 0 || d->wi < 32) return false;
+  if (up_ca > 0 && (up_ca % 64 != 0 || up_ca >= d->ci || d->hi % 2 != 0 || d->wi % 2 != 0)) return false;
+  const long long px = (long long)d->n * d->hi * d->wi;
+  return px * d->ci * 4 < (1LL << 31) && px * d->co * 4 < (1LL << 31);
+}
+
+template <int TR>
+static int launch_wgrad_halo_f3_t(const udaseg_conv_desc* d, const float* x, const float* x2, int up_ca, const float* dy, float* dw,
+                                  hipStream_t s) {
+  using C = WF3<TR>;
+  WgradHaloF3Args a = {};
+  a.x = x; a.x2 = x2; a.dy = dy; a.dw = dw;
+  a.n = d->n; a.h = d->hi; a.w = d->wi; a.ci = d->ci; a.co = d->co; a.up_ca = up_ca;
+  a.ntx = cdiv(d->wi, 32); a.nty = cdiv(d->hi, TR); a.ntiles = d->n * a.ntx * a.nty;
+  a.ncib = d->ci / 64; a.pairs = a.ncib * (d->co / 64);
+  static int target = -1;      // blocks per launch (UDASEG_WGRAD_F3_BLOCKS: tuning aid)
+  if (target < 0) {
+    const char* e = getenv("UDASEG_WGRAD_F3_BLOCKS");
+    target = e ? atoi(e) : 160;      // measured on the r18 8 x 512^2 step: 96 / 128 / 192 / 256 blocks = 781.8 / 818.7 / 820.4 / 812.0 images/s
+    if (target < 1) target = 160;
+  }
+  int P = target / a.pairs;
+  if (P < 1) P = 1;
+  if (P > a.ntiles) P = a.ntiles;
+  a.P = P;
+  const long long px = (long long)d->n * d->hi * d->wi;
+  a.x_bytes = (unsigned)(up_ca > 0 ? (long long)d->n * (d->hi / 2) * (d->wi / 2) * up_ca * 4 : px * d->ci * 4);
+  a.x2_bytes = (unsigned)(up_ca > 0 ? px * (d->ci - up_ca) * 4 : 0);
+  a.dy_bytes = (unsigned)(px * d->co * 4);
+  auto kern = conv_wgrad_halo_f32x3_kernel<TR>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv_wgrad_halo_f32x3)");
+    attr_done = true;
+  }
+  static int kid = -1;
+  if (kid < 0) {
+    char nm[64];
+    snprintf(nm, sizeof(nm), "conv_wgrad_halo_f32x3_kernel<%d>", TR);
+    kid = kprof_id(nm);
+  }
+  hipEvent_t ev = kprof_begin(s);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(a.pairs * P)), dim3(256), C::LDS, s, a);
+  kprof_end(kid, ev, s, 2.0 * (double)px * d->co * 9.0 * d->ci);
+  UDASEG_LAUNCH_CHECK("conv_wgrad_halo_f32x3 launch");
+  return UDASEG_OK;
+}
+
 }  // namespace udaseg
 
 using namespace udaseg;
@@ -905,6 +1110,25 @@ extern "C" int udaseg_conv2d_wgrad_halo_bf16(const udaseg_conv_desc* d, const vo
   hipStream_t st = as_stream(stream);
   prof_begin(1, st);
   const int rc = launch_wgrad_halo(d, x, skip, up_ca, dy, dw, st);
+  prof_end(1, st, udaseg_conv_flops(d), 2, d);
+  return rc;
+}
+
+extern "C" int udaseg_conv2d_wgrad_halo_f32x3_ok(const udaseg_conv_desc* d, int up_ca) {
+  return d != nullptr && wgrad_halo_f3_applicable(d, up_ca) ? 1 : 0;
+}
+
+extern "C" int udaseg_conv2d_wgrad_halo_f32x3(const udaseg_conv_desc* d, const float* x, const float* skip, int up_ca, const float* dy,
+                                              float* dw, void* stream) {
+  UDASEG_CHECK_ARG(d && x && dy && dw, "conv2d_wgrad_halo_f32x3: NULL pointer");
+  UDASEG_CHECK_ARG((up_ca > 0) == (skip != nullptr), "conv2d_wgrad_halo_f32x3: up_ca=%d, skip %s", up_ca, skip ? "given" : "NULL");
+  if (!wgrad_halo_f3_applicable(d, up_ca)) {
+    set_error("conv2d_wgrad_halo_f32x3: geometry not supported (ask udaseg_conv2d_wgrad_halo_f32x3_ok first)");
+    return UDASEG_E_UNSUPPORTED;
+  }
+  hipStream_t st = as_stream(stream);
+  prof_begin(1, st);
+  const int rc = launch_wgrad_halo_f3_t<2>(d, x, skip, up_ca, dy, dw, st);
   prof_end(1, st, udaseg_conv_flops(d), 2, d);
   return rc;
 }

@@ -53,6 +53,25 @@ __device__ __forceinline__ void halfwave_sum_n(float (&x)[N]) {
   for (int v = 0; v < N; ++v) asm volatile("v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(x[v]));
 }
 
+// x = p0 + p1 + p2 exactly, eight values at a time (two 16-byte fp32 pieces -> three bf16x8 fragments pieces)
+__device__ __forceinline__ void split3(const u32x4 lo, const u32x4 hi, u32x4& p0, u32x4& p1, u32x4& p2) {
+  const f32x4 lf = __builtin_bit_cast(f32x4, lo), hf = __builtin_bit_cast(f32x4, hi);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float a = e < 2 ? lf[2 * e] : hf[2 * e - 4];
+    float b = e < 2 ? lf[2 * e + 1] : hf[2 * e - 3];
+    const unsigned h = pack_bf16x2(a, b);
+    a -= bf_lo(h);
+    b -= bf_hi(h);
+    const unsigned m = pack_bf16x2(a, b);
+    a -= bf_lo(m);
+    b -= bf_hi(m);
+    p0[e] = h;
+    p1[e] = m;
+    p2[e] = pack_bf16x2(a, b);
+  }
+}
+
 // f64 partial-sum scratch of launches with more than 1024 blocks (udaseg_set_stats_scratch): the current device's, when it holds
 // HALO_SCR_REPLICAS x 2 x co doubles, else nullptr; and the launch that folds it into the [R][2][co] accumulators
 double* halo_stats_scratch(int co);

@@ -420,6 +420,7 @@ class Plan:
         self.conv_flops = 0.0
         self._packed = None
         self._bnb = {}                    # id(conv output y) -> BN-backward sums already made by the consumer's data gradient
+        self._wgrad_halo = USE_WGRAD_HALO and (self.bf16 or USE_F32_SPLIT)      # halo-resident weight gradients (bf16 / fp32 split)
         if training and save and SIDE_STREAM_WGRAD and PREPACK_DGRAD:
             self._prepack_dgrad_weights()
 
@@ -637,7 +638,7 @@ class Plan:
             wst = self.st
         if isinstance(x, UpCat):
             gw = self.gw(conv)
-            if self.bf16 and USE_WGRAD_HALO and x.skip is not None and K.conv2d_wgrad_halo_ok(d, x.a.shape[-1]):
+            if self._wgrad_halo and x.skip is not None and K.conv2d_wgrad_halo_ok(d, x.a.shape[-1], f32=not self.bf16):
                 K.conv2d_wgrad_halo(d, x.a, x.skip, dy, gw, up=True, st=wst)      # both sources in one launch
             else:
                 K.conv2d_wgrad_part(d, x.a, 0, True, dy, gw, True, wst)
@@ -655,7 +656,7 @@ class Plan:
             return
         if isinstance(x, LazyAct):
             K.conv2d_wgrad_bnin(d, x.y, x.scale, x.shift, x.act, x.slope, dy, self.gw(conv), True, wst)
-        elif self.bf16 and USE_WGRAD_HALO and K.conv2d_wgrad_halo_ok(d):
+        elif self._wgrad_halo and K.conv2d_wgrad_halo_ok(d, f32=not self.bf16):
             K.conv2d_wgrad_halo(d, x, None, dy, self.gw(conv), st=wst)
         else:
             K.conv2d_wgrad(d, x, dy, self.gw(conv), True, wst)

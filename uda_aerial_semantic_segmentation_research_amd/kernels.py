@@ -181,15 +181,20 @@ def bn_bwd_apply_recompute(dz, y, fwd_scale, fwd_shift, save_mean, save_rstd, ga
           "bn_bwd_apply_recompute_bf16")
 
 
-def conv2d_wgrad_halo_ok(d, up_ca=0):
+def conv2d_wgrad_halo_ok(d, up_ca=0, f32=False):
+    if f32:
+        return bool(_lib.load().udaseg_conv2d_wgrad_halo_f32x3_ok(_byref(d), up_ca))
     return bool(_lib.load().udaseg_conv2d_wgrad_halo_bf16_ok(_byref(d), up_ca))
 
 
 def conv2d_wgrad_halo(d, x, skip, dy, dw, up=False, st=None):
-    """dW += weight gradient of a stride-1 3x3 layer (channel counts multiples of 64), bf16: halo-resident kernel.  up: x is the
-    half-resolution source of a fused decoder input, skip the other one."""
-    check(_lib.load().udaseg_conv2d_wgrad_halo_bf16(_byref(d), x.data_ptr(), _ptr(skip), x.shape[-1] if up else 0, dy.data_ptr(),
-                                                     dw.data_ptr(), st if st is not None else stream()), "conv2d_wgrad_halo_bf16")
+    """dW += weight gradient of a stride-1 3x3 layer (channel counts multiples of 64) on the halo-resident kernel: bf16 tensors,
+    or fp32 tensors with the exact three-term split.  up: x is the half-resolution source of a fused decoder input, skip the
+    other one."""
+    fn, name = ((_lib.load().udaseg_conv2d_wgrad_halo_f32x3, "conv2d_wgrad_halo_f32x3") if x.dtype == torch.float32
+                else (_lib.load().udaseg_conv2d_wgrad_halo_bf16, "conv2d_wgrad_halo_bf16"))
+    check(fn(_byref(d), x.data_ptr(), _ptr(skip), x.shape[-1] if up else 0, dy.data_ptr(), dw.data_ptr(),
+             st if st is not None else stream()), name)
 
 
 def conv2d_wgrad_bnin(d, y_prev, in_scale, in_shift, in_act, in_slope, dy, dw, accumulate=False, st=None):
