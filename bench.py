@@ -36,6 +36,13 @@ import torch.distributed as dist
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # same guide: ~2.5 PF dense bf16 (never the 2:1-sparsity figure)
+F32X3_MFMA_PRODUCTS = 6             # bf16 MFMA products per fp32 product in the three-term-split kernels (i + j <= 2 of 3 x 3)
+ARITHMETIC_FP32 = ("fp32 tensors, weights, gradients and accumulation.  Stride-1 3x3 convolutions (forward, data and weight "
+                   "gradient where the channel counts allow) evaluate each fp32 product on the bf16 matrix pipe from an EXACT "
+                   "three-term split of both operands (x = bf16(x) + bf16(x - x0) + bf16(x - x0 - x1); the six products with "
+                   "i + j <= 2, fp32 accumulate; what is left out is <= 2^-23 of a product = one fp32 ulp; measured against f64 "
+                   "next to the fp32-MFMA kernels in tests/test_gpu_f32x3.py); every other layer on v_mfma_f32_32x32x2_f32.  "
+                   "UDASEG_F32_SPLIT=0 runs everything on the fp32-MFMA kernels (also-leg 'fp32-MFMA kernels only').")
 WORKLOAD_TEXT = {
     "segmentation": "source-only CE train step (zero_grad,fwd,CE,bwd,allreduce,Adam)",
     "adversarial": "adversarial iteration (D step on 8 source + 8 target images, then segmenter step: CE + lambda*BCE)",
@@ -319,12 +326,23 @@ def roofline_leg(step, model, trainer, dtype, psteps=3, layer_table=False, pmc_t
         "other_ms": round(serial_ms - (kern_ms + bn_ms) / psteps, 3)}
     kern.sort(key=lambda k: -k[1])
     dom = kern[0]                                   # the kernel symbol with the most device time
-    achieved = dom[2] / (dom[1] * 1e-3) / 1e12
+    algorithmic = dom[2] / (dom[1] * 1e-3) / 1e12
     conv_ms = sum(k[1] for k in kern) / psteps
     peak = BF16_MFMA_PEAK_TFLOPS if dtype == "bf16" else FP32_MFMA_PEAK_TFLOPS
+    split = "f32x3" in dom[0]
+    # the three-term-split kernels evaluate every fp32 product as SIX bf16 MFMA products (csrc/conv_halo_f32x3.hip): the pipe that
+    # bounds them is the bf16 one and the work it does is 6 x the algorithmic FLOPs -- priced against the dense bf16 peak
+    achieved = algorithmic * (F32X3_MFMA_PRODUCTS if split else 1)
+    if split:
+        peak = BF16_MFMA_PEAK_TFLOPS
     traffic, traffic_src = pmc_traffic(dom[0], pmc_tag)
     return {"bound": "mfma", "kernel": dom[0], "achieved": round(achieved, 2), "peak": peak,
-            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+            "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+            "algorithmic_tflops": round(algorithmic, 2),
+            "pipe": ("bf16 MFMA, 6 products per fp32 product (exact three-term operand split, fp32 accumulation): achieved = 6 x "
+                     "algorithmic FLOPs / launch time, peak = dense bf16") if split else
+                    ("bf16 MFMA" if dtype == "bf16" else "fp32 MFMA"),
+            "traffic": traffic,
             "traffic_source": (traffic_src + " (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this symbol; "
                                "counters cannot be collected from inside the timed process)") if traffic_src else None,
             "launches_per_step": dom[3] // psteps, "avg_launch_us": round(1e3 * dom[1] / dom[3], 2),
@@ -342,14 +360,24 @@ def roofline_leg(step, model, trainer, dtype, psteps=3, layer_table=False, pmc_t
                                                "conv_mfma_util_per_gpu uses the logical 133.30 GFLOP per image",
                                  "by_kernel": {k[0]: {"ms_per_step": round(k[1] / psteps, 3),
                                                       "tflops": round(k[2] / (k[1] * 1e-3) / 1e12, 1),
+                                                      **({"bf16_pipe_tflops": round(F32X3_MFMA_PRODUCTS * k[2] / (k[1] * 1e-3) / 1e12, 1)}
+                                                         if "f32x3" in k[0] else {}),
                                                       "launches_per_step": k[3] // psteps} for k in kern}}}
 
 
-def also_leg(name, workload, encoder, dtype, batch, size, classes, dev, steps=10, warmup=6, cpu=False):
-    """A short informational leg of another BASELINE config in the same process (N=1 only)."""
-    step, model, trainer = build_leg(workload, encoder, dtype, batch, size, classes, dev, 0, 1, False)
-    dt, ev_ms, loss = timed_region(step, steps, warmup, 1, dev, False)
-    roof = roofline_leg(step, model, trainer, dtype, psteps=2, pmc_tag="cfg3" if workload == "adversarial" else "cfg5")
+def also_leg(name, workload, encoder, dtype, batch, size, classes, dev, steps=10, warmup=6, cpu=False, split=True):
+    """A short informational leg of another BASELINE config in the same process (N=1 only).  split=False: the fp32 network
+    built without the three-term-split kernels (what UDASEG_F32_SPLIT=0 gives)."""
+    from uda_aerial_semantic_segmentation_research_amd import engine as _engine
+    was_split = _engine.USE_F32_SPLIT
+    _engine.USE_F32_SPLIT = was_split and split
+    try:
+        step, model, trainer = build_leg(workload, encoder, dtype, batch, size, classes, dev, 0, 1, False)
+        dt, ev_ms, loss = timed_region(step, steps, warmup, 1, dev, False)
+        roof = roofline_leg(step, model, trainer, dtype, psteps=2,
+                            pmc_tag="cfg3" if workload == "adversarial" else ("cfg5" if dtype == "bf16" else "fp32"))
+    finally:
+        _engine.USE_F32_SPLIT = was_split
     value = batch * steps / dt
     gf = CONV_GFLOP_PER_IMAGE.get((workload, encoder, size))
     peak = BF16_MFMA_PEAK_TFLOPS if dtype == "bf16" else FP32_MFMA_PEAK_TFLOPS
@@ -470,6 +498,9 @@ def main():
                                    f"batch {args.batch}x3x{args.size}x{args.size} per GPU, {args.classes} classes, random init",
                        "global_batch": args.batch * world, "image": f"{args.size}x{args.size}", "parallelism": f"dp{world}",
                        "final_loss": round(final_loss, 5),
+                       "arithmetic": ARITHMETIC_FP32 if args.dtype == "fp32" else
+                       "bf16 storage of activations / weight copies, bf16 MFMA with fp32 accumulation, fp32 master weights, "
+                       "statistics, gradients and optimizer state",
                        # whole-job conv FLOP rate per GPU over the dense MFMA peak of the dtype; only for workloads whose conv
                        # FLOPs per image are tabulated
                        "conv_mfma_util_per_gpu": round(value * gf / 1e3 / world / peak, 4) if gf else None},
@@ -484,6 +515,8 @@ def main():
             del step, model, trainer
             torch.cuda.empty_cache()
             out["also"] = [
+                also_leg("BASELINE cfg 2 on the fp32-MFMA kernels only (UDASEG_F32_SPLIT=0)", "segmentation", "resnet18", "fp32", 8, 512,
+                         args.classes, dev, split=False),
                 also_leg("BASELINE cfg 3", "adversarial", "resnet18", "bf16", 8, 512, args.classes, dev,
                          cpu=not args.no_cpu_baseline),
                 also_leg("BASELINE cfg 5 (per-GPU work)", "segmentation", "resnet50", "bf16", 8, 768, args.classes, dev),

@@ -13,8 +13,9 @@ import json, sys
 d = json.loads(open("gpurun_out/sweep_tmp.json").read().strip().splitlines()[-1])
 ts = d["roofline"].get("time_split", {})
 bn = ts.get("batchnorm_passes", {})
-print(sys.argv[1], "leg", sys.argv[2], d["value"], "img/s", d["ms_per_step"], "ms  bn_ms", bn.get("ms"),
-      {k[:22]: (v["ms"], v["TB_per_s"]) for k, v in bn.get("by_kernel", {}).items()})
+ck = d["roofline"]["all_conv_kernels"]["by_kernel"]
+print(sys.argv[1], "leg", sys.argv[2], d["value"], "img/s", d["ms_per_step"], "ms  serial", ts.get("serial_step_ms"), " bn_ms", bn.get("ms"),
+      " conv:", {k.replace("conv_", "").replace("_kernel", "")[:26]: v["ms_per_step"] for k, v in list(ck.items())[:6]})
 PY
 done; done
 cat $out

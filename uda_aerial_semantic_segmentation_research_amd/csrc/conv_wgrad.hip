@@ -26,6 +26,8 @@
 //  * the same with loads two K-tiles ahead: 89.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "halo_common.h"
 
@@ -829,18 +831,21 @@ struct WgradHaloF3Args {
   unsigned x_bytes, x2_bytes, dy_bytes;
 };
 
-template <int TR>
+template <int TR, int NWV>
 struct WF3 {
+  static constexpr int NT = 64 * NWV;                  // 4 waves: each owns all nine taps of its 32 x 32 (co, ci) block; 8 waves: waves
+                                                       // 0-3 taps 0-4, waves 4-7 taps 5-8 (two waves per SIMD cover each other's stalls)
   static constexpr int HR = TR + 2, HWD = 34, TP = TR * 32;
   static constexpr int LD = 96;                        // elements per LDS pixel row (see WH_LD)
   static constexpr int XPL = HR * HWD * LD, DPL = TP * LD;     // elements per plane
-  static constexpr int NX = (HR * HWD * 8 + 255) / 256, ND = TP * 8 / 256;
+  static constexpr int NX = (HR * HWD * 8 + NT - 1) / NT, ND = (TP * 8 + NT - 1) / NT;
   static constexpr int LDS = 3 * (XPL + DPL) * 2;
+  static constexpr int NACC = NWV == 4 ? 9 : 5;
 };
 
-template <int TR>
-__global__ __launch_bounds__(256, 1) void conv_wgrad_halo_f32x3_kernel(const WgradHaloF3Args a) {
-  using C = WF3<TR>;
+template <int TR, int NWV>
+__global__ __launch_bounds__(64 * NWV, NWV / 4) void conv_wgrad_halo_f32x3_kernel(const WgradHaloF3Args a) {
+  using C = WF3<TR, NWV>;
   extern __shared__ __attribute__((aligned(16))) char whs3[];
   unsigned short* Xs = reinterpret_cast<unsigned short*>(whs3);                         // [3][HR * 34][LD]
   unsigned short* Ds = Xs + 3 * C::XPL;                                                  // [3][TP][LD]
@@ -848,7 +853,8 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_halo_f32x3_kernel(const Wgr
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 31, lh = lane >> 5;
   const int grp = lane >> 4, cb = 16 * (grp & 1), hk = grp >> 1, tq = (lane & 15) >> 2, tp = lane & 3;
-  const int wco = wave >> 1, wci = wave & 1;
+  const int wq = wave & 3, tg = wave >> 2;             // 32 x 32 quadrant of the block's 64 x 64; tap group
+  const int wco = wq >> 1, wci = wq & 1;
   const int pair = (int)blockIdx.x % a.pairs, split = (int)blockIdx.x / a.pairs;
   const int cob = pair / a.ncib, cib = pair % a.ncib;
   const int H = a.h, W = a.w;
@@ -871,7 +877,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_halo_f32x3_kernel(const Wgr
     const int y0 = ty * TR, x0 = tx * 32;
 #pragma unroll
     for (int i = 0; i < C::NX; ++i) {
-      const int pix = (tid + i * 256) >> 3;
+      const int pix = (tid + i * C::NT) >> 3;
       const int hy = pix / C::HWD, hx = pix - hy * C::HWD;
       const int iy = y0 + hy - 1, ix = x0 + hx - 1;
       const bool ok = pix < C::HR * C::HWD && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
@@ -882,9 +888,9 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_halo_f32x3_kernel(const Wgr
     }
 #pragma unroll
     for (int i = 0; i < C::ND; ++i) {
-      const int pix = (tid + i * 256) >> 3;
+      const int pix = (tid + i * C::NT) >> 3;
       const int oy = y0 + (pix >> 5), ox = x0 + (pix & 31);
-      const bool ok = oy < H && ox < W;
+      const bool ok = pix < C::TP && oy < H && ox < W;
       const unsigned off = ok ? (unsigned)((((img * H + oy) * W + ox) * a.co + cob * 64 + oct * 8) * 4) : 0x80000000u;
       sd[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_d, (int)off, 0, 0);
       sd[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_d, (int)off, 16, 0);
@@ -893,7 +899,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_halo_f32x3_kernel(const Wgr
   auto store_tile = [&]() {
 #pragma unroll
     for (int i = 0; i < C::NX; ++i) {
-      const int pix = (tid + i * 256) >> 3;
+      const int pix = (tid + i * C::NT) >> 3;
       if (i < C::NX - 1 || pix < C::HR * C::HWD) {
         u32x4 p0, p1, p2;
         split3(sx[i][0], sx[i][1], p0, p1, p2);
@@ -905,23 +911,43 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_halo_f32x3_kernel(const Wgr
     }
 #pragma unroll
     for (int i = 0; i < C::ND; ++i) {
-      u32x4 p0, p1, p2;
-      split3(sd[i][0], sd[i][1], p0, p1, p2);
-      unsigned short* q = Ds + ((tid + i * 256) >> 3) * C::LD + oct * 8;
-      *reinterpret_cast<u32x4*>(q) = p0;
-      *reinterpret_cast<u32x4*>(q + C::DPL) = p1;
-      *reinterpret_cast<u32x4*>(q + 2 * C::DPL) = p2;
+      const int pix = (tid + i * C::NT) >> 3;
+      if (i < C::ND - 1 || pix < C::TP) {
+        u32x4 p0, p1, p2;
+        split3(sd[i][0], sd[i][1], p0, p1, p2);
+        unsigned short* q = Ds + pix * C::LD + oct * 8;
+        *reinterpret_cast<u32x4*>(q) = p0;
+        *reinterpret_cast<u32x4*>(q + C::DPL) = p1;
+        *reinterpret_cast<u32x4*>(q + 2 * C::DPL) = p2;
+      }
     }
   };
 
-  f32x16 acc[9];
+  f32x16 acc[C::NACC];
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < C::NACC; ++t)
 #pragma unroll
     for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
 
   const int a_lane = (8 * hk + tq) * C::LD + wco * 32 + cb + 4 * tp;
   const int b_lane = (8 * hk + tq) * C::LD + wci * 32 + cb + 4 * tp;
+
+  // the nine taps (T0 .. T0 + NTAP) of one 16-pixel K step: three plane reads per operand feed six MFMAs
+  auto taps = [&](auto t0c, auto ntc, const bf16x8w (&af)[3], int r, int hf) {
+    constexpr int T0 = decltype(t0c)::value, NTAP = decltype(ntc)::value;
+#pragma unroll
+    for (int tt = 0; tt < NTAP; ++tt) {
+      const int t = T0 + tt, dy = t / 3, dx = t % 3;
+      bf16x8w bf[3];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        bf[pl] = tr_fragment(Xs + pl * C::XPL + ((r + dy) * C::HWD + 16 * hf + dx) * C::LD + b_lane, C::LD);
+#pragma unroll
+      for (int ij = 2; ij >= 0; --ij)
+#pragma unroll
+        for (int i = 0; i <= ij; ++i) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[ij - i], acc[tt], 0, 0, 0);
+    }
+  };
 
   if (split < a.ntiles) load_tile(split);
   for (int tile = split; tile < a.ntiles; tile += a.P) {
@@ -934,32 +960,28 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_halo_f32x3_kernel(const Wgr
       bf16x8w af[3];
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) af[pl] = tr_fragment(Ds + pl * C::DPL + (r * 32 + 16 * hf) * C::LD + a_lane, C::LD);
-#pragma unroll
-      for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-          bf16x8w bf[3];
-#pragma unroll
-          for (int pl = 0; pl < 3; ++pl)
-            bf[pl] = tr_fragment(Xs + pl * C::XPL + ((r + dy) * C::HWD + 16 * hf + dx) * C::LD + b_lane, C::LD);
-#pragma unroll
-          for (int ij = 2; ij >= 0; --ij)
-#pragma unroll
-            for (int i = 0; i <= ij; ++i)
-              acc[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[ij - i], acc[dy * 3 + dx], 0, 0, 0);
-        }
+      if constexpr (NWV == 4) {
+        taps(std::integral_constant<int, 0>{}, std::integral_constant<int, 9>{}, af, r, hf);
+      } else {
+        if (tg == 0) taps(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{}, af, r, hf);
+        else taps(std::integral_constant<int, 5>{}, std::integral_constant<int, 4>{}, af, r, hf);
+      }
     }
     __syncthreads();
   }
 
   const int ci_g = cib * 64 + wci * 32 + lr;
+  const int tbase = NWV == 4 ? 0 : 5 * tg, ntap = NWV == 4 ? 9 : (tg == 0 ? 5 : 4);
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int tt = 0; tt < C::NACC; ++tt) {
+    if (tt < ntap) {
 #pragma unroll
-    for (int v = 0; v < 16; ++v) {
-      const int co_g = cob * 64 + wco * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
-      atomicAdd(a.dw + ((size_t)co_g * 9 + t) * a.ci + ci_g, acc[t][v]);
+      for (int v = 0; v < 16; ++v) {
+        const int co_g = cob * 64 + wco * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
+        atomicAdd(a.dw + ((size_t)co_g * 9 + tbase + tt) * a.ci + ci_g, acc[tt][v]);
+      }
     }
+  }
 }
 
 bool wgrad_halo_f3_applicable(const udaseg_conv_desc* d, int up_ca) {
@@ -975,10 +997,10 @@ bool wgrad_halo_f3_applicable(const udaseg_conv_desc* d, int up_ca) {
   return px * d->ci * 4 < (1LL << 31) && px * d->co * 4 < (1LL << 31);
 }
 
-template <int TR>
+template <int TR, int NWV>
 static int launch_wgrad_halo_f3_t(const udaseg_conv_desc* d, const float* x, const float* x2, int up_ca, const float* dy, float* dw,
                                   hipStream_t s) {
-  using C = WF3<TR>;
+  using C = WF3<TR, NWV>;
   WgradHaloF3Args a = {};
   a.x = x; a.x2 = x2; a.dy = dy; a.dw = dw;
   a.n = d->n; a.h = d->hi; a.w = d->wi; a.ci = d->ci; a.co = d->co; a.up_ca = up_ca;
@@ -987,8 +1009,11 @@ static int launch_wgrad_halo_f3_t(const udaseg_conv_desc* d, const float* x, con
   static int target = -1;      // blocks per launch (UDASEG_WGRAD_F3_BLOCKS: tuning aid)
   if (target < 0) {
     const char* e = getenv("UDASEG_WGRAD_F3_BLOCKS");
-    target = e ? atoi(e) : 160;      // measured on the r18 8 x 512^2 step: 96 / 128 / 192 / 256 blocks = 781.8 / 818.7 / 820.4 / 812.0 images/s
-    if (target < 1) target = 160;
+    target = e ? atoi(e) : 120;      // r18 8 x 512^2 step, 8-wave blocks: 64 / 96 / 112 / 128 / 144 blocks = 741 / 823 / 845 / 840 / 826
+                                     // images/s (the kernel alone keeps getting faster with more blocks -- 2.5 / 2.3 / 2.2 / 1.9 ms
+                                     // per step -- but it runs beside the main stream's chain and takes its CUs);
+                                     // 4-wave blocks: 96 / 128 / 192 / 256 = 782 / 819 / 820 / 812 (profiles/r03_f32x3.txt)
+    if (target < 1) target = 120;
   }
   int P = target / a.pairs;
   if (P < 1) P = 1;
@@ -998,7 +1023,7 @@ static int launch_wgrad_halo_f3_t(const udaseg_conv_desc* d, const float* x, con
   a.x_bytes = (unsigned)(up_ca > 0 ? (long long)d->n * (d->hi / 2) * (d->wi / 2) * up_ca * 4 : px * d->ci * 4);
   a.x2_bytes = (unsigned)(up_ca > 0 ? px * (d->ci - up_ca) * 4 : 0);
   a.dy_bytes = (unsigned)(px * d->co * 4);
-  auto kern = conv_wgrad_halo_f32x3_kernel<TR>;
+  auto kern = conv_wgrad_halo_f32x3_kernel<TR, NWV>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
@@ -1008,11 +1033,11 @@ static int launch_wgrad_halo_f3_t(const udaseg_conv_desc* d, const float* x, con
   static int kid = -1;
   if (kid < 0) {
     char nm[64];
-    snprintf(nm, sizeof(nm), "conv_wgrad_halo_f32x3_kernel<%d>", TR);
+    snprintf(nm, sizeof(nm), "conv_wgrad_halo_f32x3_kernel<%d, %d>", TR, NWV);
     kid = kprof_id(nm);
   }
   hipEvent_t ev = kprof_begin(s);
-  hipLaunchKernelGGL(kern, dim3((unsigned)(a.pairs * P)), dim3(256), C::LDS, s, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(a.pairs * P)), dim3(C::NT), C::LDS, s, a);
   kprof_end(kid, ev, s, 2.0 * (double)px * d->co * 9.0 * d->ci);
   UDASEG_LAUNCH_CHECK("conv_wgrad_halo_f32x3 launch");
   return UDASEG_OK;
@@ -1128,7 +1153,13 @@ extern "C" int udaseg_conv2d_wgrad_halo_f32x3(const udaseg_conv_desc* d, const f
   }
   hipStream_t st = as_stream(stream);
   prof_begin(1, st);
-  const int rc = launch_wgrad_halo_f3_t<2>(d, x, skip, up_ca, dy, dw, st);
+  static int waves = -1;       // UDASEG_WGRAD_F3_WAVES = 4 | 8 (A/B)
+  if (waves < 0) {
+    const char* e = getenv("UDASEG_WGRAD_F3_WAVES");
+    waves = (e && atoi(e) == 4) ? 4 : 8;
+  }
+  const int rc = waves == 4 ? launch_wgrad_halo_f3_t<2, 4>(d, x, skip, up_ca, dy, dw, st)
+                            : launch_wgrad_halo_f3_t<2, 8>(d, x, skip, up_ca, dy, dw, st);
   prof_end(1, st, udaseg_conv_flops(d), 2, d);
   return rc;
 }
