@@ -288,6 +288,9 @@ def roofline_leg(step, model, trainer, dtype, psteps=3, layer_table=False, pmc_t
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     _engine.SIDE_STREAM_WGRAD = False
+    for _ in range(2):          # the profiling events above are released asynchronously: keep that out of the timed steps
+        step()
+    torch.cuda.synchronize()
     e0.record()
     for _ in range(psteps):
         step()

@@ -836,7 +836,10 @@ struct WF3 {
   static constexpr int NT = 64 * NWV;                  // 4 waves: each owns all nine taps of its 32 x 32 (co, ci) block; 8 waves: waves
                                                        // 0-3 taps 0-4, waves 4-7 taps 5-8 (two waves per SIMD cover each other's stalls)
   static constexpr int HR = TR + 2, HWD = 34, TP = TR * 32;
-  static constexpr int LD = 96;                        // elements per LDS pixel row (see WH_LD)
+  // elements per LDS pixel row: 64 channels + pad.  96 (192 B, WH_LD) for the 2-row tile; 72 (144 B) for the 4-row tile -- the four
+  // rows of a transposed read then start at bytes 0, 144, 32, 176 (mod 256): still four disjoint 32-byte bank ranges, and three
+  // planes of a 6 x 34 halo + 128 dy pixels fit the 160 KB (143 KB)
+  static constexpr int LD = TR >= 4 ? 72 : 96;
   static constexpr int XPL = HR * HWD * LD, DPL = TP * LD;     // elements per plane
   static constexpr int NX = (HR * HWD * 8 + NT - 1) / NT, ND = (TP * 8 + NT - 1) / NT;
   static constexpr int LDS = 3 * (XPL + DPL) * 2;
@@ -1158,8 +1161,14 @@ extern "C" int udaseg_conv2d_wgrad_halo_f32x3(const udaseg_conv_desc* d, const f
     const char* e = getenv("UDASEG_WGRAD_F3_WAVES");
     waves = (e && atoi(e) == 4) ? 4 : 8;
   }
+  static int rows = -1;        // UDASEG_WGRAD_F3_ROWS = 2 | 4 (A/B)
+  if (rows < 0) {
+    const char* e = getenv("UDASEG_WGRAD_F3_ROWS");
+    rows = (e && atoi(e) == 2) ? 2 : 4;      // 4 x 32 pixel tiles: 2.16 against 2.24 ms per r18 step for the 2-row tile (half the barriers per MFMA)
+  }
   const int rc = waves == 4 ? launch_wgrad_halo_f3_t<2, 4>(d, x, skip, up_ca, dy, dw, st)
-                            : launch_wgrad_halo_f3_t<2, 8>(d, x, skip, up_ca, dy, dw, st);
+                 : rows == 4 ? launch_wgrad_halo_f3_t<4, 8>(d, x, skip, up_ca, dy, dw, st)
+                             : launch_wgrad_halo_f3_t<2, 8>(d, x, skip, up_ca, dy, dw, st);
   prof_end(1, st, udaseg_conv_flops(d), 2, d);
   return rc;
 }

@@ -57,6 +57,8 @@ FUSE_BN_APPLY_1X1_ONLY = os.environ.get("UDASEG_FUSE_BN_APPLY", "2") == "2"
 USE_WGRAD_HALO = os.environ.get("UDASEG_WGRAD_HALO", "1") != "0"
 
 
+# HIP priority of that stream (0 = default, -1 = high): UDASEG_SIDE_PRIORITY (measurement)
+SIDE_STREAM_PRIORITY = int(os.environ.get("UDASEG_SIDE_PRIORITY", "0"))
 _SIDE_STREAMS = {}   # device -> the one side HIP stream the weight gradients of every network on that device run on
 _ARENA_OWNERS = {}   # parameter-arena storage pointer -> weakref of the ArenaModule that owns it
 
@@ -319,7 +321,7 @@ class ArenaModule(nn.Module):
         dev = self._arena.device
         st = _SIDE_STREAMS.get(dev)
         if st is None:
-            st = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
+            st = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev, priority=SIDE_STREAM_PRIORITY)
         return st
 
     def tick_batchnorm_counters(self):
