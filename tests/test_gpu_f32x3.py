@@ -107,7 +107,7 @@ def force_cfg(K):
 
 
 @pytest.mark.parametrize("case", CASES, ids=[("n%d_%dx%d_ci%d_co%d" % c) for c in CASES])
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3], ids=["heuristic", "32ch_blocks", "64ch_blocks", "64ch_4rows"])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8], ids=["heuristic", "8x32x32ch", "8x32x64ch", "4x32x64ch", "16x32x64ch", "ws_8x32x64ch", "ws_4x32x64ch", "ws_8x32x32ch", "ws_16x32x32ch"])
 def test_conv_f32x3_fwd_dgrad_fp32_grade(K, case, cfg, force_cfg):
     n, h, w, ci, co = case
     force_cfg(cfg)

@@ -57,6 +57,7 @@ struct F3Args {
   float bnb_slope;
   int ntx, nty, ncb, nk16;
   unsigned x_bytes, x2_bytes, w_plane_bytes, y_bytes, y2_bytes, bnb_bytes;
+  int probe;            // UDASEG_F3_PROBE (timing-only diagnosis, results wrong): 1 no MFMAs, 2 no halo split / LDS stores, 4 no epilogue, 8 no fragment reads
 };
 
 template <int WM, int WN, int RPW>
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_f32x3_kernel(const F3
   auto store_chunk = [&]() {
 #pragma unroll
     for (int i = 0; i < C::NI; ++i) {
-      if (i < C::NI - 1 || tid + i * C::NT < C::NPIECE) {
+      if ((i < C::NI - 1 || tid + i * C::NT < C::NPIECE) && !(a.probe & 2)) {
         u32x4 p0, p1, p2;
         split3(stage[i][0], stage[i][1], p0, p1, p2);
         *reinterpret_cast<u32x4*>(smem + soffl[i]) = p0;
@@ -231,12 +232,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_f32x3_kernel(const F3
       for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) bf[dy][pl] = *reinterpret_cast<const u32x4*>(wb + (dy * 3 + pl) * 1024);
+      // the halo row of step s + 1 is requested before the MFMAs of step s
+      u32x4 pf[2][3];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) pf[0][pl] = *reinterpret_cast<const u32x4*>(smem + pl * C::PLANE + poff[dx]);
 #pragma unroll
       for (int s = 0; s < C::S; ++s) {
-        u32x4 pf[3];
+        if (s + 1 < C::S && !(a.probe & 8)) {
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-          pf[pl] = *reinterpret_cast<const u32x4*>(smem + pl * C::PLANE + poff[dx] + s * C::HWD * 32);
+          for (int pl = 0; pl < 3; ++pl)
+            pf[(s + 1) & 1][pl] = *reinterpret_cast<const u32x4*>(smem + pl * C::PLANE + poff[dx] + (s + 1) * C::HWD * 32);
+        }
         // smallest terms first (weight piece i x pixel piece j, i + j <= 2); consecutive MFMAs go to DIFFERENT accumulators (the
         // up to three output rows this halo row feeds)
 #pragma unroll
@@ -246,9 +252,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_f32x3_kernel(const F3
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
               const int r = s - dy;
-              if (r >= 0 && r < RPW)
+              if (r >= 0 && r < RPW && !(a.probe & 1))
                 acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bf[dy][i]),
-                                                                 __builtin_bit_cast(bf16x8, pf[ij - i]), acc[r], 0, 0, 0);
+                                                                 __builtin_bit_cast(bf16x8, pf[s & 1][ij - i]), acc[r], 0, 0, 0);
             }
       }
       gbuf ^= 1;
@@ -256,116 +262,238 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_f32x3_kernel(const F3
     __syncthreads();                 // every wave is done with the halo before the next chunk overwrites it
   }
 
-  // ---- epilogue.  acc[r][v] of lane (lp, lh): channel nb*32 + (v&3) + 8*(v>>2) + 4*lh of pixel (row wm*RPW + r, column lp)
-  const int cbase = nb * 32;
-  float* yb = a.y;
-  int ldc = a.co, csub = 0;
-  unsigned ybytes = a.y_bytes;
-  if (a.split_n > 0) {
-    if (cbase >= a.split_n) { yb = a.y2; ldc = a.co - a.split_n; csub = a.split_n; ybytes = a.y2_bytes; }
-    else ldc = a.split_n;
+  if (a.probe & 4) {
+    if (acc[0][0] == 123.456f) a.y[0] = acc[0][1];      // keep the accumulators alive
+    return;
   }
-  __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(yb, 0, (int)ybytes, 0x00020000);
-  const bool want_stats = a.stats != nullptr && a.bnb_y == nullptr;
-  const bool want_bnb = a.bnb_y != nullptr;
-  __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(want_bnb ? a.bnb_y : a.x), 0,
-                                                                  (int)(want_bnb ? a.bnb_bytes : 0u), 0x00020000);
-  float sA[16], sB[16];
-#pragma unroll
-  for (int v = 0; v < 16; ++v) sA[v] = sB[v] = 0.f;
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const int c0 = cbase + 8 * g + 4 * lh;          // this lane's 4 consecutive channels of group g
-    const bool cok = wave_live && c0 < a.co;
-    f32x4 bq = {0.f, 0.f, 0.f, 0.f}, sc = bq, sh = bq, mu = bq, rsd = bq;
-    if (a.bias != nullptr && cok) bq = *reinterpret_cast<const f32x4*>(a.bias + c0);
-    if (want_bnb && cok) {
-      mu = *reinterpret_cast<const f32x4*>(a.bnb_mean + c0);
-      rsd = *reinterpret_cast<const f32x4*>(a.bnb_rstd + c0);
-      const f32x4 gm = *reinterpret_cast<const f32x4*>(a.bnb_gamma + c0), bt = *reinterpret_cast<const f32x4*>(a.bnb_beta + c0);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        sc[e] = gm[e] * rsd[e];                     // as bn_apply forms them
-        sh[e] = bt[e] - mu[e] * sc[e];
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < RPW; ++r) {
-      const int oy = y0 + wm * RPW + r, ox = x0 + lp;
-      const bool cv = cok && oy < H && ox < W;
-      const unsigned pixoff = (unsigned)((img * H + oy) * W + ox);
-      float val[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) val[e] = acc[r][4 * g + e] + bq[e];
-      if (want_stats) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float q = cv ? val[e] : 0.f;
-          sA[4 * g + e] += q;
-          sB[4 * g + e] = __builtin_fmaf(q, q, sB[4 * g + e]);
-        }
-      }
-      if (a.act != UDASEG_ACT_NONE) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) val[e] = act_apply(val[e], a.act, a.slope);
-      }
-      const unsigned off = cv ? (pixoff * (unsigned)ldc + (unsigned)(c0 - csub)) * 4u : 0x80000000u;
-      if (a.accumulate) {
-        // (whole-vector cast: an element-wise bit_cast of the loaded vector compiled to ONE dword load feeding all four adds)
-        const f32x4 old = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_y, (int)off, 0, 0));
-#pragma unroll
-        for (int e = 0; e < 4; ++e) val[e] += old[e];
-      }
-      u32x4 d;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) d[e] = __builtin_bit_cast(unsigned, val[e]);
-      __builtin_amdgcn_raw_buffer_store_b128(d, rs_y, (int)off, 0, 0);
-      if (want_bnb) {
-        const unsigned poffb = cv ? (pixoff * (unsigned)a.co + (unsigned)c0) * 4u : 0x80000000u;
-        const f32x4 yv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_p, (int)poffb, 0, 0));
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float yy = yv[e];
-          const float gg = cv ? val[e] * act_grad(__builtin_fmaf(yy, sc[e], sh[e]), a.bnb_act, a.bnb_slope) : 0.f;
-          sA[4 * g + e] += gg;
-          sB[4 * g + e] = __builtin_fmaf(gg, (yy - mu[e]) * rsd[e], sB[4 * g + e]);
-        }
-      }
-    }
-  }
+  constexpr int NW_EPI = WM * WN;
+#include "conv_halo_f32x3_epilogue.inc"
+}
 
-  if (want_stats || want_bnb) {
-    asm volatile("s_nop 1");
-    halfwave_sum_n(sA);
-    halfwave_sum_n(sB);
-    asm volatile("s_nop 1");
-    float* red = reinterpret_cast<float*>(smem);   // [2][waves][32]; the K loop ended with a barrier
-    if (lp == 31) {
+// ------------------------------------------------------------------------------------------------ wave-specialised form
+// Timing-only probes of the kernel above (tools/f3_probe.py, 64 -> 64 at 128^2: 67 us) put its MFMA phase at ~30 us and
+// everything else -- fp32 loads, the operand split, LDS stores, weight staging, barriers, epilogue -- at ~37 us, and the two
+// hardly overlap: a wave does them in turn and the waves of a block are in step.  Here the roles are split between waves:
+//   waves 0-3 (2 x 2 over the tile): LDS fragment reads and MFMAs, nothing else until the epilogue;
+//   waves 4-7: request the fp32 halo of chunk c + 2 and the weights of group G + 2, split chunk c + 1 into the OTHER halo buffer
+//              and store the weights of group G + 1 into the other weight buffer -- all while the MFMA waves work on group G.
+// One barrier per (chunk, dx) group for all eight waves.  LDS: two halo buffers (3 planes each) + two weight buffers.
+template <int WM_, int WN_, int RPW>
+struct F3WsCfg {
+  static constexpr int WM = WM_, WN = WN_;
+  static_assert(WM_ * WN_ == 4, "four MFMA waves");
+  static constexpr int NT = 512, NLD = 256;               // threads; loader threads
+  static constexpr int TH = WM * RPW, TW = 32;
+  static constexpr int HR = TH + 2, HWD = TW + 2;
+  static constexpr int PLANE = HR * HWD * 32;
+  static constexpr int LDS_HALO = 3 * PLANE;
+  static constexpr int NPIECE = HR * HWD * 2;
+  static constexpr int NI = (NPIECE + NLD - 1) / NLD;
+  static constexpr int S = RPW + 2;
+  static constexpr int NFG = WN * 9;
+  static constexpr int NWI = (NFG + 3) / 4;               // fragments a loader wave stages per group
+  static constexpr int LDS_WBUF = NFG * 1024;
+  static constexpr int LDS = 2 * LDS_HALO + 2 * LDS_WBUF;
+};
+
+template <int WM, int WN, int RPW>
+__global__ __launch_bounds__(512, 1) void conv3x3_f32x3_ws_kernel(const F3Args a) {
+  using C = F3WsCfg<WM, WN, RPW>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const wlds = smem + 2 * C::LDS_HALO;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wave >= 4;
+  const int mw = wave & 3;                         // index inside the role
+  const int lp = lane & 31, lh = lane >> 5;
+  const int wm = mw / WN, wn = mw % WN;
+
+  int bid = blockIdx.x;
+  {
+    const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int cb = bid % a.ncb;
+  int t = bid / a.ncb;
+  const int tx = t % a.ntx;
+  t /= a.ntx;
+  const int ty = t % a.nty;
+  const int img = t / a.nty;
+  const int y0 = ty * C::TH, x0 = tx * C::TW;
+  const int H = a.h, W = a.w;
+  const int nblocks32 = (a.co + 31) >> 5;
+  const int nchunk = (a.ci + 15) >> 4, NG = 3 * nchunk;
+
+  int nb = cb * WN + wn;
+  const bool wave_live = nb < nblocks32;
+  if (!wave_live) nb = 0;
+  f32x16 acc[RPW];
 #pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        const int cl = (v & 3) + 8 * (v >> 2) + 4 * lh;
-        red[wave * 32 + cl] = wave_live ? sA[v] : 0.f;
-        red[C::NW * 32 + wave * 32 + cl] = wave_live ? sB[v] : 0.f;
+  for (int r = 0; r < RPW; ++r)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[r][v] = 0.f;
+
+  if (loader) {
+    const int lt = tid - 256;
+    const int oct = lt & 1;
+    unsigned voff[C::NI], voff2[C::NI], soffl[C::NI];
+    const bool UPC = a.up_ca > 0;
+    const int cx = UPC ? a.up_ca : a.ci, cx2 = a.ci - a.up_ca;
+#pragma unroll
+    for (int i = 0; i < C::NI; ++i) {
+      const int piece = lt + i * C::NLD;
+      const int pix = piece >> 1;
+      const int hy = pix / C::HWD, hx = pix - hy * C::HWD;
+      const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+      const bool ok = piece < C::NPIECE && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      if (UPC) {
+        voff[i] = ok ? (unsigned)((((img * (H >> 1) + (iy >> 1)) * (W >> 1) + (ix >> 1)) * cx + oct * 8) * 4) : 0x80000000u;
+        voff2[i] = ok ? (unsigned)((((img * H + iy) * W + ix) * cx2 + oct * 8) * 4) : 0x80000000u;
+      } else {
+        voff[i] = ok ? (unsigned)((((img * H + iy) * W + ix) * cx + oct * 8) * 4) : 0x80000000u;
+        voff2[i] = 0x80000000u;
       }
+      soffl[i] = (unsigned)(pix * 32 + ((oct ^ ((hx >> 3) & 1)) * 16));
     }
-    __syncthreads();
-    if (tid < 32 * WN) {
-      const int wc = tid >> 5, cl = tid & 31;
-      const int c = (cb * WN + wc) * 32 + cl;
-      if (c < a.co) {
-        float t1 = 0.f, t2 = 0.f;
+    __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_x2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(UPC && a.x2 ? a.x2 : a.x), 0,
+                                                                     (int)(UPC && a.x2 ? a.x2_bytes : 0u), 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wf), 0, (int)(3u * a.w_plane_bytes), 0x00020000);
+    const int frag_per_nb = 3 * a.nk16 * 3;
+    int wbase[C::NWI];
+    const unsigned wlane16 = (unsigned)lane * 16u;
 #pragma unroll
-        for (int m = 0; m < WM; ++m) {
-          t1 += red[(m * WN + wc) * 32 + cl];
-          t2 += red[C::NW * 32 + (m * WN + wc) * 32 + cl];
+    for (int i = 0; i < C::NWI; ++i) {
+      const int q = mw + 4 * i;                    // slot of the group: ((wq * 3 + dy) * 3 + plane)
+      const int wq = q / 9, rem = q - wq * 9;
+      const int dy = rem / 3, pl = rem - dy * 3;
+      const int nbq = cb * WN + wq;
+      const bool live = q < C::NFG && nbq < nblocks32;
+      wbase[i] = live ? (int)(pl * a.w_plane_bytes) + (nbq * frag_per_nb + dy) * 1024 : -1;
+    }
+    u32x4 stage[C::NI][2], wstage[C::NWI];
+    auto load_chunk = [&](int c) {
+      const int cbeg = c * 16;
+      const bool second = UPC && cbeg >= a.up_ca;
+      const int soff = (second ? cbeg - a.up_ca : cbeg) * 4;
+      const unsigned kill = (cbeg + oct * 8 < a.ci) ? 0u : 0x80000000u;
+      if (second) {
+#pragma unroll
+        for (int i = 0; i < C::NI; ++i) {
+          stage[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_x2, (int)(voff2[i] | kill), soff, 0);
+          stage[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_x2, (int)(voff2[i] | kill), soff + 16, 0);
         }
-        double* rep = a.sscr != nullptr ? a.sscr + (size_t)(blockIdx.x % HALO_SCR_REPLICAS) * 2 * a.co
-                                        : a.stats + (size_t)(blockIdx.x % HALO_STATS_REPLICAS) * 2 * a.co;
-        atomicAdd(rep + c, (double)t1);
-        atomicAdd(rep + a.co + c, (double)t2);
+      } else {
+#pragma unroll
+        for (int i = 0; i < C::NI; ++i) {
+          stage[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(voff[i] | kill), soff, 0);
+          stage[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(voff[i] | kill), soff + 16, 0);
+        }
+      }
+    };
+    auto store_chunk = [&](int buf) {
+      char* hb = smem + buf * C::LDS_HALO;
+#pragma unroll
+      for (int i = 0; i < C::NI; ++i) {
+        if (i < C::NI - 1 || lt + i * C::NLD < C::NPIECE) {
+          u32x4 p0, p1, p2;
+          split3(stage[i][0], stage[i][1], p0, p1, p2);
+          *reinterpret_cast<u32x4*>(hb + soffl[i]) = p0;
+          *reinterpret_cast<u32x4*>(hb + C::PLANE + soffl[i]) = p1;
+          *reinterpret_cast<u32x4*>(hb + 2 * C::PLANE + soffl[i]) = p2;
+        }
+      }
+    };
+    auto load_w = [&](int G) {
+      const int c = G / 3, dx = G - 3 * c;
+      const int soff = (dx * a.nk16 + c) * 3 * 1024;
+#pragma unroll
+      for (int i = 0; i < C::NWI; ++i)
+        wstage[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wbase[i] < 0 ? 0x80000000u : wlane16), wbase[i] < 0 ? 0 : wbase[i] + soff, 0);
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+      for (int i = 0; i < C::NWI; ++i) {
+        const int q = mw + 4 * i;
+        if (i < C::NWI - 1 || q < C::NFG) *reinterpret_cast<u32x4*>(wlds + buf * C::LDS_WBUF + q * 1024 + lane * 16) = wstage[i];
+      }
+    };
+
+    load_chunk(0);
+    load_w(0);
+    store_chunk(0);
+    store_w(0);
+    if (nchunk > 1) load_chunk(1);
+    if (NG > 1) load_w(1);
+    __syncthreads();                               // group 0 is staged
+    for (int G = 0; G < NG; ++G) {
+      const int c = G / 3, dx = G - 3 * c;
+      if (G + 1 < NG) {
+        store_w((G + 1) & 1);                      // last read by the MFMA waves in group G - 1
+        if (G + 2 < NG) load_w(G + 2);
+      }
+      if (dx == 1 && c + 1 < nchunk) {
+        store_chunk((c + 1) & 1);                  // last read in chunk c - 1
+        if (c + 2 < nchunk) load_chunk(c + 2);
+      }
+      __syncthreads();
+    }
+  } else {
+    // pixel fragment address per dx: lane pixel lp of a row, K half lh (swapped where bit 3 of the halo column is set)
+    int poff[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int hx = lp + dx;
+      poff[dx] = (wm * RPW * C::HWD + hx) * 32 + ((lh ^ ((hx >> 3) & 1)) * 16);
+    }
+    const int wrd = (wn * 9) * 1024 + lane * 16;
+    __syncthreads();                               // group 0 is staged
+    for (int c = 0; c < nchunk; ++c) {
+      const char* hb = smem + (c & 1) * C::LDS_HALO;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const char* wb = wlds + ((3 * c + dx) & 1) * C::LDS_WBUF + wrd;
+        u32x4 bf[3][3];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) bf[dy][pl] = *reinterpret_cast<const u32x4*>(wb + (dy * 3 + pl) * 1024);
+        u32x4 pf[2][3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) pf[0][pl] = *reinterpret_cast<const u32x4*>(hb + pl * C::PLANE + poff[dx]);
+#pragma unroll
+        for (int s = 0; s < C::S; ++s) {
+          if (s + 1 < C::S) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+              pf[(s + 1) & 1][pl] = *reinterpret_cast<const u32x4*>(hb + pl * C::PLANE + poff[dx] + (s + 1) * C::HWD * 32);
+          }
+#pragma unroll
+          for (int ij = 2; ij >= 0; --ij)
+#pragma unroll
+            for (int i = 0; i <= ij; ++i)
+#pragma unroll
+              for (int dy = 0; dy < 3; ++dy) {
+                const int r = s - dy;
+                if (r >= 0 && r < RPW)
+                  acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bf[dy][i]),
+                                                                   __builtin_bit_cast(bf16x8, pf[s & 1][ij - i]), acc[r], 0, 0, 0);
+              }
+        }
+        __syncthreads();                           // group G + 1 is staged; this group's buffers may be rewritten
       }
     }
   }
+  if (loader) {                                    // the statistics reduction has one block barrier
+    if (a.stats != nullptr) __syncthreads();
+    return;
+  }
+  constexpr int NW_EPI = WM * WN;
+  const int wave_mfma = mw;
+#define wave wave_mfma
+#include "conv_halo_f32x3_epilogue.inc"
+#undef wave
 }
 
 // ------------------------------------------------------------------------------------------------ fragment packing
@@ -409,6 +537,42 @@ __global__ void pack_frag_batched_f32x3_kernel(const float* __restrict__ w32, co
 
 // ------------------------------------------------------------------------------------------------- host side
 template <int WM, int WN, int RPW>
+static int launch_f3_ws_t(F3Args a, hipStream_t s, double flops) {
+  using C = F3WsCfg<WM, WN, RPW>;
+  auto kern = conv3x3_f32x3_ws_kernel<WM, WN, RPW>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv3x3_f32x3_ws)");
+    attr_done = true;
+  }
+  a.ntx = cdiv(a.w, C::TW);
+  a.nty = cdiv(a.h, C::TH);
+  a.ncb = cdiv(a.co, 32 * C::WN);
+  a.nk16 = (a.ci + 15) / 16;
+  const long long blocks = (long long)a.n * a.nty * a.ntx * a.ncb;
+  if (blocks <= 0) return UDASEG_OK;
+  a.sscr = nullptr;
+  if (a.stats != nullptr && blocks > 1024) a.sscr = halo_stats_scratch(a.co);
+  a.probe = 0;
+  static int kid = -1;
+  if (kid < 0) {
+    char nm[96];
+    snprintf(nm, sizeof(nm), "conv3x3_f32x3_ws_kernel<%d, %d, %d>", WM, WN, RPW);
+    kid = kprof_id(nm);
+  }
+  hipEvent_t ev = kprof_begin(s);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::NT), C::LDS, s, a);
+  kprof_end(kid, ev, s, flops);
+  UDASEG_LAUNCH_CHECK("conv3x3_f32x3_ws launch");
+  if (a.sscr != nullptr) {
+    launch_halo_stats_fold(a.sscr, a.co, a.stats, s);
+    UDASEG_LAUNCH_CHECK("halo_stats_fold launch");
+  }
+  return UDASEG_OK;
+}
+
+template <int WM, int WN, int RPW>
 static int launch_f3_t(F3Args a, hipStream_t s, double flops) {
   using C = F3Cfg<WM, WN, RPW>;
   auto kern = conv3x3_f32x3_kernel<WM, WN, RPW>;
@@ -426,6 +590,14 @@ static int launch_f3_t(F3Args a, hipStream_t s, double flops) {
   if (blocks <= 0) return UDASEG_OK;
   a.sscr = nullptr;
   if (a.stats != nullptr && blocks > 1024) a.sscr = halo_stats_scratch(a.co);
+  {
+    static int probe = -1;
+    if (probe < 0) {
+      const char* e = getenv("UDASEG_F3_PROBE");
+      probe = e ? atoi(e) : 0;
+    }
+    a.probe = probe;
+  }
   static int kid = -1;
   if (kid < 0) {
     char nm[96];
@@ -471,28 +643,37 @@ static int f3_choice(int h, int w, int n, int gathered, int produced) {
     const char* e = getenv("UDASEG_F3_CFG");
     g_f3_force = e ? atoi(e) : 0;
   }
-  if (g_f3_force >= 1 && g_f3_force <= 3) return g_f3_force;
+  if (g_f3_force >= 1 && g_f3_force <= 8) return g_f3_force;
   if (w < 32) return 0;                             // 16-pixel-wide images: half of every 32-pixel tile row is outside
   const long long tiles = (long long)n * cdiv(h, 8) * cdiv(w, 32);
   if (produced <= 32) return 1;
-  // 64-channel blocks on 4 x 32 pixel tiles rather than 8 x 32: a launch is then two or more generations of blocks, whose prologues
-  // and epilogues fall into other blocks' K loops instead of all at once (r18 8 x 512^2 step: 834 -> 856 images/s; profiles/r03_f32x3.txt)
-  return tiles * cdiv(produced, 64) >= 256 ? 3 : 1;
+  // 64 and more produced channels: the wave-specialised kernel (one 8-wave block per CU), on 4 x 32 pixel tiles, or 8 x 32 where the
+  // K loop is long and the launch still has a block per CU.  Per layer, stand-alone, us (tools/f3_probe.py; configurations
+  // 1 / 2 / 3 / 5 / 6): 64 -> 64 at 128^2 70 / 59 / 67 / 64 / 58; 128 -> 128 at 64^2 62 / 66 / 62 / 55 / 53; 256 -> 256 at 32^2
+  // 75 / 101 / 74 / 80 / 59; 192 -> 64 at 128^2 179 / 163 / 180 / 158 / 167; 384 -> 128 at 64^2 172 / 179 / 172 / 156 / 160;
+  // 768 -> 256 at 32^2 208 / 281 / 207 / 216 / 166 (profiles/r03_f32x3.txt).  Launches too small for that keep 32-channel blocks.
+  static int ws = -1;        // UDASEG_F3_WS=0 (A/B): the one-role kernel everywhere (4 x 32 pixel tiles x 64 channels)
+  if (ws < 0) {
+    const char* e = getenv("UDASEG_F3_WS");
+    ws = (e && atoi(e) == 0) ? 0 : 1;
+  }
+  if (!ws) return tiles * cdiv(produced, 64) >= 256 ? 3 : 1;
+  const long long ncb64 = cdiv(produced, 64);
+  const long long blocks4 = (long long)n * cdiv(h, 4) * cdiv(w, 32) * ncb64;
+  if (blocks4 < 192) return 1;
+  return (gathered >= 192 && tiles * ncb64 >= 256) ? 5 : 6;
 }
 
 static int launch_f3(F3Args a, hipStream_t s, double flops) {
   int choice = f3_choice(a.h, a.w, a.n, a.ci, a.co);
-  if (choice == 0) choice = a.co <= 32 ? 1 : 3;
+  if (choice == 0) choice = a.co <= 32 ? 1 : 6;
   if (choice == 1) return launch_f3_t<4, 1, 2>(a, s, flops);
-  if (choice == 3) {
-    static int alt = -1;     // UDASEG_F3_ALT=4 (measurement): 8 waves on 8 x 32 pixels x 64 channels instead
-    if (alt < 0) {
-      const char* e = getenv("UDASEG_F3_ALT");
-      alt = e ? atoi(e) : 0;
-    }
-    if (alt == 4) return launch_f3_t<4, 2, 2>(a, s, flops);
-    return launch_f3_t<2, 2, 2>(a, s, flops);      // 4 x 32 pixels x 64 channels
-  }
+  if (choice == 3) return launch_f3_t<2, 2, 2>(a, s, flops);      // 4 x 32 pixels x 64 channels
+  if (choice == 4) return launch_f3_t<4, 2, 4>(a, s, flops);      // 16 x 32 pixels x 64 channels, 8 waves
+  if (choice == 5) return launch_f3_ws_t<2, 2, 4>(a, s, flops);   // 8 x 32 pixels x 64 channels, 4 MFMA waves + 4 loader waves
+  if (choice == 6) return launch_f3_ws_t<2, 2, 2>(a, s, flops);   // 4 x 32 pixels x 64 channels, same roles
+  if (choice == 7) return launch_f3_ws_t<4, 1, 2>(a, s, flops);   // 8 x 32 pixels x 32 channels, same roles
+  if (choice == 8) return launch_f3_ws_t<4, 1, 4>(a, s, flops);   // 16 x 32 pixels x 32 channels, same roles
   return launch_f3_t<2, 2, 4>(a, s, flops);
 }
 
@@ -510,7 +691,7 @@ extern "C" int udaseg_pack_frag_batched_f32x3(const float* w32, const float* wt3
 }
 
 extern "C" int udaseg_f32x3_force_config(int cfg) {
-  UDASEG_CHECK_ARG(cfg >= 0 && cfg <= 3, "f32x3_force_config: 0 (heuristic), 1 (32-channel blocks), 2 (64-channel blocks) or 3 (64 channels x 4 rows)");
+  UDASEG_CHECK_ARG(cfg >= 0 && cfg <= 8, "f32x3_force_config: 0 (heuristic), 1 (8 x 32 px x 32 ch), 2 (8 x 32 x 64), 3 (4 x 32 x 64), 4 (16 x 32 x 64), 5 / 6 (wave-specialised 8 / 4 x 32 x 64), 7 / 8 (wave-specialised 8 / 16 x 32 x 32)");
   g_f3_force = cfg;
   return UDASEG_OK;
 }
