@@ -821,6 +821,8 @@ int launch_wgrad_halo(const udaseg_conv_desc* d, const void* x, const void* x2, 
 // fp32, split in registers into three bf16 planes each in LDS; per (16-pixel K step, tap) the six products with i + j <= 2.
 // Against the bf16 kernel above the LDS traffic per MFMA halves (three plane reads feed six MFMAs), which is what bounded it;
 // the tile shrinks to TR x 32 pixels so that three planes of halo + dy fit the 160 KB.  dW is fp32 either way.
+// (Measured and not kept, tools/micro/conv_wgrad_halo_f32x3_ws.hip.txt: loader waves + MFMA waves as in conv3x3_f32x3_ws_kernel --
+// two LDS buffers only fit one-row tiles, whose 3 x 34 halo triples the x traffic and the split work: 2.53 against 2.14 ms per step.)
 struct WgradHaloF3Args {
   const float* x;     // [n][h][w][cx] fp32, or the half-resolution a [n][h/2][w/2][up_ca] of a fused decoder input
   const float* x2;    // fused decoder input: the skip tensor [n][h][w][ci - up_ca]
