@@ -71,6 +71,26 @@ def main():
                            lib.udaseg_conv2d_wgrad_part_bf16(r, P, max(ca, 8), 0, 1, P, P, 0, None)):
                     assert rc in ok_codes, (rc, ca, [getattr(d, f) for f, _ in d._fields_])
                     calls += 1
+                # halo-resident kernels (bf16 and the fp32 three-term split): support queries and launch descriptions
+                upc = ca if 0 < ca <= d.ci else 0
+                sk = P if 0 < upc < d.ci else None
+                split = ca if 0 < ca < d.ci else 0
+                for q in (lib.udaseg_conv_frag_ok(r, 0, upc), lib.udaseg_conv_frag_preferred(r, 1, 0),
+                          lib.udaseg_conv_f32x3_ok(r, 0, upc), lib.udaseg_conv_f32x3_preferred(r, 1, 0),
+                          lib.udaseg_conv2d_wgrad_halo_bf16_ok(r, upc), lib.udaseg_conv2d_wgrad_halo_f32x3_ok(r, upc)):
+                    assert q in (0, 1), q
+                    calls += 1
+                for rc in (lib.udaseg_conv2d_fwd_frag_bf16(r, P, sk, upc, P, None, None, None, 0, 0.0, P, 0, 0, 0.0, P, None),
+                           lib.udaseg_conv2d_dgrad_frag_bf16(r, P, P, P, P if split else None, split, None, None, None, None, None,
+                                                             0, 0.0, None, 0, None),
+                           lib.udaseg_conv2d_fwd_f32x3(r, P, sk, upc, P, None, P, 0, 0.0, P, None),
+                           lib.udaseg_conv2d_dgrad_f32x3(r, P, P, P, P if split else None, split, None, None, None, None, None,
+                                                         0, 0.0, None, 0, None),
+                           lib.udaseg_conv2d_dgrad_f32x3(r, P, P, P, None, 0, P, P, P, P, P, 1, 0.0, P, 0, None),
+                           lib.udaseg_conv2d_wgrad_halo_bf16(r, P, sk, upc if sk else 0, P, P, None),
+                           lib.udaseg_conv2d_wgrad_halo_f32x3(r, P, sk, upc if sk else 0, P, P, None)):
+                    assert rc in ok_codes, (rc, ca, [getattr(d, f) for f, _ in d._fields_])
+                    calls += 1
     # element-wise / loss / optimizer entry points: shape validation
     for c in (0, 3, 4, 24, 4096, 4100):
         for pixels in (0, 1, 1 << 20):
