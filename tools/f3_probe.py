@@ -1,7 +1,10 @@
-"""Timing-only probes of conv3x3_f32x3_kernel (UDASEG_F3_PROBE bits: 1 no MFMAs, 2 no halo split / LDS stores, 4 no epilogue, 8 no
-pixel-fragment reads; results are wrong by construction).  One layer shape, forced configuration, HIP-event time per launch.
+"""Stand-alone timing of the fp32-on-the-bf16-pipe forward kernels (csrc/conv_halo_f32x3.hip): one layer shape, one forced tile
+configuration (udaseg_f32x3_force_config: 1-4 one-role kernels, 5-8 wave-specialised), HIP-event time per launch.
 
-    UDASEG_F3_PROBE=<bits> python tools/f3_probe.py [n h w ci co cfg]
+    python tools/f3_probe.py [n h w ci co cfg]
+
+(The same script drove the timing-only probes of DESIGN section 5 -- a diagnostic build with uniform branches around the MFMAs,
+the operand split, the fragment reads and the epilogue, selected by UDASEG_F3_PROBE; the branches cost 8 % and were removed.)
 """
 import math
 import os
@@ -37,4 +40,4 @@ e1.record()
 torch.cuda.synchronize()
 us = 1e3 * e0.elapsed_time(e1) / R
 fl = 2.0 * n * h * w * ci * co * 9
-print(f"probe {os.environ.get('UDASEG_F3_PROBE', '0'):>2s} cfg {cfg} {n}x{h}x{w} {ci}->{co}: {us:7.1f} us  {fl / us / 1e6:7.1f} TFLOP/s fp32-equivalent")
+print(f"cfg {cfg} {n}x{h}x{w} {ci}->{co}: {us:7.1f} us  {fl / us / 1e6:7.1f} TFLOP/s fp32-equivalent")
