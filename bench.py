@@ -251,6 +251,15 @@ def roofline_leg(step, model, trainer, dtype, psteps=3, layer_table=False, pmc_t
     for _ in range(2):
         step()
     torch.cuda.synchronize()
+    # single-stream step time without any event in the stream (for the "other" share of the split below) -- taken BEFORE the
+    # profiled steps: releasing their thousands of events afterwards stalled the next launches now and then (45 instead of 11 ms)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(psteps):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    serial_ms = e0.elapsed_time(e1) / psteps
     K.prof_reset()
     K.prof_enable(True)
     for _ in range(psteps):
@@ -284,20 +293,6 @@ def roofline_leg(step, model, trainer, dtype, psteps=3, layer_table=False, pmc_t
     K.prof_reset()
     kern = [k for k in allk if k[0].startswith("conv")]            # MFMA kernels: k[2] = FLOPs
     hbm_k = [k for k in allk if not k[0].startswith("conv")]       # bandwidth kernels (BatchNorm passes): k[2] = algorithmic bytes
-    # single-stream step time without any event in the stream (for the "other" share of the split below)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    _engine.SIDE_STREAM_WGRAD = False
-    for _ in range(2):          # the profiling events above are released asynchronously: keep that out of the timed steps
-        step()
-    torch.cuda.synchronize()
-    e0.record()
-    for _ in range(psteps):
-        step()
-    e1.record()
-    torch.cuda.synchronize()
-    _engine.SIDE_STREAM_WGRAD = was_side
-    serial_ms = e0.elapsed_time(e1) / psteps
     # BASELINE cfg 5 asks for the split "HBM-bound vs MFMA-bound": every conv call is classed by its arithmetic intensity
     # (FLOPs / algorithmic bytes) against the machine balance peak / 6.3 TB/s (measured copy rate, MI355X_MICROARCH.md)
     balance = (BF16_MFMA_PEAK_TFLOPS if dtype == "bf16" else FP32_MFMA_PEAK_TFLOPS) * 1e12 / 6.3e12
