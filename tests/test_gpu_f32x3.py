@@ -307,3 +307,50 @@ def test_wgrad_halo_f32x3_fused_decoder_input(K):
     dw = torch.zeros(co, 3, 3, ca + cs, device="cuda")
     K.conv2d_wgrad_halo(d, nhwc(a), nhwc(skip), nhwc(dy), dw, up=True)
     assert err2(dw.cpu(), ref) <= 1e-6 and err(dw.cpu(), ref) <= 5e-6
+
+
+def test_packed_planes_equal_the_oracle_split_bit_for_bit(K):
+    """The device split (csrc/halo_common.h::split3, here through the weight packer) against oracle/f32x3_ref.py::split3."""
+    import numpy as np
+    from oracle.f32x3_ref import bf16_bits, split3
+    g = torch.Generator().manual_seed(21)
+    co, ci = 64, 48
+    wt = torch.randn(co, ci, 3, 3, generator=g) * torch.exp2(torch.randint(-40, 40, (co, ci, 3, 3), generator=g).float())
+    wf, _, _, _ = pack3(K, wt)
+    nf = K.frag_elems(co, ci, 3)
+    got = wf.view(3, nf).view(torch.int16).cpu().numpy().view(np.uint16).reshape(3, 2, 3, 3, 3, 64, 8)   # [plane][nb][dx][k16][dy][lane][j]
+    terms = split3(wt.numpy())
+    lane = np.arange(64)
+    for pl in range(3):
+        want = bf16_bits(terms[pl])                              # [co][ci][dy][dx]
+        for nb in range(2):
+            for k16 in range(3):
+                for dy in range(3):
+                    for dx in range(3):
+                        ref = np.stack([want[32 * nb + (l & 31), 16 * k16 + 8 * (l >> 5):16 * k16 + 8 * (l >> 5) + 8, dy, dx] for l in lane])
+                        assert np.array_equal(got[pl, nb, dx, k16, dy], ref), (pl, nb, k16, dy, dx)
+
+
+def test_special_values(K):
+    """Zeros stay exact zeros, a non-finite input poisons exactly the outputs that see it (inf operands become NaN: the split's
+    remainders are inf - inf), everything else is untouched."""
+    n, h, w, ci, co = 1, 16, 32, 32, 32
+    g = torch.Generator().manual_seed(2)
+    wt = torch.randn(co, ci, 3, 3, generator=g) / math.sqrt(ci * 9)
+    d = K.conv_desc(n, h, w, ci, co, 3, 1, 1)
+    wf, _, _, _ = pack3(K, wt)
+    y = torch.full((n, h, w, co), float("nan"), device="cuda", dtype=f32)
+    K.conv2d_fwd_frag(d, torch.zeros(n, h, w, ci, device="cuda"), None, wf, None, y)
+    assert torch.equal(y, torch.zeros_like(y))
+    x = torch.randn(n, ci, h, w, generator=g)
+    x[0, 3, 8, 16] = float("inf")
+    K.conv2d_fwd_frag(d, nhwc(x), None, wf, None, y)
+    bad = ~torch.isfinite(y).all(dim=-1)[0].cpu()                # [h][w]
+    want = torch.zeros(h, w, dtype=torch.bool)
+    want[7:10, 15:18] = True
+    assert torch.equal(bad, want)
+    x[0, 3, 8, 16] = 0.0
+    y_ref = F.conv2d(x.double(), wt.double(), padding=1)
+    yc = nchw(y).double()
+    keep = ~want.expand(co, h, w).unsqueeze(0)
+    assert ((yc - y_ref).abs()[keep].max() / y_ref.abs().max()).item() <= 3e-6
