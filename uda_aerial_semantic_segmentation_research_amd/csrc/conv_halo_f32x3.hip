@@ -25,6 +25,9 @@
 //     channels of one pixel and stores them as one 16-byte fp32 piece straight from registers;
 //   * the fused decoder input, the split data gradient, BatchNorm statistics of the output, BatchNorm-backward sums of the
 //     producer (data gradient) and accumulation into the destination are the bf16 kernel's options, on fp32 tensors.
+// Two kernels share this scheme and one epilogue (conv_halo_f32x3_epilogue.inc): conv3x3_f32x3_kernel, where every wave loads,
+// splits, stages and multiplies in turn (<= 32 produced channels: short K loops, three blocks per CU), and
+// conv3x3_f32x3_ws_kernel, where four waves only issue MFMAs while four others prepare the next chunk (>= 64 produced channels).
 // (Measured and not kept, tools/micro/conv_halo_f32x3_chunk_staged.hip.txt: all 27 weight fragments of a chunk staged at once, one
 // chunk ahead like the halo, two barriers per chunk instead of four, next halo row read before the current row's MFMAs: 842 against
 // 856 images/s -- the larger LDS block costs the 32-channel configuration its third resident block.)
@@ -490,10 +493,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_f32x3_ws_kernel(const F3Args a
     return;
   }
   constexpr int NW_EPI = WM * WN;
-  const int wave_mfma = mw;
-#define wave wave_mfma
+  {
+    const int wave = mw;                           // the epilogue's statistics slot: this wave's index among the MFMA waves
 #include "conv_halo_f32x3_epilogue.inc"
-#undef wave
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ fragment packing
