@@ -94,7 +94,7 @@ def test_three_term_split_is_exact(K):
 CASES = [
     (2, 16, 32, 64, 64), (1, 8, 32, 256, 256), (2, 64, 64, 64, 64), (1, 24, 40, 32, 16), (1, 24, 24, 16, 24),
     (1, 12, 20, 192, 64), (2, 32, 32, 32, 32), (1, 10, 14, 16, 16), (2, 20, 36, 128, 128), (1, 9, 33, 48, 40),
-    (1, 5, 70, 32, 96), (1, 16, 48, 512, 128), (1, 40, 40, 24, 8), (8, 32, 32, 256, 256),
+    (1, 5, 70, 32, 96), (1, 16, 48, 512, 128), (1, 40, 40, 24, 8), (8, 32, 32, 256, 256), (4, 256, 320, 16, 16), (2, 200, 264, 32, 24),
 ]
 
 
