@@ -143,6 +143,8 @@ int udaseg_nchw_to_nhwc(const float* x, float* y, int n, int c, int h, int w, in
  *      sum and sum of squares, spread to avoid same-address atomic serialisation), zeroed by the caller. ---- */
 int udaseg_bn_replicas(void);
 int udaseg_bn_stats(const float* y, int64_t pixels, int c, double* sums, void* stream);
+/* the same for a bf16 tensor (channels a multiple of 8): behind the library GEMMs, which have no statistics epilogue */
+int udaseg_bn_stats_bf16(const void* y, int64_t pixels, int c, double* sums, void* stream);
 /* z = act(gamma*(y-mean)*rstd + beta (+ residual)); writes save_mean/save_rstd [c]; updates running stats
  * (momentum, unbiased variance) when running_mean != NULL.  residual may be NULL. */
 int udaseg_bn_apply(const float* y, const double* sums, const float* gamma, const float* beta, const float* residual,
@@ -423,6 +425,16 @@ int udaseg_conv2d_dgrad_f32x3(const udaseg_conv_desc* d, const float* dy, const 
 int udaseg_conv2d_wgrad_halo_f32x3_ok(const udaseg_conv_desc* d, int up_ca);
 int udaseg_conv2d_wgrad_halo_f32x3(const udaseg_conv_desc* d, const float* x, const float* skip, int up_ca, const float* dy,
                                    float* dw, void* stream);
+
+/* ---- plain GEMMs behind 1x1 / stride-1 convolutions, bf16 storage, through hipBLASLt (csrc/gemm_lt.hip): r50's bottleneck
+ *      projections below 192^2 (reference smp.Unet("resnet50"), src/models/train.py:341,343) are small GEMMs the vendor library
+ *      runs 2-3x faster than the hand-written streaming / split-K kernels; no fused epilogues (the caller runs udaseg_bn_stats /
+ *      udaseg_bn_bwd_reduce_bf16 behind them).  mode 0: y[M][co] = x[M][ci] . w[co][ci]^T (a = x, b = w, c = y bf16);
+ *      mode 1: dx[M][ci] = beta * dx + dy[M][co] . w[co][ci] (a = dy, b = w, c = dx bf16); mode 2: dW[co][ci] = beta * dW +
+ *      dy[M][co]^T . x[M][ci] (a = x, b = dy, c = dW fp32).  beta is 0 or 1.  udaseg_gemm_1x1_preferred: the measured rule
+ *      (1x1 / stride 1, >= 64 channels both ways, M <= 73728); UDASEG_GEMM_1X1=0 switches it off. ---- */
+int udaseg_gemm_1x1_preferred(const udaseg_conv_desc* d);
+int udaseg_gemm_1x1_bf16(int mode, int64_t M, int ci, int co, const void* a, const void* b, void* c, float beta, void* stream);
 
 /* ---- diagnosis: while a device buffer of 6 * blocks u64 is registered, every implicit-GEMM launch of at most `blocks` blocks
  *      writes per block {entry, first tile load, end of K loop, exit} (100 MHz wall-clock ticks), HW_ID and XCC_ID into it

@@ -15,7 +15,7 @@ ts = d["roofline"].get("time_split", {})
 bn = ts.get("batchnorm_passes", {})
 ck = d["roofline"]["all_conv_kernels"]["by_kernel"]
 print(sys.argv[1], "leg", sys.argv[2], d["value"], "img/s", d["ms_per_step"], "ms  serial", ts.get("serial_step_ms"), " bn_ms", bn.get("ms"),
-      " conv:", {k.replace("conv_", "").replace("_kernel", "")[:26]: v["ms_per_step"] for k, v in list(ck.items())[:6]})
+      " conv:", {k.replace("conv_", "").replace("_kernel", "")[:26]: v["ms_per_step"] for k, v in list(ck.items())[:12]})
 PY
 done; done
 cat $out

@@ -158,6 +158,28 @@ __global__ void bn_bwd_reduce_bf16_kernel(const f32x4* __restrict__ dz, const f3
   block_fold_add8(sgx, rep + (size_t)c8 * 8, c8, q, red);
 }
 
+// Per-channel sum and sum of squares of a bf16 tensor into the f64 replicas (what a convolution's fused statistics epilogue adds):
+// behind the library GEMMs of csrc/gemm_lt.hip, which have no such epilogue.
+__global__ void bn_stats_bf16_kernel(const f32x4* __restrict__ y, int64_t n8, int c8, double* __restrict__ sums) {
+  __shared__ d8 red[256];
+  const int64_t T = (int64_t)gridDim.x * blockDim.x;
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int q = (int)(g % c8);
+  d8 s1 = {{0, 0, 0, 0, 0, 0, 0, 0}}, s2 = {{0, 0, 0, 0, 0, 0, 0, 0}};
+  for (int64_t i = g; i < n8; i += T) {
+    float v[8];
+    unpack8(y[i], v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      s1.v[e] += (double)v[e];
+      s2.v[e] += (double)v[e] * (double)v[e];
+    }
+  }
+  double* rep = sums + (size_t)(blockIdx.x % BN_REPLICAS) * 2 * c8 * 8;
+  block_fold_add8(s1, rep, c8, q, red);
+  block_fold_add8(s2, rep + (size_t)c8 * 8, c8, q, red);
+}
+
 __global__ void bn_bwd_apply_bf16_kernel(const f32x4* __restrict__ dz, const f32x4* __restrict__ z,
                                          const f32x4* __restrict__ y, const float* __restrict__ save_mean,
                                          const float* __restrict__ save_rstd, const float* __restrict__ gamma,
@@ -549,6 +571,19 @@ extern "C" int udaseg_bn_apply_bf16(const void* y, const double* sums, const flo
                      (const f32x4*)y, sums, gamma, beta, (const f32x4*)residual, (f32x4*)z, n8, s.c4, pixels, eps, momentum,
                      running_mean, running_var, save_mean, save_rstd, act, slope);
   UDASEG_LAUNCH_CHECK("bn_apply_bf16 launch");
+  return UDASEG_OK;
+}
+
+extern "C" int udaseg_bn_stats_bf16(const void* y, int64_t pixels, int c, double* sums, void* stream) {
+  int rc = check_pc8(pixels, c, "bn_stats_bf16");
+  if (rc) return rc;
+  UDASEG_CHECK_ARG(y && sums, "bn_stats_bf16: NULL pointer");
+  const int64_t n8 = pixels * (c / 8);
+  const StreamShape s = stream_shape(n8, c / 8, reduce_max_blocks());
+  static int kid_bn_stats_bf16_kernel = -1;
+  KTimer kt_bn_stats_bf16_kernel(&kid_bn_stats_bf16_kernel, "bn_stats_bf16_kernel", as_stream(stream), (double)pixels * c * 2.0);
+  hipLaunchKernelGGL(bn_stats_bf16_kernel, dim3(s.grid), dim3(s.bs), 0, as_stream(stream), (const f32x4*)y, n8, s.c4, sums);
+  UDASEG_LAUNCH_CHECK("bn_stats_bf16 launch");
   return UDASEG_OK;
 }
 

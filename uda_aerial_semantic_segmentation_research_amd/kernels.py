@@ -262,6 +262,26 @@ def conv2d_dgrad_frag(d, dy, wfrag_t, dx, dx2=None, bn=None, accumulate=False, s
              st if st is not None else stream()), name)
 
 
+def gemm_1x1_preferred(d):
+    """1x1 / stride-1 bf16 convolution that the library GEMM (hipBLASLt, csrc/gemm_lt.hip) runs faster than the hand-written kernels."""
+    return bool(_lib.load().udaseg_gemm_1x1_preferred(_byref(d)))
+
+
+def gemm_1x1(mode, a, b, c, accumulate=False, st=None):
+    """mode 0: c = y[M][co] from a = x[M][ci], b = w[co][ci]; mode 1: c = dx[M][ci] (+)= from a = dy[M][co], b = w;
+    mode 2: c = dW[co][ci] (fp32) (+)= from a = x[M][ci], b = dy[M][co].  bf16 operands."""
+    if mode == 0:
+        ci, co = a.shape[-1], c.shape[-1]
+    elif mode == 1:
+        ci, co = c.shape[-1], a.shape[-1]
+    else:
+        ci, co = a.shape[-1], b.shape[-1]
+    M = a.numel() // a.shape[-1]
+    assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and c.dtype == (torch.float32 if mode == 2 else torch.bfloat16)
+    check(_lib.load().udaseg_gemm_1x1_bf16(mode, M, ci, co, a.data_ptr(), b.data_ptr(), c.data_ptr(), 1.0 if accumulate else 0.0,
+                                           st if st is not None else stream()), "gemm_1x1_bf16")
+
+
 def pack_dgrad_weights(d, w, w_t, st=None):
     check(_lib.load().udaseg_pack_dgrad_weights(_byref(d), w.data_ptr(), w_t.data_ptr(),
                                                  st if st is not None else stream()), "pack_dgrad_weights")
@@ -346,8 +366,11 @@ def bn_replicas():
 
 def bn_stats(y, sums, st=None):
     c = y.shape[-1]
-    check(_lib.load().udaseg_bn_stats(y.data_ptr(), y.numel() // c, c, sums.data_ptr(),
-                                       st if st is not None else stream()), "bn_stats")
+    if y.dtype not in (torch.float32, torch.bfloat16) or not y.is_contiguous():
+        raise ValueError(f"bn_stats: contiguous fp32 or bf16 tensor expected, got {y.dtype}")
+    _channel_vecs("bn_stats", c, f64=2 * c * bn_replicas(), sums=sums)
+    fn = _lib.load().udaseg_bn_stats_bf16 if y.dtype == torch.bfloat16 else _lib.load().udaseg_bn_stats
+    check(fn(y.data_ptr(), y.numel() // c, c, sums.data_ptr(), st if st is not None else stream()), "bn_stats")
 
 
 def bn_apply(y, sums, gamma, beta, residual, z, eps, momentum, running_mean, running_var, save_mean, save_rstd, act, slope,
