@@ -433,6 +433,8 @@ int udaseg_conv2d_wgrad_halo_f32x3(const udaseg_conv_desc* d, const float* x, co
  *      mode 1: dx[M][ci] = beta * dx + dy[M][co] . w[co][ci] (a = dy, b = w, c = dx bf16); mode 2: dW[co][ci] = beta * dW +
  *      dy[M][co]^T . x[M][ci] (a = x, b = dy, c = dW fp32).  beta is 0 or 1.  udaseg_gemm_1x1_preferred: the measured rule
  *      (1x1 / stride 1, >= 64 channels both ways, M <= 73728); UDASEG_GEMM_1X1=0 switches it off. ---- */
+/* two caller-owned scratch buffers of `bytes` each (<= 32 MiB used) for the current device; the library allocates nothing */
+int udaseg_gemm_set_workspace(void* ws_main, void* ws_side, size_t bytes);
 int udaseg_gemm_1x1_preferred(const udaseg_conv_desc* d);
 int udaseg_gemm_1x1_bf16(int mode, int64_t M, int ci, int co, const void* a, const void* b, void* c, float beta, void* stream);
 

@@ -99,6 +99,8 @@ def main():
     for d in geoms[:40]:
         assert lib.udaseg_gemm_1x1_preferred(C.byref(d)) in (0, 1)
         calls += 1
+    assert lib.udaseg_gemm_set_workspace(P, P, 1 << 20) in ok_codes | {0} and lib.udaseg_gemm_set_workspace(None, P, 0) in ok_codes
+    calls += 2
     for rc in (lib.udaseg_bn_stats_bf16(P, 16, 64, P, None), lib.udaseg_bn_stats_bf16(P, 16, 60, P, None), lib.udaseg_bn_stats_bf16(None, 16, 64, P, None)):
         assert rc in ok_codes, rc
         calls += 1

@@ -6,7 +6,7 @@
 // src/models/train.py:341,343; BASELINE cfg 5).  For r50's deeper stages (96^2 and below: M <= 73728, K and N 128..2048) these are
 // small square-ish GEMMs on which the hand-written streaming kernel (conv1x1_stream_bf16_kernel: built for the HBM-bound 192^2
 // layers) and the split-K weight gradient are latency-bound: 41-61 us per launch against 19-27 us for the vendor library on the
-// same shapes (profiles/r03_gemm_1x1.txt).  These are plain library GEMMs: they go to hipBLASLt; the fused epilogues of the
+// same shapes (profiles/r03_gemm_1x1.txt).  These are plain library GEMMs: they go to hipBLASLt (workspace: caller-owned); the fused epilogues of the
 // hand-written kernels (BatchNorm statistics, BatchNorm-backward sums) become the stand-alone passes on those layers, which is
 // still a net gain below 96^2 (the tensors are small).  One handle, descriptors and the heuristic's algorithm cached per shape.
 #include <hipblaslt/hipblaslt.h>
@@ -28,9 +28,10 @@ struct LtPlan {
 };
 
 static hipblasLtHandle_t g_lt = nullptr;
-// library-owned workspaces, one per device and per use (forward / data gradient run on the compute stream, weight gradients on the
-// side stream and may overlap them): allocated on first use, never freed (process lifetime, like the handle)
+// caller-owned workspaces (udaseg_gemm_set_workspace), one pair per device: forward / data gradient run on the compute stream,
+// weight gradients on the side stream and may overlap them.  The library allocates nothing; unbound = workspace-free algorithms.
 static void* g_lt_ws[16][2] = {};
+static size_t g_lt_ws_bytes[16] = {};
 static std::map<std::tuple<int, int64_t, int, int, int>, LtPlan> g_plans;      // (mode, M, ci, co, device)
 static std::mutex g_lt_mu;
 constexpr size_t LT_WS_MAX = 32u << 20;
@@ -75,7 +76,8 @@ static int lt_plan(int mode, int64_t M, int ci, int co, int dev, LtPlan** out) {
   if (st != HIPBLAS_STATUS_SUCCESS) return lt_fail(st, "hipblasLtMatrixLayoutCreate");
   hipblasLtMatmulPreference_t pref;
   if ((st = hipblasLtMatmulPreferenceCreate(&pref)) != HIPBLAS_STATUS_SUCCESS) return lt_fail(st, "hipblasLtMatmulPreferenceCreate");
-  uint64_t ws_max = LT_WS_MAX;
+  uint64_t ws_max = (dev >= 0 && dev < 16) ? g_lt_ws_bytes[dev] : 0;
+  if (ws_max > LT_WS_MAX) ws_max = LT_WS_MAX;
   hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &ws_max, sizeof(ws_max));
   hipblasLtMatmulHeuristicResult_t res[1];
   int found = 0;
@@ -114,6 +116,21 @@ extern "C" int udaseg_gemm_1x1_preferred(const udaseg_conv_desc* d) {
   return M <= 73728 ? 1 : 0;
 }
 
+// Two caller-owned scratch buffers of `bytes` each for the CURRENT device (compute-stream GEMMs / side-stream weight gradients).
+// Bind before the first GEMM of a shape is planned: the plan keeps the algorithm chosen under the workspace available then.
+extern "C" int udaseg_gemm_set_workspace(void* ws_main, void* ws_side, size_t bytes) {
+  int dev = 0;
+  UDASEG_CHECK_ARG(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16, "gemm_set_workspace: no current HIP device");
+  UDASEG_CHECK_ARG((bytes == 0) == (ws_main == nullptr) && (bytes == 0) == (ws_side == nullptr) &&
+                       (reinterpret_cast<uintptr_t>(ws_main) & 255) == 0 && (reinterpret_cast<uintptr_t>(ws_side) & 255) == 0,
+                   "gemm_set_workspace: two 256-byte-aligned buffers of `bytes` each, or NULL / NULL / 0");
+  std::lock_guard<std::mutex> lock(g_lt_mu);
+  g_lt_ws[dev][0] = ws_main;
+  g_lt_ws[dev][1] = ws_side;
+  g_lt_ws_bytes[dev] = bytes;
+  return UDASEG_OK;
+}
+
 extern "C" int udaseg_gemm_1x1_bf16(int mode, int64_t M, int ci, int co, const void* a, const void* b, void* c, float beta, void* stream) {
   UDASEG_CHECK_ARG(mode >= 0 && mode <= 2 && M > 0 && ci > 0 && co > 0 && ci % 8 == 0 && co % 8 == 0,
                    "gemm_1x1_bf16: mode %d M=%lld ci=%d co=%d (channels multiples of 8)", mode, (long long)M, ci, co);
@@ -127,13 +144,9 @@ extern "C" int udaseg_gemm_1x1_bf16(int mode, int64_t M, int ci, int co, const v
   if (rc) return rc;
   void* ws = nullptr;
   if (p->ws > 0) {
-    UDASEG_CHECK_ARG(dev >= 0 && dev < 16 && p->ws <= LT_WS_MAX, "gemm_1x1_bf16: workspace of %zu bytes on device %d", p->ws, dev);
-    void*& slot = g_lt_ws[dev][mode == 2 ? 1 : 0];
-    if (slot == nullptr) {
-      hipError_t e = hipMalloc(&slot, LT_WS_MAX);
-      if (e != hipSuccess) return hip_fail(e, "hipMalloc(hipBLASLt workspace)");
-    }
-    ws = slot;
+    UDASEG_CHECK_ARG(dev >= 0 && dev < 16 && p->ws <= g_lt_ws_bytes[dev] && g_lt_ws[dev][mode == 2 ? 1 : 0] != nullptr,
+                     "gemm_1x1_bf16: the planned algorithm wants %zu bytes of workspace; bind one with udaseg_gemm_set_workspace", p->ws);
+    ws = g_lt_ws[dev][mode == 2 ? 1 : 0];
   }
   const float alpha = 1.f;
   // mode 0: A = w (b), B = x (a); mode 1: A = w (b), B = dy (a); mode 2: A = x (a), B = dy (b)

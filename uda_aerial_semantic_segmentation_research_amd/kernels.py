@@ -28,8 +28,11 @@ def ensure_workspace(device, nbytes=16 << 20):
         with torch.cuda.device(device):          # the library binds the buffers to the CURRENT device
             check(_lib.load().udaseg_set_workspace(buf.data_ptr(), nbytes), "set_workspace")
             check(_lib.load().udaseg_set_stats_scratch(scr.data_ptr(), scr.numel()), "set_stats_scratch")
+            gws = torch.empty(2, 32 << 20, dtype=torch.uint8, device=device)   # hipBLASLt workspaces (compute / side stream)
+            check(_lib.load().udaseg_gemm_set_workspace(gws[0].data_ptr(), gws[1].data_ptr(), gws.shape[1]), "gemm_set_workspace")
         _WORKSPACE[key] = buf
         _WORKSPACE[key + "/stats"] = scr
+        _WORKSPACE[key + "/gemm"] = gws
     return _WORKSPACE[key]
 
 
