@@ -426,18 +426,6 @@ int udaseg_conv2d_wgrad_halo_f32x3_ok(const udaseg_conv_desc* d, int up_ca);
 int udaseg_conv2d_wgrad_halo_f32x3(const udaseg_conv_desc* d, const float* x, const float* skip, int up_ca, const float* dy,
                                    float* dw, void* stream);
 
-/* ---- plain GEMMs behind 1x1 / stride-1 convolutions, bf16 storage, through hipBLASLt (csrc/gemm_lt.hip): r50's bottleneck
- *      projections below 192^2 (reference smp.Unet("resnet50"), src/models/train.py:341,343) are small GEMMs the vendor library
- *      runs 2-3x faster than the hand-written streaming / split-K kernels; no fused epilogues (the caller runs udaseg_bn_stats /
- *      udaseg_bn_bwd_reduce_bf16 behind them).  mode 0: y[M][co] = x[M][ci] . w[co][ci]^T (a = x, b = w, c = y bf16);
- *      mode 1: dx[M][ci] = beta * dx + dy[M][co] . w[co][ci] (a = dy, b = w, c = dx bf16); mode 2: dW[co][ci] = beta * dW +
- *      dy[M][co]^T . x[M][ci] (a = x, b = dy, c = dW fp32).  beta is 0 or 1.  udaseg_gemm_1x1_preferred: the measured rule
- *      (1x1 / stride 1, >= 64 channels both ways, M <= 73728); UDASEG_GEMM_1X1=0 switches it off. ---- */
-/* two caller-owned scratch buffers of `bytes` each (<= 32 MiB used) for the current device; the library allocates nothing */
-int udaseg_gemm_set_workspace(void* ws_main, void* ws_side, size_t bytes);
-int udaseg_gemm_1x1_preferred(const udaseg_conv_desc* d);
-int udaseg_gemm_1x1_bf16(int mode, int64_t M, int ci, int co, const void* a, const void* b, void* c, float beta, void* stream);
-
 /* ---- diagnosis: while a device buffer of 6 * blocks u64 is registered, every implicit-GEMM launch of at most `blocks` blocks
  *      writes per block {entry, first tile load, end of K loop, exit} (100 MHz wall-clock ticks), HW_ID and XCC_ID into it
  *      (tools/igemm_timeline.py).  NULL switches it off.  Not for timed runs. ---- */

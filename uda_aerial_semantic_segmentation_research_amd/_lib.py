@@ -122,9 +122,6 @@ SIGNATURES = {
     "udaseg_conv2d_fwd_frag_bf16": (_I, [_D, _P, _P, _I, _P, _P, _P, _P, _I, _F, _P, _I, _I, _F, _P, _P]),
     "udaseg_conv2d_dgrad_frag_bf16": (_I, [_D, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _F, _P, _I, _P]),
     "udaseg_pack_frag_batched_f32x3": (_I, [_P, _P, _P, _P, _I, _P]),
-    "udaseg_gemm_set_workspace": (_I, [_P, _P, C.c_size_t]),
-    "udaseg_gemm_1x1_preferred": (_I, [_D]),
-    "udaseg_gemm_1x1_bf16": (_I, [_I, _L, _I, _I, _P, _P, _P, _F, _P]),
     "udaseg_conv2d_wgrad_halo_f32x3_ok": (_I, [_D, _I]),
     "udaseg_conv2d_wgrad_halo_f32x3": (_I, [_D, _P, _P, _I, _P, _P, _P]),
     "udaseg_conv_f32x3_ok": (_I, [_D, _I, _I]),

@@ -52,12 +52,6 @@ FUSE_BN_APPLY = os.environ.get("UDASEG_FUSE_BN_APPLY", "2") != "0"
 FUSE_BN_APPLY_1X1_ONLY = os.environ.get("UDASEG_FUSE_BN_APPLY", "2") == "2"
 
 
-# bf16 storage: 1x1 / stride-1 convolutions that are small GEMMs (r50's bottleneck projections at 96^2 and below) go to the vendor
-# library (csrc/gemm_lt.hip, hipBLASLt) in all three directions; their BatchNorm statistics / backward sums become the stand-alone
-# passes.  UDASEG_GEMM_1X1=0: the hand-written kernels everywhere (A/B; tests flip the module attribute to cross-check)
-USE_GEMM_1X1 = os.environ.get("UDASEG_GEMM_1X1", "1") != "0"
-# ... and their weight gradients too (UDASEG_GEMM_1X1_WGRAD=1; measured slower than the split-K kernel: off)
-USE_GEMM_1X1_WGRAD = os.environ.get("UDASEG_GEMM_1X1_WGRAD", "0") == "1"
 # bf16 storage: weight gradients of the stride-1 3x3 layers with channel counts that are multiples of 64 on the halo-resident
 # kernel (few long-lived blocks, x halo and dy staged once per tile); UDASEG_WGRAD_HALO=0: per-tap split-K kernel everywhere
 USE_WGRAD_HALO = os.environ.get("UDASEG_WGRAD_HALO", "1") != "0"
@@ -518,11 +512,6 @@ class Plan:
         """An empty tensor shaped like activation ``t`` (which may be a LazyAct)."""
         return torch.empty_like(t.y if isinstance(t, LazyAct) else t)
 
-    def _gemm_ok(self, conv, d):
-        """This convolution runs as a library GEMM (training, bf16 storage, 1x1 / stride 1 / no bias, the library's measured rule)."""
-        return (USE_GEMM_1X1 and self.training and self.bf16 and conv.k == 1 and conv.stride == 1 and conv.pad == 0
-                and conv.bias is None and K.gemm_1x1_preferred(d))
-
     def _lazy_ok(self, c, n, ho, wo, consumer, act, residual):
         """May BatchNorm + activation of this [n, ho, wo, c] output stay unwritten?  Only when its single consumer runs on the
         bf16-first kernels in BOTH directions (the forward applies the transform while staging; the data gradient's epilogue
@@ -533,8 +522,6 @@ class Plan:
         if consumer.stride != 1 or consumer.cin_p != c or c % 16 != 0 or (FUSE_BN_APPLY_1X1_ONLY and consumer.k != 1):
             return False
         d2 = K.conv_desc(n, ho, wo, c, consumer.cout_p, consumer.k, 1, consumer.pad)
-        if self._gemm_ok(consumer, d2):             # a library GEMM cannot apply the transform while it reads its input
-            return False
         return self.wfrag(consumer, d2) is not None and self.wfrag(consumer, d2, dgrad=True) is not None
 
     def conv_bn_act(self, conv, bn, x, act=ACT_LEAKY, slope=0.0, residual=None, lazy_for=None):
@@ -557,10 +544,7 @@ class Plan:
             y = torch.empty((n, d.ho, d.wo, conv.cout_p), device=dev, dtype=self.adt)
             sums = self._next_stats(ceil4(bn.c))
             wf = self.wfrag(conv, d, up_ca=x.a.shape[3] if up else 0)
-            if not up and not lazy_in and self._gemm_ok(conv, d):
-                K.gemm_1x1(0, x, self.w(conv), y, st=self.st)
-                K.bn_stats(y, sums[0], self.st)
-            elif lazy_in:
+            if lazy_in:
                 assert wf is not None, "a LazyAct input needs the bf16-first kernels (decided by the producer)"
                 K.conv2d_fwd_frag(d, x.y, None, wf, bias, y, stats=sums[0], in_scale=x.scale, in_shift=x.shift, in_act=x.act,
                                   in_slope=x.slope, st=self.st)
@@ -672,10 +656,7 @@ class Plan:
             else:
                 K.conv2d_dgrad_split(d, dy, self.packed_wt(conv), d_up, d_skip, self.st)
             return
-        gemm = not isinstance(x, LazyAct) and self._gemm_ok(conv, d)
-        if gemm and USE_GEMM_1X1_WGRAD:
-            K.gemm_1x1(2, x, dy, self.gw(conv), accumulate=True, st=wst)
-        elif isinstance(x, LazyAct):
+        if isinstance(x, LazyAct):
             K.conv2d_wgrad_bnin(d, x.y, x.scale, x.shift, x.act, x.slope, dy, self.gw(conv), True, wst)
         elif self._wgrad_halo and K.conv2d_wgrad_halo_ok(d, f32=not self.bf16):
             K.conv2d_wgrad_halo(d, x, None, dy, self.gw(conv), st=wst)
@@ -686,11 +667,7 @@ class Plan:
                 K.axpy(self.gvec(conv, "bias"), dbias, 1.0, wst)
             else:
                 K.channel_sum(dy, self.gvec(conv, "bias"), True, wst)
-        if dx is not None and gemm:
-            if prev is not None and isinstance(prev[5], LazyAct):
-                raise RuntimeError("internal: an unwritten activation in front of a library-GEMM convolution")
-            K.gemm_1x1(1, dy, self.w(conv), dx, accumulate=dx_acc, st=self.st)
-        elif dx is not None:
+        if dx is not None:
             wfd = self.wfrag(conv, d, dgrad=True)
             fuse = (prev is not None and FUSE_BN_REDUCE and not dx_acc and not prev[9] and prev[7] != ACT_NONE
                     and prev[4].shape == dx.shape and (wfd is not None or K.conv2d_dgrad_bnreduce_ok(d, dy.dtype)))

@@ -28,11 +28,8 @@ def ensure_workspace(device, nbytes=16 << 20):
         with torch.cuda.device(device):          # the library binds the buffers to the CURRENT device
             check(_lib.load().udaseg_set_workspace(buf.data_ptr(), nbytes), "set_workspace")
             check(_lib.load().udaseg_set_stats_scratch(scr.data_ptr(), scr.numel()), "set_stats_scratch")
-            gws = torch.empty(2, 32 << 20, dtype=torch.uint8, device=device)   # hipBLASLt workspaces (compute / side stream)
-            check(_lib.load().udaseg_gemm_set_workspace(gws[0].data_ptr(), gws[1].data_ptr(), gws.shape[1]), "gemm_set_workspace")
         _WORKSPACE[key] = buf
         _WORKSPACE[key + "/stats"] = scr
-        _WORKSPACE[key + "/gemm"] = gws
     return _WORKSPACE[key]
 
 
@@ -263,26 +260,6 @@ def conv2d_dgrad_frag(d, dy, wfrag_t, dx, dx2=None, bn=None, accumulate=False, s
     check(fn(_byref(d), dy.data_ptr(), wfrag_t.data_ptr(), dx.data_ptr(), _ptr(dx2), dx.shape[-1] if dx2 is not None else 0,
              _ptr(py), _ptr(mu), _ptr(rs), _ptr(ga), _ptr(be), act, slope, _ptr(bs), int(accumulate),
              st if st is not None else stream()), name)
-
-
-def gemm_1x1_preferred(d):
-    """1x1 / stride-1 bf16 convolution that the library GEMM (hipBLASLt, csrc/gemm_lt.hip) runs faster than the hand-written kernels."""
-    return bool(_lib.load().udaseg_gemm_1x1_preferred(_byref(d)))
-
-
-def gemm_1x1(mode, a, b, c, accumulate=False, st=None):
-    """mode 0: c = y[M][co] from a = x[M][ci], b = w[co][ci]; mode 1: c = dx[M][ci] (+)= from a = dy[M][co], b = w;
-    mode 2: c = dW[co][ci] (fp32) (+)= from a = x[M][ci], b = dy[M][co].  bf16 operands."""
-    if mode == 0:
-        ci, co = a.shape[-1], c.shape[-1]
-    elif mode == 1:
-        ci, co = c.shape[-1], a.shape[-1]
-    else:
-        ci, co = a.shape[-1], b.shape[-1]
-    M = a.numel() // a.shape[-1]
-    assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and c.dtype == (torch.float32 if mode == 2 else torch.bfloat16)
-    check(_lib.load().udaseg_gemm_1x1_bf16(mode, M, ci, co, a.data_ptr(), b.data_ptr(), c.data_ptr(), 1.0 if accumulate else 0.0,
-                                           st if st is not None else stream()), "gemm_1x1_bf16")
 
 
 def pack_dgrad_weights(d, w, w_t, st=None):
