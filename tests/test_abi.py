@@ -118,3 +118,107 @@ def test_bn_bindings_refuse_mismatched_operands_before_any_launch():
         K.bn_bwd_apply(dz, z, y, vec(), vec(), vec(), sums, torch.zeros(px, c, dtype=f32), None, vec(), vec(), 1, 0.0)
     with pytest.raises(ValueError):
         K.bn_bwd_apply(dz, z, y, vec(), vec(), vec(), sums[: c], dz, None, vec(), vec(), 1, 0.0)
+
+
+def _scalars_for(entry, roles, ConvDesc):
+    """One valid-looking set of scalar arguments per entry point (tensor slots left as None)."""
+    special = {"up_ca": 0, "ca": 8, "split": 0, "src_c": 8, "c_off": 0, "up": 0, "out_f32": 0, "out_bf16": 1, "bf16_": 1, "cpad": 8,
+               "classes": 5, "ldc": 8, "pooled": 0, "entries": 3, "blocks": 4, "bytes": 64, "scratch_bytes": 256, "count": 48}
+    args = []
+    for r in roles:
+        if r[0] == "desc":
+            args.append(ConvDesc(2, 8, 8, 16, 8, 8, 16, 3, 3, 1, 1))
+        elif r[0] == "int":
+            args.append(special.get(r[1], 4))
+        elif r[0] == "float":
+            args.append(0.5)
+        elif r[0] == "stream":
+            args.append(0)               # the NULL stream (None would ask torch for its current stream: no GPU here)
+        else:
+            args.append(None)            # tensors, host pointers
+    return args
+
+
+def test_every_entry_point_checks_its_operands_before_the_library_is_called():
+    """Walks EVERY name of _lib.SIGNATURES: it has a row in the operand table whose argument kinds match the ctypes signature,
+    and for every tensor role of every pointer-passing entry point a wrong dtype, a short buffer, a non-contiguous tensor and a
+    missing required operand raise ValueError while the (stubbed) library function is never reached; the well-formed call reaches
+    it exactly once with the tensors' addresses.  CPU tensors: the device rule is switched off for this test and tested by
+    itself at the end."""
+    import torch
+    from uda_aerial_semantic_segmentation_research_amd import _lib, _operands as O
+    kinds = {"desc": (_lib._D,), "stream": (ctypes.c_void_p,), "tensor": (ctypes.c_void_p,),
+             "int": (ctypes.c_int, ctypes.c_int64, ctypes.c_size_t), "float": (ctypes.c_float,)}
+    assert sorted(O.OPERANDS) == sorted(_lib.SIGNATURES)
+    other = {torch.float32: torch.bfloat16, torch.bfloat16: torch.float32, torch.float64: torch.float32, torch.int64: torch.int32,
+             torch.int32: torch.int64, torch.uint8: torch.int32}
+    calls = []
+    n_roles = n_entries = 0
+    O.set_require_cuda(False)
+    saved = dict(O._FN)
+    try:
+        for entry, (res, argtypes) in _lib.SIGNATURES.items():
+            roles = O.OPERANDS[entry]
+            assert len(roles) == len(argtypes), entry
+            for r, a in zip(roles, argtypes):
+                assert (a in kinds[r[0]]) if r[0] != "host" else (a is ctypes.c_void_p or hasattr(a, "_type_")), (entry, r, a)
+            tens = [i for i, r in enumerate(roles) if r[0] == "tensor"]
+            if not tens:
+                continue
+            n_entries += 1
+            O._FN[entry] = lambda *a, _e=entry: calls.append((_e, a)) or 0
+            base = _scalars_for(entry, roles, _lib.ConvDesc)
+            req = {nm: (dt, cnt, opt) for nm, dt, cnt, opt in O.requirements(entry, *base)}
+
+            def make(i, dtype=None, count=None):
+                nm = roles[i][1]
+                dt, cnt, _ = req[nm]
+                dt = torch.float32 if dt == "raw32" else dt
+                return torch.zeros(max(cnt if count is None else count, 0), dtype=dtype or dt)
+
+            good = list(base)
+            for i in tens:
+                good[i] = make(i)
+            fn = getattr(O.ops, entry)
+            calls.clear()
+            assert fn(*good) == 0 and len(calls) == 1, entry
+            sent = calls[0][1]
+            for i in tens:
+                assert sent[i] == good[i].data_ptr(), (entry, roles[i][1])
+            for i in tens:
+                nm = roles[i][1]
+                dt, cnt, opt = req[nm]
+                assert cnt >= 1, (entry, nm, "the test's scalars must give every operand a positive extent")
+                n_roles += 1
+                trials = [make(i, count=cnt - 1)]                                  # short by one element
+                if dt != "raw32":
+                    trials.append(make(i, dtype=other[dt]))                         # same element count, other dtype
+                trials.append(torch.zeros(2 * cnt + 2, dtype=torch.float32 if dt == "raw32" else dt)[::2])      # not contiguous
+                trials.append("not a tensor")
+                if not opt:
+                    trials.append(None)
+                for t in trials:
+                    bad = list(good)
+                    bad[i] = t
+                    calls.clear()
+                    with pytest.raises(ValueError):
+                        fn(*bad)
+                    assert not calls, (entry, nm, "the library was reached with a bad operand")
+                if opt:                                                             # NULL is legal there
+                    okn = list(good)
+                    okn[i] = None
+                    calls.clear()
+                    assert fn(*okn) == 0 and calls[0][1][i] is None
+        assert n_entries >= 85 and n_roles >= 390, (n_entries, n_roles)
+        # the device rule: CPU tensors are refused when it is on (what the product runs with)
+        O.set_require_cuda(True)
+        d = _lib.ConvDesc(2, 8, 8, 16, 8, 8, 16, 3, 3, 1, 1)
+        O._FN["udaseg_conv2d_dgrad"] = lambda *a: calls.append(a) or 0
+        calls.clear()
+        with pytest.raises(ValueError, match="GPU"):
+            O.ops.udaseg_conv2d_dgrad(d, torch.zeros(2048), torch.zeros(2304), torch.zeros(2048), 0, None)
+        assert not calls
+    finally:
+        O.set_require_cuda(True)
+        O._FN.clear()
+        O._FN.update(saved)

@@ -111,6 +111,37 @@ def main():
                        lib.udaseg_adam_flat(P, P, P, P, pixels, 1e-3, 0.9, 0.999, 1e-8, 0.1, 0.001, None)):
                 assert rc in ok_codes or rc == 0, rc        # zero-size launches may legitimately return OK
                 calls += 1
+    # NULL sweep over the operand table (uda_aerial_semantic_segmentation_research_amd/_operands.py): for EVERY entry point that takes
+    # device pointers, each required pointer in turn is NULL -- the C side must answer BADARG (-1) before any launch description is
+    # built -- and the all-valid call must come back with an error CODE (no device on this box), never crash.  What the C side can
+    # check without extents: NULL-ness, channel granules (c % 4 / c % 8), enum ranges; extents are the binding's job (the table).
+    from uda_aerial_semantic_segmentation_research_amd import _operands as O
+    special = {"up_ca": 0, "ca": 8, "split": 0, "src_c": 8, "c_off": 0, "up": 0, "out_f32": 0, "out_bf16": 1, "bf16_": 1, "cpad": 8,
+               "classes": 5, "ldc": 8, "pooled": 0, "entries": 3, "blocks": 4, "bytes": 64, "scratch_bytes": 256, "count": 48, "c": 16}
+    missing = []
+    null_ok = {"udaseg_set_workspace", "udaseg_set_stats_scratch", "udaseg_debug_set_timeline"}      # NULL un-binds there
+    for entry, roles in O.OPERANDS.items():
+        tens = [i for i, r in enumerate(roles) if r[0] == "tensor"]
+        if not tens or entry in null_ok:
+            continue
+        base = []
+        for r in roles:
+            base.append(C.byref(desc(2, 8, 8, 16, 16, 3, 1, 1)) if r[0] == "desc" else special.get(r[1], 4) if r[0] == "int"
+                        else 0.5 if r[0] == "float" else None if r[0] == "stream" else (C.c_float * 3)(1, 1, 1) if r[0] == "host" else P)
+        fn = getattr(lib, entry)
+        rc = fn(*base)
+        assert rc in ok_codes, (entry, rc)
+        calls += 1
+        for i in tens:
+            if roles[i][4]:
+                continue                                      # optional operand: NULL is a legal value
+            a = list(base)
+            a[i] = None
+            rc = fn(*a)
+            if rc not in (-1, -2):                            # BADARG, or UNSUPPORTED geometry found first: both precede any launch
+                missing.append((entry, roles[i][1], rc))
+            calls += 1
+    assert not missing, f"required pointers the C side does not check for NULL: {missing}"
     assert lib.udaseg_set_workspace(P, 1 << 20) in ok_codes          # no current device on this box
     assert lib.udaseg_debug_set_timeline(None, 0) == 0 and lib.udaseg_debug_set_timeline(P, 16) == 0
     d = desc(8, 128, 128, 64, 64, 3, 1, 1)

@@ -130,7 +130,7 @@ SIGNATURES = {
     "udaseg_conv2d_fwd_f32x3": (_I, [_D, _P, _P, _I, _P, _P, _P, _I, _F, _P, _P]),
     "udaseg_conv2d_dgrad_f32x3": (_I, [_D, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _F, _P, _I, _P]),
     "udaseg_set_workspace": (_I, [_P, C.c_size_t]),
-    "udaseg_workspace_bytes": (C.c_size_t, [_P]),
+    "udaseg_workspace_bytes": (C.c_size_t, [_D]),
     "udaseg_debug_set_timeline": (_I, [_P, _I]),
     "udaseg_fill_f32": (_I, [_P, _L, _F, _P]),
     "udaseg_axpy_f32": (_I, [_P, _P, _L, _F, _P]),

@@ -14,6 +14,7 @@ import torch
 
 from . import _lib
 from ._lib import check
+from ._operands import ops
 from .engine import mark_padded_input
 
 IMAGENET_MEAN = (0.485, 0.456, 0.406)      # A.Normalize() defaults
@@ -111,11 +112,8 @@ def prepare_batch(images_u8, masks_u8=None, d4_codes=None, dtype=torch.float32, 
     # A.Normalize: mean*max_pixel_value and reciprocal(std*max_pixel_value), both rounded to fp32 first
     m255 = f3(*[float(torch.tensor(m, dtype=torch.float32) * max_pixel_value) for m in mean])
     r255 = f3(*[float(1.0 / (torch.tensor(s, dtype=torch.float32) * max_pixel_value)) for s in std])
-    check(_lib.load().udaseg_prepare_batch_u8(img.data_ptr(), None if msk is None else msk.data_ptr(),
-                                               None if codes is None else codes.data_ptr(), n, h, w, m255, r255,
-                                               out.data_ptr(), cpad, int(dtype == torch.bfloat16),
-                                               None if out_m is None else out_m.data_ptr(), square_ok,
-                                               torch.cuda.current_stream().cuda_stream), "prepare_batch_u8")
+    check(ops.udaseg_prepare_batch_u8(img, msk, codes, n, h, w, m255, r255, out, cpad, int(dtype == torch.bfloat16), out_m, square_ok,
+                                      None), "prepare_batch_u8")
     mark_padded_input(out)
     return out.permute(0, 3, 1, 2)[:, :3], out_m
 
