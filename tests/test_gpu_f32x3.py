@@ -271,7 +271,11 @@ def test_network_step_matches_fp32_mfma_path(K, monkeypatch):
 
 
 @pytest.mark.parametrize("n,h,w,ci,co", [(2, 16, 32, 64, 64), (1, 10, 40, 128, 64), (2, 32, 32, 64, 128), (3, 9, 70, 64, 64),
-                                         (8, 32, 32, 256, 256)])
+                                         (8, 32, 32, 256, 256),
+                                         # round 4: 16-pixel-wide images (8 x 16 tiles), 32 produced channels (K split over the spare
+                                         # waves), 32 x 32 channel blocks, and the HEADLINE's own K (8 x 128^2 pixels, 64 -> 64)
+                                         (8, 16, 16, 512, 512), (2, 16, 16, 64, 128), (3, 20, 24, 128, 64), (2, 24, 40, 64, 32),
+                                         (1, 40, 72, 128, 32), (2, 18, 36, 32, 32), (8, 128, 128, 64, 64)])
 def test_wgrad_halo_f32x3_fp32_grade(K, n, h, w, ci, co):
     """Weight gradient on the halo-resident split kernel against f64, next to the fp32-MFMA split-K kernel on the same launch;
     accumulation onto an existing gradient."""
@@ -292,8 +296,8 @@ def test_wgrad_halo_f32x3_fp32_grade(K, n, h, w, ci, co):
     grade(dw.cpu() - base, dw_nat.cpu(), ref, "weight gradient", cap=5e-6, k2=1.6)
 
 
-def test_wgrad_halo_f32x3_fused_decoder_input(K):
-    n, h, w, ca, cs, co = 2, 16, 64, 128, 64, 64
+@pytest.mark.parametrize("n,h,w,ca,cs,co", [(2, 16, 64, 128, 64, 64), (2, 20, 40, 64, 64, 32), (1, 12, 36, 32, 32, 32)])
+def test_wgrad_halo_f32x3_fused_decoder_input(K, n, h, w, ca, cs, co):
     g = torch.Generator().manual_seed(9)
     a = torch.randn(n, ca, h // 2, w // 2, generator=g)
     skip = torch.randn(n, cs, h, w, generator=g)

@@ -301,7 +301,8 @@ def test_network_with_and_without_unwritten_activations(K, monkeypatch):
 
 
 @pytest.mark.parametrize("n,h,w,ci,co", [(2, 16, 32, 64, 64), (1, 24, 40, 128, 64), (8, 64, 64, 64, 64), (1, 9, 33, 64, 128),
-                                          (3, 8, 32, 192, 64)])
+                                          (3, 8, 32, 192, 64), (2, 16, 16, 128, 64), (3, 24, 24, 64, 64), (2, 20, 36, 64, 32),
+                                          (1, 17, 40, 32, 32), (2, 16, 32, 128, 96), (4, 16, 16, 512, 512)])
 def test_wgrad_halo(K, n, h, w, ci, co):
     """Halo-resident bf16 weight gradient (64 x 64 channel block of all nine taps per block, pixel tiles walked by few
     long-lived blocks) against torch's fp32 CPU gradient on the bf16-rounded operands, and against the per-tap split-K kernel."""
@@ -311,7 +312,7 @@ def test_wgrad_halo(K, n, h, w, ci, co):
     wr = torch.zeros(co, ci, 3, 3, requires_grad=True)
     F.conv2d(x, wr, None, padding=1).backward(dy)
     d = K.conv_desc(n, h, w, ci, co, 3, 1, 1)
-    assert K.conv2d_wgrad_halo_ok(d) and not K.conv2d_wgrad_halo_ok(K.conv_desc(n, h, w, 32, co, 3, 1, 1))
+    assert K.conv2d_wgrad_halo_ok(d) and not K.conv2d_wgrad_halo_ok(K.conv_desc(n, h, w, 16, co, 3, 1, 1))
     dw = torch.full((co, 3, 3, ci), 0.25, device="cuda")
     K.conv2d_wgrad_halo(d, nhwc(x), None, nhwc(dy), dw)
     close(dw.cpu().permute(0, 3, 1, 2), wr.grad + 0.25, "halo wgrad (accumulated onto 0.25)", 1e-4)
@@ -320,7 +321,8 @@ def test_wgrad_halo(K, n, h, w, ci, co):
     close(dw.cpu(), dw2.cpu(), "halo wgrad vs split-K kernel", 2e-5)
 
 
-@pytest.mark.parametrize("n,h,w,ca,cb,co", [(2, 8, 16, 64, 64, 64), (1, 6, 18, 128, 64, 64)])
+@pytest.mark.parametrize("n,h,w,ca,cb,co", [(2, 8, 16, 64, 64, 64), (1, 6, 18, 128, 64, 64), (2, 10, 16, 64, 64, 32),
+                                             (1, 8, 20, 32, 32, 32)])
 def test_wgrad_halo_over_fused_upsample_concat(K, n, h, w, ca, cb, co):
     g = torch.Generator().manual_seed(ca + cb + co + h)
     a = rb(torch.randn(n, ca, h, w, generator=g))

@@ -1124,8 +1124,30 @@ extern "C" int udaseg_conv2d_wgrad_bnin_bf16(const udaseg_conv_desc* d, const vo
   return conv2d_wgrad_impl(d, x, d->ci, 0, 0, dy, dw, accumulate, stream, 1, in_scale, in_shift, in_act, in_slope);
 }
 
+// second form of the halo kernels (conv_wgrad_halo2.hip); UDASEG_WGRAD_V1=1 keeps round 3's kernels (A/B)
+namespace udaseg {
+bool wgrad_h2_applicable(const udaseg_conv_desc* d, int up_ca, bool f32);
+int launch_wgrad_h2(const udaseg_conv_desc* d, const void* x, const void* x2, int up_ca, const void* dy, float* dw, bool f32, hipStream_t s);
+static bool wgrad_v1() {
+  static int v = -1;
+  if (v < 0) v = getenv("UDASEG_WGRAD_V1") != nullptr ? 1 : 0;
+  return v != 0;
+}
+static bool wgrad_halo_off(bool f32) {
+  static int off = -1, off3 = -1;
+  if (off < 0) {
+    const char* e = getenv("UDASEG_F32_SPLIT");
+    off = getenv("UDASEG_NO_WGRAD_HALO") != nullptr ? 1 : 0;
+    off3 = (off || (e && atoi(e) == 0)) ? 1 : 0;
+  }
+  return f32 ? off3 != 0 : off != 0;
+}
+}  // namespace udaseg
+
 extern "C" int udaseg_conv2d_wgrad_halo_bf16_ok(const udaseg_conv_desc* d, int up_ca) {
-  return d != nullptr && wgrad_halo_applicable(d, up_ca) ? 1 : 0;
+  if (d == nullptr) return 0;
+  if (wgrad_v1()) return wgrad_halo_applicable(d, up_ca) ? 1 : 0;
+  return !wgrad_halo_off(false) && wgrad_h2_applicable(d, up_ca, false) ? 1 : 0;
 }
 
 extern "C" int udaseg_conv2d_wgrad_halo_bf16(const udaseg_conv_desc* d, const void* x, const void* skip, int up_ca, const void* dy,
@@ -1133,31 +1155,38 @@ extern "C" int udaseg_conv2d_wgrad_halo_bf16(const udaseg_conv_desc* d, const vo
   UDASEG_CHECK_ARG(d && x && dy && dw, "conv2d_wgrad_halo_bf16: NULL pointer");
   UDASEG_CHECK_ARG(d->n > 0 && d->hi > 0 && d->wi > 0 && d->ho == d->hi && d->wo == d->wi, "conv2d_wgrad_halo_bf16: bad extents");
   UDASEG_CHECK_ARG(up_ca == 0 ? skip == nullptr : skip != nullptr, "conv2d_wgrad_halo_bf16: up_ca and skip come together");
-  if (!wgrad_halo_applicable(d, up_ca)) {
+  if (!udaseg_conv2d_wgrad_halo_bf16_ok(d, up_ca)) {
     set_error("conv2d_wgrad_halo_bf16: geometry not supported (ask udaseg_conv2d_wgrad_halo_bf16_ok first)");
     return UDASEG_E_UNSUPPORTED;
   }
   hipStream_t st = as_stream(stream);
   prof_begin(1, st);
-  const int rc = launch_wgrad_halo(d, x, skip, up_ca, dy, dw, st);
+  const int rc = wgrad_v1() ? launch_wgrad_halo(d, x, skip, up_ca, dy, dw, st) : launch_wgrad_h2(d, x, skip, up_ca, dy, dw, false, st);
   prof_end(1, st, udaseg_conv_flops(d), 2, d);
   return rc;
 }
 
 extern "C" int udaseg_conv2d_wgrad_halo_f32x3_ok(const udaseg_conv_desc* d, int up_ca) {
-  return d != nullptr && wgrad_halo_f3_applicable(d, up_ca) ? 1 : 0;
+  if (d == nullptr) return 0;
+  if (wgrad_v1()) return wgrad_halo_f3_applicable(d, up_ca) ? 1 : 0;
+  return !wgrad_halo_off(true) && wgrad_h2_applicable(d, up_ca, true) ? 1 : 0;
 }
 
 extern "C" int udaseg_conv2d_wgrad_halo_f32x3(const udaseg_conv_desc* d, const float* x, const float* skip, int up_ca, const float* dy,
                                               float* dw, void* stream) {
   UDASEG_CHECK_ARG(d && x && dy && dw, "conv2d_wgrad_halo_f32x3: NULL pointer");
   UDASEG_CHECK_ARG((up_ca > 0) == (skip != nullptr), "conv2d_wgrad_halo_f32x3: up_ca=%d, skip %s", up_ca, skip ? "given" : "NULL");
-  if (!wgrad_halo_f3_applicable(d, up_ca)) {
+  if (!udaseg_conv2d_wgrad_halo_f32x3_ok(d, up_ca)) {
     set_error("conv2d_wgrad_halo_f32x3: geometry not supported (ask udaseg_conv2d_wgrad_halo_f32x3_ok first)");
     return UDASEG_E_UNSUPPORTED;
   }
   hipStream_t st = as_stream(stream);
   prof_begin(1, st);
+  if (!wgrad_v1()) {
+    const int rc2 = launch_wgrad_h2(d, x, skip, up_ca, dy, dw, true, st);
+    prof_end(1, st, udaseg_conv_flops(d), 2, d);
+    return rc2;
+  }
   static int waves = -1;       // UDASEG_WGRAD_F3_WAVES = 4 | 8 (A/B)
   if (waves < 0) {
     const char* e = getenv("UDASEG_WGRAD_F3_WAVES");

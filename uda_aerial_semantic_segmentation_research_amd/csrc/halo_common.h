@@ -53,22 +53,39 @@ __device__ __forceinline__ void halfwave_sum_n(float (&x)[N]) {
   for (int v = 0; v < N; ++v) asm volatile("v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(x[v]));
 }
 
-// x = p0 + p1 + p2 exactly, eight values at a time (two 16-byte fp32 pieces -> three bf16x8 fragments pieces)
+// x = p0 + p1 + p2 exactly, eight values at a time (two 16-byte fp32 pieces -> three bf16x8 fragment pieces).
+// Eleven vector instructions per pair of values: v_cvt_pk_bf16_f32, a shift and a mask to widen the two halves again, two subtractions,
+// twice, and the last conversion.  The subtractions are inline asm: left to itself hipcc packs the two of a pair into v_pk_add_f32,
+// which wants its operands in adjacent registers -- the ISA of round 3's kernels shows ~65 instructions per eight values (v_mov
+// copies, conversions paired with zero, v_and_or / sdwa / alignbit repacking) against the 44 of this form, and packed fp32 adds are
+// slow beside MFMAs (MI355X_MICROARCH.md, per-instruction constants).  Bit-identical: tests/test_gpu_f32x3.py compares the planes
+// with oracle/f32x3_ref.py bit for bit.
+typedef float f32x2h __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2h __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+  const f32x2h v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2h));
+}
+__device__ __forceinline__ float sub_f32(float a, unsigned bits) {      // a - as_float(bits), kept out of the SLP vectoriser's reach
+  float r;
+  asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(bits));
+  return r;
+}
 __device__ __forceinline__ void split3(const u32x4 lo, const u32x4 hi, u32x4& p0, u32x4& p1, u32x4& p2) {
   const f32x4 lf = __builtin_bit_cast(f32x4, lo), hf = __builtin_bit_cast(f32x4, hi);
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     float a = e < 2 ? lf[2 * e] : hf[2 * e - 4];
     float b = e < 2 ? lf[2 * e + 1] : hf[2 * e - 3];
-    const unsigned h = pack_bf16x2(a, b);
-    a -= bf_lo(h);
-    b -= bf_hi(h);
-    const unsigned m = pack_bf16x2(a, b);
-    a -= bf_lo(m);
-    b -= bf_hi(m);
+    const unsigned h = cvt_pk_bf16(a, b);
+    a = sub_f32(a, h << 16);
+    b = sub_f32(b, h & 0xffff0000u);
+    const unsigned m = cvt_pk_bf16(a, b);
+    a = sub_f32(a, m << 16);
+    b = sub_f32(b, m & 0xffff0000u);
     p0[e] = h;
     p1[e] = m;
-    p2[e] = pack_bf16x2(a, b);
+    p2[e] = cvt_pk_bf16(a, b);
   }
 }
 
