@@ -95,6 +95,7 @@ CASES = [
     (2, 16, 32, 64, 64), (1, 8, 32, 256, 256), (2, 64, 64, 64, 64), (1, 24, 40, 32, 16), (1, 24, 24, 16, 24),
     (1, 12, 20, 192, 64), (2, 32, 32, 32, 32), (1, 10, 14, 16, 16), (2, 20, 36, 128, 128), (1, 9, 33, 48, 40),
     (1, 5, 70, 32, 96), (1, 16, 48, 512, 128), (1, 40, 40, 24, 8), (8, 32, 32, 256, 256), (4, 256, 320, 16, 16), (2, 200, 264, 32, 24),
+    (8, 16, 16, 512, 512), (3, 13, 16, 64, 128),          # round 4: 16-pixel-wide images (r18 layer4 at 512^2)
 ]
 
 
@@ -107,7 +108,7 @@ def force_cfg(K):
 
 
 @pytest.mark.parametrize("case", CASES, ids=[("n%d_%dx%d_ci%d_co%d" % c) for c in CASES])
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8], ids=["heuristic", "8x32x32ch", "8x32x64ch", "4x32x64ch", "16x32x64ch", "ws_8x32x64ch", "ws_4x32x64ch", "ws_8x32x32ch", "ws_16x32x32ch"])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9], ids=["heuristic", "8x32x32ch", "8x32x64ch", "4x32x64ch", "16x32x64ch", "ws_8x32x64ch", "ws_4x32x64ch", "ws_8x32x32ch", "ws_16x32x32ch", "ws_4x16x64ch"])
 def test_conv_f32x3_fwd_dgrad_fp32_grade(K, case, cfg, force_cfg):
     n, h, w, ci, co = case
     force_cfg(cfg)

@@ -711,6 +711,266 @@ __global__ __launch_bounds__(512, 2) void conv1x1_stream_bf16_kernel(const HaloA
   }
 }
 
+// ------------------------------------------------------------------------------------------------ small-GEMM 1x1 (round 4)
+// r50's bottleneck projections from 96^2 down (M = n*h*w <= 73728 pixels, K / N = 128 .. 2048 channels; reference
+// smp.Unet("resnet50"), src/test_system.py:90-95, driven src/models/train.py:341,343) are ~10-GFLOP GEMMs on which the streaming
+// kernel above is latency-bound: per 64-channel K step it issues one tile of loads, multiplies for 0.25 us and then waits a
+// memory round trip (41-61 us a layer; round 3 handed these shapes to a vendor library, 19-27 us).  This kernel is a GEMM proper:
+//   * 256 pixels x 128 channels per 8-wave block (a wave: 64 x 64), K in 64-channel stages through a THREE-stage LDS ring;
+//   * both operands arrive by LDS-DMA (buffer_load ... lds, 16 bytes per lane): no staging registers, no ds_write, two stages in
+//     flight across every barrier (counted vmcnt, one barrier per stage).  Pixel rows are unpadded 128-byte rows whose eight
+//     16-byte pieces are XOR-swizzled with (row >> 1) & 7 -- applied to the SOURCE address, the DMA writes linearly -- so the
+//     16-byte fragment reads of 32 consecutive rows are conflict-free; the weights are already in MFMA-fragment order
+//     (udaseg_pack_frag_batched_bf16) and land fragment by fragment;
+//   * the epilogue is the streaming kernel's: 16-byte bf16 stores from registers, BatchNorm statistics / BatchNorm-backward sums /
+//     accumulation onto the destination -- what the library route had to give up.
+template <int PBW_>
+struct GemmCfg {
+  static constexpr int NT = 512, WM = 4, WN = 2;                     // 8 waves: 4 over pixels x 2 over channels, 64 x 64 per wave ...
+  static constexpr int PBW = PBW_;                                   // ... (PBW 2: 256 x 128 tile) or 32 x 64 (PBW 1: 128 x 128 tile)
+  static constexpr int BM = 32 * PBW * WM, BN = 64 * WN, BK = 64, NS = 3;
+  static constexpr int A_STAGE = BM * BK * 2, W_STAGE = BN * BK * 2, STAGE = A_STAGE + W_STAGE;
+  static constexpr int RED = 2 * 8 * 2 * 32 * 4;                     // statistics fold: [2][8 waves][2 channel blocks][32] floats
+  static constexpr int LDS = NS * STAGE + RED;
+  static constexpr int A_DMA = A_STAGE / 1024 / 8, W_DMA = W_STAGE / 1024 / 8;      // 1 KB pieces per wave per stage
+  static constexpr int DMA = A_DMA + W_DMA;
+  static constexpr int NBB = BN / 32;                                // 32-channel blocks per tile
+};
+typedef __attribute__((address_space(3))) void* lds_vptr;
+// (a plain function on purpose: with this builtin inside a kernel TEMPLATE the host pass drops the instantiation without a
+// diagnostic -- the kernel handle stays an undefined symbol -- hipcc of ROCm 7.2)
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, char* lds_wave_base, unsigned voffset, int soffset) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_vptr)lds_wave_base, 16, (int)voffset, soffset, 0, 0);
+}
+
+// PERSISTENT: a block walks the tiles bid, bid + grid, ...; the ring runs on across tile boundaries (the first two stages of
+// the next tile are in flight during the epilogue of the current one), so a layer with four K stages per tile -- 256 -> 1024 at
+// 48^2 -- does not pay a memory round trip plus a store tail per tile with nothing beside them.
+template <int PBW>
+__global__ __launch_bounds__(512, 2) void conv1x1_gemm_bf16_kernel(const HaloArgs a) {
+  using C = GemmCfg<PBW>;
+  extern __shared__ __attribute__((aligned(1024))) char gsmem[];
+  char* const smem = gsmem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lp = lane & 31, lh = lane >> 5;
+  const int wm = wave / C::WN, wn = wave % C::WN;
+  const int M = a.n * a.h * a.w;
+  const int nblocks32 = (a.co + 31) >> 5;
+  const int nk = a.ci / C::BK;
+  const int ntiles = a.ntx;                          // pixel tiles x channel blocks (host)
+  const int G = (int)gridDim.x;
+
+  __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wf), 0, (int)a.w_bytes, 0x00020000);
+  // this wave's DMA pieces of a stage of tile t: pixel rows (8 rows x 128 bytes per piece, source pre-swizzled) and weight fragments
+  auto offsets = [&](int t, unsigned (&ao)[C::A_DMA], unsigned (&wo)[C::W_DMA]) {
+    const int cb = t % a.ncb, m0 = (t / a.ncb) * C::BM;
+#pragma unroll
+    for (int p = 0; p < C::A_DMA; ++p) {
+      const int S = (wave * C::A_DMA + p) * 64 + lane, row = S >> 3, j = S & 7, c = j ^ ((row >> 1) & 7);
+      ao[p] = (t < ntiles && (m0 + row) < M) ? (unsigned)(((m0 + row) * a.ci + c * 8) * 2) : 0x80000000u;
+    }
+#pragma unroll
+    for (int p = 0; p < C::W_DMA; ++p) {
+      const int q = wave * C::W_DMA + p;                 // fragment (32-channel block q >> 2, k16 step q & 3) of the stage
+      const int nbq = cb * C::NBB + (q >> 2);
+      wo[p] = (t < ntiles && nbq < nblocks32) ? (unsigned)(((nbq * a.nk16 + (q & 3)) * 64 + lane) * 16) : 0x80000000u;
+    }
+  };
+  auto issue = [&](int kt, int slot, const unsigned (&ao)[C::A_DMA], const unsigned (&wo)[C::W_DMA]) {
+    char* st = smem + slot * C::STAGE;
+#pragma unroll
+    for (int p = 0; p < C::A_DMA; ++p)
+      lds_dma16(rs_x, st + (wave * C::A_DMA + p) * 1024, ao[p], kt * C::BK * 2);
+#pragma unroll
+    for (int p = 0; p < C::W_DMA; ++p)
+      lds_dma16(rs_w, st + C::A_STAGE + (wave * C::W_DMA + p) * 1024, wo[p], kt * 4 * 1024);
+  };
+
+  // fragment read addresses inside a stage
+  int prd[C::PBW][4];
+#pragma unroll
+  for (int pb = 0; pb < C::PBW; ++pb) {
+    const int row = (wm * C::PBW + pb) * 32 + lp;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) prd[pb][s] = row * 128 + (((2 * s + lh) ^ ((row >> 1) & 7)) * 16);
+  }
+  const int wrd = C::A_STAGE + (wn * 2 * 4) * 1024 + lane * 16;
+  float* red = reinterpret_cast<float*>(smem + C::NS * C::STAGE);       // [2 statistics][8 waves][2 channel blocks][32]
+  __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)a.y_bytes, 0x00020000);
+  const bool want_stats = a.stats != nullptr && a.bnb_y == nullptr;
+  const bool want_bnb = a.bnb_y != nullptr;
+  __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(want_bnb ? a.bnb_y : a.x), 0,
+                                                                  (int)(want_bnb ? a.bnb_bytes : 0u), 0x00020000);
+
+  // the stage sequence of this block: tiles t0, t0 + G, ... x nk stages each; stage g sits in ring slot g % NS, two stages ahead
+  unsigned ao_c[C::A_DMA], wo_c[C::W_DMA], ao_n[C::A_DMA], wo_n[C::W_DMA];
+  int t = (int)blockIdx.x;
+  offsets(t, ao_c, wo_c);
+  offsets(t + G, ao_n, wo_n);
+  // (a tile has at least two stages: the host requires ci >= 128)
+  issue(0, 0, ao_c, wo_c);
+  issue(1, 1, ao_c, wo_c);
+  int g = 0;                                         // global stage index of (t, kt = 0)
+  for (; t < ntiles; t += G) {
+    f32x16 acc[C::PBW][2];          // [pixel block][channel block]
+#pragma unroll
+    for (int i = 0; i < C::PBW; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+    for (int kt = 0; kt < nk; ++kt, ++g) {
+      // stage g has landed (this wave's pieces: everything but the DMA of the one younger stage), every wave's has after the
+      // barrier -- which also says that stage g - 1's slot has been read by all and may be refilled.  (Past the block's last
+      // tile the younger "stage" is a killed DMA that still counts.)
+      if constexpr (C::DMA == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      static_assert(C::DMA == 6 || C::DMA == 4, "counted wait");
+      __builtin_amdgcn_s_barrier();
+      if (kt + 2 < nk) issue(kt + 2, (g + 2) % C::NS, ao_c, wo_c);
+      else issue(kt + 2 - nk, (g + 2) % C::NS, ao_n, wo_n);            // the next tile's first stages (killed offsets past the end)
+      const char* st = smem + (g % C::NS) * C::STAGE;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        u32x4 wf[2], pf[C::PBW];
+#pragma unroll
+        for (int nn = 0; nn < 2; ++nn) wf[nn] = *reinterpret_cast<const u32x4*>(st + wrd + (nn * 4 + s) * 1024);
+#pragma unroll
+        for (int pb = 0; pb < C::PBW; ++pb) pf[pb] = *reinterpret_cast<const u32x4*>(st + prd[pb][s]);
+#pragma unroll
+        for (int pb = 0; pb < C::PBW; ++pb)
+#pragma unroll
+          for (int nn = 0; nn < 2; ++nn)
+            acc[pb][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[nn]), __builtin_bit_cast(bf16x8, pf[pb]),
+                                                                  acc[pb][nn], 0, 0, 0);
+      }
+    }
+    const int cb = t % a.ncb, m0 = (t / a.ncb) * C::BM;
+    // the next tile becomes the current one (its first two stages are already in flight)
+#pragma unroll
+    for (int p = 0; p < C::A_DMA; ++p) ao_c[p] = ao_n[p];
+#pragma unroll
+    for (int p = 0; p < C::W_DMA; ++p) wo_c[p] = wo_n[p];
+    offsets(t + 2 * G, ao_n, wo_n);
+
+    // ---- epilogue: the streaming kernel's, per (pixel block, channel block) of this wave
+#pragma unroll
+    for (int nn = 0; nn < 2; ++nn) {
+      const int nb = cb * C::NBB + wn * 2 + nn;
+      const bool live = nb < nblocks32;
+      const int cbase = nb * 32;
+      float sA[16], sB[16];
+#pragma unroll
+      for (int v = 0; v < 16; ++v) sA[v] = sB[v] = 0.f;
+#pragma unroll
+      for (int pb = 0; pb < C::PBW; ++pb) {
+        const int pix = m0 + (wm * C::PBW + pb) * 32 + lp;
+        const bool pv = live && pix < M;
+        const unsigned pixoff = (unsigned)pix;
+        unsigned dw[8];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int c0 = cbase + 8 * gq + 4 * lh;
+          const bool cv = pv && c0 < a.co;
+          float val[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) val[e] = acc[pb][nn][4 * gq + e];
+          if (a.bias != nullptr) {
+            const f32x4 bq = *reinterpret_cast<const f32x4*>(a.bias + (c0 < a.co ? c0 : 0));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) val[e] += bq[e];
+          }
+          if (want_stats) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float q = cv ? val[e] : 0.f;
+              sA[4 * gq + e] += q;
+              sB[4 * gq + e] = __builtin_fmaf(q, q, sB[4 * gq + e]);
+            }
+          }
+          if (a.act != UDASEG_ACT_NONE) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) val[e] = act_apply(val[e], a.act, a.slope);
+          }
+          if (a.accumulate) {
+            const unsigned ooff = cv ? (pixoff * (unsigned)a.co + (unsigned)c0) * 2u : 0x80000000u;
+            const u32x2 old = __builtin_amdgcn_raw_buffer_load_b64(rs_y, (int)ooff, 0, 0);
+            val[0] += bf_lo(old[0]); val[1] += bf_hi(old[0]); val[2] += bf_lo(old[1]); val[3] += bf_hi(old[1]);
+          }
+          dw[2 * gq] = pack_bf16x2(val[0], val[1]);
+          dw[2 * gq + 1] = pack_bf16x2(val[2], val[3]);
+          if (want_bnb) {
+            const unsigned poff = cv ? (pixoff * (unsigned)a.co + (unsigned)c0) * 2u : 0x80000000u;
+            const u32x2 yv = __builtin_amdgcn_raw_buffer_load_b64(rs_p, (int)poff, 0, 0);
+            const f32x4 mu = *reinterpret_cast<const f32x4*>(a.bnb_mean + (c0 < a.co ? c0 : 0));
+            const f32x4 rsd = *reinterpret_cast<const f32x4*>(a.bnb_rstd + (c0 < a.co ? c0 : 0));
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(a.bnb_gamma + (c0 < a.co ? c0 : 0));
+            const f32x4 bt = *reinterpret_cast<const f32x4*>(a.bnb_beta + (c0 < a.co ? c0 : 0));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float yy = (e & 1) ? bf_hi(yv[e >> 1]) : bf_lo(yv[e >> 1]);
+              const float gr = (e & 1) ? bf_hi(dw[2 * gq + (e >> 1)]) : bf_lo(dw[2 * gq + (e >> 1)]);
+              const float sc = gm[e] * rsd[e], sh = bt[e] - mu[e] * sc;
+              const float gg = cv ? gr * act_grad(__builtin_fmaf(yy, sc, sh), a.bnb_act, a.bnb_slope) : 0.f;
+              sA[4 * gq + e] += gg;
+              sB[4 * gq + e] = __builtin_fmaf(gg, (yy - mu[e]) * rsd[e], sB[4 * gq + e]);
+            }
+          }
+        }
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+          const u32x2 s0 = __builtin_amdgcn_permlane32_swap(dw[4 * gp], dw[4 * gp + 2], false, false);
+          const u32x2 s1 = __builtin_amdgcn_permlane32_swap(dw[4 * gp + 1], dw[4 * gp + 3], false, false);
+          const u32x4 d = {s0[0], s1[0], s0[1], s1[1]};
+          const int c8 = cbase + 8 * (2 * gp + lh);
+          const unsigned off = (pv && c8 < a.co) ? (pixoff * (unsigned)a.co + (unsigned)c8) * 2u : 0x80000000u;
+          __builtin_amdgcn_raw_buffer_store_b128(d, rs_y, (int)off, 0, 0);
+        }
+      }
+      if (want_stats || want_bnb) {
+        asm volatile("s_nop 1");
+        halfwave_sum_n(sA);
+        halfwave_sum_n(sB);
+        asm volatile("s_nop 1");
+        if (lp == 31) {
+#pragma unroll
+          for (int v = 0; v < 16; ++v) {
+            const int cl = (v & 3) + 8 * (v >> 2) + 4 * lh;
+            red[(wave * 2 + nn) * 32 + cl] = live ? sA[v] : 0.f;
+            red[512 + (wave * 2 + nn) * 32 + cl] = live ? sB[v] : 0.f;
+          }
+        }
+      }
+    }
+    if (want_stats || want_bnb) {
+      // (the epilogue's stores and loads must not hold the next tile's counted DMA waits hostage: they are older than the two
+      // stages in flight, so vmcnt(DMA) at the next stage waits for them too -- which is what orders `red` as well)
+      __syncthreads();
+      if (tid < C::BN) {           // one thread per channel of the block: the WM pixel-row waves that share it, in wave order
+        const int cl = tid & 31, q = tid >> 5;                 // q: 32-channel block of the tile = (wn, nn)
+        const int c = cb * C::BN + q * 32 + cl;
+        if (c < a.co) {
+          float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+          for (int m = 0; m < C::WM; ++m) {
+            const int w = m * C::WN + (q >> 1);
+            t1 += red[(w * 2 + (q & 1)) * 32 + cl];
+            t2 += red[512 + (w * 2 + (q & 1)) * 32 + cl];
+          }
+          double* rep = a.sscr != nullptr ? a.sscr + (size_t)(blockIdx.x % HALO_SCR_REPLICAS) * 2 * a.co
+                                          : a.stats + (size_t)(blockIdx.x % HALO_STATS_REPLICAS) * 2 * a.co;
+          atomicAdd(rep + c, (double)t1);
+          atomicAdd(rep + a.co + c, (double)t2);
+        }
+      }
+      __syncthreads();             // `red` may be rewritten by the next tile
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the killed DMAs of the stages past the end
+}
+
 // ------------------------------------------------------------------------------------------------ fragment packing
 // Weights in MFMA-fragment order.  For a convolution with N produced and K gathered channels and a KS x KS window:
 //   packed[nb][dx][k16][dy][lane][j]  (nb < ceil(N/32), k16 < ceil(K/16), lane < 64, j < 8; bf16)
@@ -864,6 +1124,76 @@ static int launch_stream_t(HaloArgs a, hipStream_t s, double flops) {
   return UDASEG_OK;
 }
 
+template <int PBW>
+static int launch_gemm_t(HaloArgs a, hipStream_t s, double flops) {
+  using C = GemmCfg<PBW>;
+  auto kern = conv1x1_gemm_bf16_kernel<PBW>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv1x1_gemm_bf16)");
+    attr_done = true;
+  }
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hip_fail(hipGetLastError(), "hipGetDeviceProperties");
+    cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  a.ncb = cdiv(a.co, C::BN);
+  a.nk16 = (a.ci + 15) / 16;
+  const long long tiles = cdiv64((long long)a.n * a.h * a.w, C::BM) * a.ncb;
+  if (tiles <= 0) return UDASEG_OK;
+  a.ntx = (int)tiles;
+  // persistent blocks, one per CU; an even share where the tile count allows it (288 tiles: 144 blocks x 2 finish with 256 x 1 + 32 x 2)
+  long long grid = tiles < cus ? tiles : cus;
+  const long long per = cdiv64(tiles, grid);
+  grid = cdiv64(tiles, per);
+  a.sscr = nullptr;
+  static int kid = -1;
+  if (kid < 0) {
+    char nm[64];
+    snprintf(nm, sizeof(nm), "conv1x1_gemm_bf16_kernel<%d>", PBW);
+    kid = kprof_id(nm);
+  }
+  hipEvent_t ev = kprof_begin(s);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C::NT), C::LDS, s, a);
+  kprof_end(kid, ev, s, flops);
+  UDASEG_LAUNCH_CHECK("conv1x1_gemm_bf16 launch");
+  return UDASEG_OK;
+}
+
+static int launch_gemm(HaloArgs a, hipStream_t s, double flops) {
+  // 256 x 128 tiles while they occupy at least half the CUs; 128 x 128 below that (r50's 24^2 stage, 2048 -> 512: 72 tiles).
+  // Stand-alone, us (tools/gemm1x1_probe.py, profiles/r04_gemm_1x1.txt), 256- / 128-pixel tiles: M 18432 K 1024 N 256 22.0 / 27.2;
+  // M 4608 K 2048 N 512 30.7 / 23.6; M 4608 K 512 N 2048 26.8 / 27.7; M 73728 K 128 N 512 45.4 / 53.0
+  static int force = -1;      // UDASEG_GEMM_1X1_TILE = 128 | 256 (A/B)
+  if (force < 0) {
+    const char* e = getenv("UDASEG_GEMM_1X1_TILE");
+    force = e ? atoi(e) : 0;
+  }
+  const long long t256 = cdiv64((long long)a.n * a.h * a.w, 256) * cdiv(a.co, 128);
+  const bool small = force == 128 || (force != 256 && t256 < 128);
+  return small ? launch_gemm_t<1>(a, s, flops) : launch_gemm_t<2>(a, s, flops);
+}
+
+// The GEMM kernel takes the 1x1 launches that are GEMMs proper: whole 64-channel K stages, at least 128 produced channels, no
+// transform of the gathered tensor (LDS-DMA moves bytes), and -- UDASEG_GEMM_1X1_MAXM, default 73728 = r50's 96^2 stage at batch 8 --
+// few enough pixels that the streaming kernel's one-tile-per-CU schedule is latency-bound.  UDASEG_GEMM_1X1=0: never (A/B).
+static bool gemm_applicable(const HaloArgs& a) {
+  static int on = -1;
+  static long long maxm = 0;
+  if (on < 0) {
+    const char* e = getenv("UDASEG_GEMM_1X1");
+    on = (e && atoi(e) == 0) ? 0 : 1;
+    const char* m = getenv("UDASEG_GEMM_1X1_MAXM");
+    maxm = m ? atoll(m) : 73728;
+  }
+  return on && a.in_scale == nullptr && a.ci % 64 == 0 && a.ci >= 128 && a.co % 64 == 0 && a.co >= 128 &&
+         (long long)a.n * a.h * a.w <= maxm;
+}
+
 // The streamer takes the plain 1x1 launches: bf16 output, no fused decoder input, no split.
 static bool stream_applicable(const HaloArgs& a, int ks) {
   static int off = -1;   // UDASEG_NO_STREAM=1: 1x1 layers stay on the tile kernel (A/B)
@@ -952,7 +1282,7 @@ int launch_halo(const udaseg_conv_desc* d, HaloArgs a, hipStream_t s, bool dgrad
   // chunk: 32 channels (64 for the 1x1 kernels) when that divides the gathered channels and both sources of a fused input
   int ck = 32;
   if (a.ci % 32 != 0 || (a.up_ca > 0 && (a.up_ca % 32 != 0 || (a.ci - a.up_ca) % 32 != 0))) ck = 16;
-  if (stream_applicable(a, d->kh)) return launch_stream(a, s, flops);
+  if (stream_applicable(a, d->kh)) return gemm_applicable(a) ? launch_gemm(a, s, flops) : launch_stream(a, s, flops);
   int choice = halo_choice(d->kh, a.h, a.w, a.n, a.ci, a.co, dgrad);
   if (choice == 0) choice = a.co <= 32 ? 1 : (a.co <= 64 ? 2 : 3);     // called although not preferred (tests, UDASEG_FRAG=2)
   if (choice > 3 && (d->kh != 3 || ck != 32)) choice = a.co <= 64 ? 2 : 3;

@@ -60,7 +60,10 @@ struct F3Args {
   float bnb_slope;
   int ntx, nty, ncb, nk16;
   unsigned x_bytes, x2_bytes, w_plane_bytes, y_bytes, y2_bytes, bnb_bytes;
+  unsigned long long* timeline;   // diagnosis (udaseg_debug_set_timeline; stamped twin of the wave-specialised kernel only)
 };
+extern unsigned long long* g_timeline;      // conv_igemm.hip
+extern int g_timeline_blocks;
 
 template <int WM, int WN, int RPW>
 struct F3Cfg {
@@ -265,6 +268,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_f32x3_kernel(const F3
   }
 
   constexpr int NW_EPI = WM * WN;
+  constexpr int EPI_TW = 32;
 #include "conv_halo_f32x3_epilogue.inc"
 }
 
@@ -281,12 +285,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_f32x3_kernel(const F3
 // with the loader running on across tile boundaries, statistics kept in registers until the block ends, weights requested three
 // groups ahead -- 59 / 57 / 60 us on the 64 / 128 / 256-channel layers against 58 / 53 / 59 for this form, whose two co-resident
 // blocks per CU already cover each other's prologue and epilogue.)
-template <int WM_, int WN_, int RPW>
+template <int WM_, int WN_, int RPW, int TW_ = 32>
 struct F3WsCfg {
   static constexpr int WM = WM_, WN = WN_;
   static_assert(WM_ * WN_ == 4, "four MFMA waves");
+  static_assert(TW_ == 32 || TW_ == 16, "32-pixel rows, or 16-pixel rows (the 32 pixels of an MFMA block are then TWO image rows)");
   static constexpr int NT = 512, NLD = 256;               // threads; loader threads
-  static constexpr int TH = WM * RPW, TW = 32;
+  static constexpr int TW = TW_, RL = 32 / TW_;           // image rows per 32-pixel MFMA block
+  static constexpr int TH = WM * RPW * RL;
+  static constexpr int NJ = RL * RPW + 2;                  // fragment start rows a wave reads per (dx) group
   static constexpr int HR = TH + 2, HWD = TW + 2;
   static constexpr int PLANE = HR * HWD * 32;
   static constexpr int LDS_HALO = 3 * PLANE;
@@ -299,11 +306,17 @@ struct F3WsCfg {
   static constexpr int LDS = 2 * LDS_HALO + 2 * LDS_WBUF;
 };
 
-template <int WM, int WN, int RPW>
+template <int WM, int WN, int RPW, bool TL = false, int TW = 32>
 __global__ __launch_bounds__(512, 1) void conv3x3_f32x3_ws_kernel(const F3Args a) {
-  using C = F3WsCfg<WM, WN, RPW>;
+  using C = F3WsCfg<WM, WN, RPW, TW>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const wlds = smem + 2 * C::LDS_HALO;
+  // TL: shader-clock stamps of one MFMA wave and one loader wave per block (tools/f3_timeline.py)
+  unsigned long long tl_e = 0, tl_first = 0, tl_bar = 0, tl_work = 0, tl_kend = 0, tl_w0 = 0, tl_t = 0;
+  if constexpr (TL) {
+    tl_w0 = __builtin_amdgcn_s_memrealtime();
+    tl_e = __builtin_amdgcn_s_memtime();
+  }
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -430,6 +443,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_f32x3_ws_kernel(const F3Args a
     if (nchunk > 1) load_chunk(1);
     if (NG > 1) load_w(1);
     __syncthreads();                               // group 0 is staged
+    if constexpr (TL) tl_first = tl_t = __builtin_amdgcn_s_memtime();
     for (int G = 0; G < NG; ++G) {
       const int c = G / 3, dx = G - 3 * c;
       if (G + 1 < NG) {
@@ -440,18 +454,31 @@ __global__ __launch_bounds__(512, 1) void conv3x3_f32x3_ws_kernel(const F3Args a
         store_chunk((c + 1) & 1);                  // last read in chunk c - 1
         if (c + 2 < nchunk) load_chunk(c + 2);
       }
+      if constexpr (TL) {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        tl_work += t - tl_t;
+        tl_t = t;
+      }
       __syncthreads();
+      if constexpr (TL) {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        tl_bar += t - tl_t;
+        tl_t = t;
+      }
     }
+    if constexpr (TL) tl_kend = tl_t;
   } else {
     // pixel fragment address per dx: lane pixel lp of a row, K half lh (swapped where bit 3 of the halo column is set)
+    // (16-pixel rows: lanes 0-15 / 16-31 of a fragment are two consecutive image rows; a fragment may start at ANY halo row)
     int poff[3];
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) {
-      const int hx = lp + dx;
-      poff[dx] = (wm * RPW * C::HWD + hx) * 32 + ((lh ^ ((hx >> 3) & 1)) * 16);
+      const int hx = lp % C::TW + dx;
+      poff[dx] = ((wm * RPW * C::RL + lp / C::TW) * C::HWD + hx) * 32 + ((lh ^ ((hx >> 3) & 1)) * 16);
     }
     const int wrd = (wn * 9) * 1024 + lane * 16;
     __syncthreads();                               // group 0 is staged
+    if constexpr (TL) tl_first = tl_t = __builtin_amdgcn_s_memtime();
     for (int c = 0; c < nchunk; ++c) {
       const char* hb = smem + (c & 1) * C::LDS_HALO;
 #pragma unroll
@@ -466,8 +493,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_f32x3_ws_kernel(const F3Args a
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) pf[0][pl] = *reinterpret_cast<const u32x4*>(hb + pl * C::PLANE + poff[dx]);
 #pragma unroll
-        for (int s = 0; s < C::S; ++s) {
-          if (s + 1 < C::S) {
+        for (int s = 0; s < C::NJ; ++s) {
+          if (s + 1 < C::NJ) {
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl)
               pf[(s + 1) & 1][pl] = *reinterpret_cast<const u32x4*>(hb + pl * C::PLANE + poff[dx] + (s + 1) * C::HWD * 32);
@@ -478,24 +505,51 @@ __global__ __launch_bounds__(512, 1) void conv3x3_f32x3_ws_kernel(const F3Args a
             for (int i = 0; i <= ij; ++i)
 #pragma unroll
               for (int dy = 0; dy < 3; ++dy) {
-                const int r = s - dy;
-                if (r >= 0 && r < RPW)
+                const int r = (s - dy) / C::RL;        // the fragment that starts at halo row s is tap row dy of MFMA block r
+                if (s - dy >= 0 && (s - dy) % C::RL == 0 && r < RPW)
                   acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bf[dy][i]),
                                                                    __builtin_bit_cast(bf16x8, pf[s & 1][ij - i]), acc[r], 0, 0, 0);
               }
         }
+        if constexpr (TL) {
+          const unsigned long long t = __builtin_amdgcn_s_memtime();
+          tl_work += t - tl_t;
+          tl_t = t;
+        }
         __syncthreads();                           // group G + 1 is staged; this group's buffers may be rewritten
+        if constexpr (TL) {
+          const unsigned long long t = __builtin_amdgcn_s_memtime();
+          tl_bar += t - tl_t;
+          tl_t = t;
+        }
       }
     }
+    if constexpr (TL) tl_kend = tl_t;
   }
   if (loader) {                                    // the statistics reduction has one block barrier
     if (a.stats != nullptr) __syncthreads();
+    if constexpr (TL) {
+      if (a.timeline != nullptr && tid == 256) {
+        unsigned long long* t = a.timeline + ((size_t)blockIdx.x * 2 + 1) * 8;
+        t[0] = tl_first - tl_e; t[1] = tl_work; t[2] = tl_bar; t[3] = 0;
+        t[4] = __builtin_amdgcn_s_memtime() - tl_e; t[5] = __builtin_amdgcn_s_memrealtime() - tl_w0; t[6] = (unsigned long long)NG; t[7] = 1;
+      }
+    }
     return;
   }
   constexpr int NW_EPI = WM * WN;
+  constexpr int EPI_TW = C::TW;
   {
     const int wave = mw;                           // the epilogue's statistics slot: this wave's index among the MFMA waves
 #include "conv_halo_f32x3_epilogue.inc"
+  }
+  if constexpr (TL) {
+    if (a.timeline != nullptr && tid == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the epilogue's stores have left
+      unsigned long long* t = a.timeline + (size_t)blockIdx.x * 2 * 8;
+      t[0] = tl_first - tl_e; t[1] = tl_work; t[2] = tl_bar; t[3] = __builtin_amdgcn_s_memtime() - tl_kend;
+      t[4] = __builtin_amdgcn_s_memtime() - tl_e; t[5] = __builtin_amdgcn_s_memrealtime() - tl_w0; t[6] = (unsigned long long)NG; t[7] = 1;
+    }
   }
 }
 
@@ -539,10 +593,10 @@ __global__ void pack_frag_batched_f32x3_kernel(const float* __restrict__ w32, co
 }
 
 // ------------------------------------------------------------------------------------------------- host side
-template <int WM, int WN, int RPW>
+template <int WM, int WN, int RPW, int TW = 32>
 static int launch_f3_ws_t(F3Args a, hipStream_t s, double flops) {
-  using C = F3WsCfg<WM, WN, RPW>;
-  auto kern = conv3x3_f32x3_ws_kernel<WM, WN, RPW>;
+  using C = F3WsCfg<WM, WN, RPW, TW>;
+  auto kern = conv3x3_f32x3_ws_kernel<WM, WN, RPW, false, TW>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
@@ -560,11 +614,24 @@ static int launch_f3_ws_t(F3Args a, hipStream_t s, double flops) {
   static int kid = -1;
   if (kid < 0) {
     char nm[96];
-    snprintf(nm, sizeof(nm), "conv3x3_f32x3_ws_kernel<%d, %d, %d>", WM, WN, RPW);
+    if (TW == 32) snprintf(nm, sizeof(nm), "conv3x3_f32x3_ws_kernel<%d, %d, %d>", WM, WN, RPW);
+    else snprintf(nm, sizeof(nm), "conv3x3_f32x3_ws_kernel<%d, %d, %d, false, %d>", WM, WN, RPW, TW);
     kid = kprof_id(nm);
   }
   hipEvent_t ev = kprof_begin(s);
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::NT), C::LDS, s, a);
+  if (g_timeline != nullptr && blocks * 16 <= (long long)g_timeline_blocks * 6) {      // stamped twin (diagnosis only)
+    auto kern_tl = conv3x3_f32x3_ws_kernel<WM, WN, RPW, true, TW>;
+    static bool tl_attr = false;
+    if (!tl_attr) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern_tl), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+      if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv3x3_f32x3_ws timeline twin)");
+      tl_attr = true;
+    }
+    a.timeline = g_timeline;
+    hipLaunchKernelGGL(kern_tl, dim3((unsigned)blocks), dim3(C::NT), C::LDS, s, a);
+  } else {
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::NT), C::LDS, s, a);
+  }
   kprof_end(kid, ev, s, flops);
   UDASEG_LAUNCH_CHECK("conv3x3_f32x3_ws launch");
   if (a.sscr != nullptr) {
@@ -637,8 +704,9 @@ static int f3_choice(int h, int w, int n, int gathered, int produced) {
     const char* e = getenv("UDASEG_F3_CFG");
     g_f3_force = e ? atoi(e) : 0;
   }
-  if (g_f3_force >= 1 && g_f3_force <= 8) return g_f3_force;
-  if (w < 32) return 0;                             // 16-pixel-wide images: half of every 32-pixel tile row is outside
+  if (g_f3_force >= 1 && g_f3_force <= 12) return g_f3_force;
+  if (w <= 16) return produced >= 64 ? 9 : 0;       // 16-pixel-wide images: 4 x 16 pixel tiles, two image rows per MFMA block
+  if (w < 32) return 0;
   const long long tiles = (long long)n * cdiv(h, 8) * cdiv(w, 32);
   if (produced <= 32) return 1;
   // 64 and more produced channels: the wave-specialised kernel (one 8-wave block per CU), on 4 x 32 pixel tiles, or 8 x 32 where the
@@ -668,6 +736,10 @@ static int launch_f3(F3Args a, hipStream_t s, double flops) {
   if (choice == 6) return launch_f3_ws_t<2, 2, 2>(a, s, flops);   // 4 x 32 pixels x 64 channels, same roles
   if (choice == 7) return launch_f3_ws_t<4, 1, 2>(a, s, flops);   // 8 x 32 pixels x 32 channels, same roles
   if (choice == 8) return launch_f3_ws_t<4, 1, 4>(a, s, flops);   // 16 x 32 pixels x 32 channels, same roles
+  if (choice == 9) return launch_f3_ws_t<2, 2, 1, 16>(a, s, flops);   // 4 x 16 pixels x 64 channels (16-pixel-wide images), same roles
+  if (choice == 10) return launch_f3_ws_t<2, 2, 2, 16>(a, s, flops);  // 8 x 16 x 64
+  if (choice == 11) return launch_f3_ws_t<4, 1, 2, 16>(a, s, flops);  // 16 x 16 x 32
+  if (choice == 12) return launch_f3_ws_t<4, 1, 1, 16>(a, s, flops);  // 8 x 16 x 32
   return launch_f3_t<2, 2, 4>(a, s, flops);
 }
 
@@ -685,7 +757,7 @@ extern "C" int udaseg_pack_frag_batched_f32x3(const float* w32, const float* wt3
 }
 
 extern "C" int udaseg_f32x3_force_config(int cfg) {
-  UDASEG_CHECK_ARG(cfg >= 0 && cfg <= 8, "f32x3_force_config: 0 (heuristic), 1 (8 x 32 px x 32 ch), 2 (8 x 32 x 64), 3 (4 x 32 x 64), 4 (16 x 32 x 64), 5 / 6 (wave-specialised 8 / 4 x 32 x 64), 7 / 8 (wave-specialised 8 / 16 x 32 x 32)");
+  UDASEG_CHECK_ARG(cfg >= 0 && cfg <= 12, "f32x3_force_config: 0 (heuristic), 1 (8 x 32 px x 32 ch), 2 (8 x 32 x 64), 3 (4 x 32 x 64), 4 (16 x 32 x 64), 5 / 6 (wave-specialised 8 / 4 x 32 x 64), 7 / 8 (wave-specialised 8 / 16 x 32 x 32), 9 (wave-specialised 4 x 16 x 64)");
   g_f3_force = cfg;
   return UDASEG_OK;
 }

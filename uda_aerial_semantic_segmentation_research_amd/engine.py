@@ -44,12 +44,14 @@ USE_F32_SPLIT = os.environ.get("UDASEG_F32_SPLIT", "1") != "0"
 
 # bf16 storage: BatchNorm + activation of a layer whose ONLY consumer is a convolution on the bf16-first kernels is not written at
 # all -- the consumer applies it while it stages its input (UDASEG_FUSE_BN_APPLY=0: always the stand-alone bn_apply pass)
-FUSE_BN_APPLY = os.environ.get("UDASEG_FUSE_BN_APPLY", "2") != "0"
-# Default "2": only in front of 1x1 consumers.  The weight gradient of a 3x3 consumer gathers every input element once per tap
+FUSE_BN_APPLY = os.environ.get("UDASEG_FUSE_BN_APPLY", "0") != "0"
+# Round 4: OFF by default.  The small-GEMM 1x1 kernel (csrc/conv_halo_bf16.hip: conv1x1_gemm_bf16_kernel) fills LDS by DMA and cannot
+# transform what it gathers, and r50's 1x1 consumers are exactly its layers: cfg 5 462.1 images/s with the unwritten activations
+# (their consumers then stay on the streaming kernel), 465.1 without (profiles/r04_gemm_1x1.txt).  "2": only in front of 1x1 consumers.  The weight gradient of a 3x3 consumer gathers every input element once per tap
 # (in different blocks), so the transform is evaluated nine times per element there and costs more than the pass it saves
 # (measured, profiles/r03_bn_fusion_ab.txt: cfg 3 / cfg 5 images/s off 987.8 / 395.3, everywhere ("1") 990.7 / 397.9, 1x1
 # consumers only 993.5 / 399.3; wgrad 256 -> 256 at 48^2 92 -> 136 us with the transform in its gather).
-FUSE_BN_APPLY_1X1_ONLY = os.environ.get("UDASEG_FUSE_BN_APPLY", "2") == "2"
+FUSE_BN_APPLY_1X1_ONLY = os.environ.get("UDASEG_FUSE_BN_APPLY", "0") == "2"
 
 
 # bf16 storage: weight gradients of the stride-1 3x3 layers with channel counts that are multiples of 64 on the halo-resident
