@@ -204,6 +204,16 @@ def build_leg(workload, encoder, dtype, batch, size, classes, dev, rank, world, 
     return step, model, trainer
 
 
+def pipe_of(symbol, dtype):
+    """(bf16-MFMA products per counted product, peak TFLOP/s of the pipe the kernel symbol runs on).  The fp32 three-term-split
+    kernels (conv3x3_f32x3*, conv_wgrad_halo_f32x3*, conv_wgrad_h2_kernel<3, ...>) evaluate every fp32 product as SIX bf16 MFMA
+    products: the pipe that bounds them is the bf16 one and the work it does is 6 x the algorithmic FLOPs."""
+    split = "f32x3" in symbol or symbol.startswith("conv_wgrad_h2_kernel<3,")
+    if split:
+        return F32X3_MFMA_PRODUCTS, BF16_MFMA_PEAK_TFLOPS
+    return 1, (BF16_MFMA_PEAK_TFLOPS if dtype == "bf16" else FP32_MFMA_PEAK_TFLOPS)
+
+
 def percentile(v, q):
     v = sorted(v)
     return v[min(len(v) - 1, max(0, int(round(q * (len(v) - 1)))))]
@@ -327,12 +337,13 @@ def roofline_leg(step, model, trainer, dtype, psteps=3, layer_table=False, pmc_t
     algorithmic = dom[2] / (dom[1] * 1e-3) / 1e12
     conv_ms = sum(k[1] for k in kern) / psteps
     peak = BF16_MFMA_PEAK_TFLOPS if dtype == "bf16" else FP32_MFMA_PEAK_TFLOPS
-    split = "f32x3" in dom[0]
+    mult, peak = pipe_of(dom[0], dtype)
+    split = mult > 1
     # the three-term-split kernels evaluate every fp32 product as SIX bf16 MFMA products (csrc/conv_halo_f32x3.hip): the pipe that
     # bounds them is the bf16 one and the work it does is 6 x the algorithmic FLOPs -- priced against the dense bf16 peak
-    achieved = algorithmic * (F32X3_MFMA_PRODUCTS if split else 1)
-    if split:
-        peak = BF16_MFMA_PEAK_TFLOPS
+    achieved = algorithmic * mult
+    # pipe-relative utilisation of the whole single-stream conv time: every kernel's pipe work against ITS pipe's dense peak
+    pipe_ms = sum(k[2] * pipe_of(k[0], dtype)[0] / (pipe_of(k[0], dtype)[1] * 1e12) * 1e3 for k in kern) / psteps
     traffic, traffic_src = pmc_traffic(dom[0], pmc_tag)
     return {"bound": "mfma", "kernel": dom[0], "achieved": round(achieved, 2), "peak": peak,
             "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
@@ -351,15 +362,16 @@ def roofline_leg(step, model, trainer, dtype, psteps=3, layer_table=False, pmc_t
                          "frac_of_8TBps": round(conv_bytes / (conv_ms_api * 1e-3) / 8e12, 4) if conv_ms_api else None,
                          "note": "all conv launches: (gathered tensor + output + weights, each counted once) / summed launch time"},
             "time_split": time_split,
+            "pipe_ms_per_step": round(pipe_ms, 4),
             "all_conv_kernels": {"ms_per_step": round(conv_ms, 3),
                                  "achieved": round(sum(k[2] for k in kern) / psteps / (conv_ms * 1e-3) / 1e12, 2),
                                  "flops_note": "per-kernel GEMM FLOPs count PHYSICAL channels (image 3->4, logits 23->24): the "
                                                "stem and head rows are overstated by 33 % / 4 %; the headline "
-                                               "conv_mfma_util_per_gpu uses the logical 133.30 GFLOP per image",
+                                               "conv_tflops_per_gpu uses the logical 133.30 GFLOP per image",
                                  "by_kernel": {k[0]: {"ms_per_step": round(k[1] / psteps, 3),
                                                       "tflops": round(k[2] / (k[1] * 1e-3) / 1e12, 1),
                                                       **({"bf16_pipe_tflops": round(F32X3_MFMA_PRODUCTS * k[2] / (k[1] * 1e-3) / 1e12, 1)}
-                                                         if "f32x3" in k[0] else {}),
+                                                         if pipe_of(k[0], dtype)[0] > 1 else {}),
                                                       "launches_per_step": k[3] // psteps} for k in kern}}}
 
 
@@ -384,6 +396,7 @@ def also_leg(name, workload, encoder, dtype, batch, size, classes, dev, steps=10
            "ms_per_step": round(1e3 * dt / steps, 3), "step_ms_median": round(percentile(ev_ms, 0.5), 3),
            "final_loss": round(float(loss.item()), 5),
            "conv_mfma_util": round(value * gf / 1e3 / peak, 4) if gf else None,
+           "conv_pipe_util": round(roof["pipe_ms_per_step"] / (1e3 * dt / steps), 4),
            "roofline": {k: roof[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
                                              "launches_per_step", "avg_launch_us", "ms_per_step", "hbm_view")},
            "time_split": roof["time_split"],
@@ -499,9 +512,14 @@ def main():
                        "arithmetic": ARITHMETIC_FP32 if args.dtype == "fp32" else
                        "bf16 storage of activations / weight copies, bf16 MFMA with fp32 accumulation, fp32 master weights, "
                        "statistics, gradients and optimizer state",
-                       # whole-job conv FLOP rate per GPU over the dense MFMA peak of the dtype; only for workloads whose conv
-                       # FLOPs per image are tabulated
-                       "conv_mfma_util_per_gpu": round(value * gf / 1e3 / world / peak, 4) if gf else None},
+                       # ALGORITHMIC conv FLOP rate per GPU (133.30 GFLOP per image), TFLOP/s
+                       "conv_tflops_per_gpu": round(value * gf / 1e3 / world, 2) if gf else None,
+                       # north_star's "conv MFMA util %", stated against the pipes the kernels actually run on: per step, every conv
+                       # kernel's pipe work (6 bf16 products per fp32 product for the three-term-split kernels, FLOPs as they are
+                       # for the fp32-MFMA ones) divided by ITS pipe's dense peak (2.5 PFLOP/s bf16, 157.3 TFLOP/s fp32), summed, over
+                       # the measured step time.  (Round 3's conv_mfma_util_per_gpu divided by the fp32 peak a pipe most FLOPs no
+                       # longer touch.)
+                       "conv_pipe_util_per_gpu": round(roofline["pipe_ms_per_step"] / (1e3 * dt / args.steps), 4) if roofline else None},
             "step_ms": {"median": round(percentile(ev_ms, 0.5), 3), "p10": round(percentile(ev_ms, 0.1), 3),
                         "p90": round(percentile(ev_ms, 0.9), 3), "timer": "hipEvent pair per step on the compute stream"},
             "sustained": sustained,
@@ -512,13 +530,19 @@ def main():
         if world == 1 and headline and not args.no_also and not rehearse:
             del step, model, trainer
             torch.cuda.empty_cache()
-            out["also"] = [
+            also = [
                 also_leg("BASELINE cfg 2 on the fp32-MFMA kernels only (UDASEG_F32_SPLIT=0)", "segmentation", "resnet18", "fp32", 8, 512,
                          args.classes, dev, split=False),
                 also_leg("BASELINE cfg 3", "adversarial", "resnet18", "bf16", 8, 512, args.classes, dev,
                          cpu=not args.no_cpu_baseline),
                 also_leg("BASELINE cfg 5 (per-GPU work)", "segmentation", "resnet50", "bf16", 8, 768, args.classes, dev),
             ]
+            out["also"] = also
+            # the driver's record keeps `config`: a compact copy of the three legs goes there too
+            out["config"]["also"] = {name: {"value": a["value"], "unit": a["unit"], "ms_per_step": a["ms_per_step"],
+                                            "dominant_kernel": a["roofline"]["kernel"], "frac": a["roofline"]["frac"],
+                                            "conv_pipe_util": a["conv_pipe_util"]}
+                                     for name, a in zip(("fp32_mfma_only", "cfg3", "cfg5"), also)}
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -727,5 +727,12 @@ def test_dgrad_with_bn_backward_reductions(K, n, h, w, c1, c2):
                 K.conv_desc(1, 16, 16, 512, 512, 3, 1, 1),     # K-sliced launch (atomic epilogue)
                 K.conv_desc(8, 128, 128, 16, 16, 3, 1, 1)):    # small-channel kernel
         assert not K.conv2d_dgrad_bnreduce_ok(bad)
+    # an unsupported geometry with well-formed operands: the LIBRARY says no (error code -> RuntimeError) ...
+    dk = K.conv_desc(1, 16, 16, 512, 512, 3, 1, 1)
+    z512 = lambda *shape: torch.zeros(*shape, device="cuda")
     with pytest.raises(RuntimeError, match="cannot carry"):
-        K.conv2d_dgrad_bnreduce(K.conv_desc(1, 16, 16, 512, 512, 3, 1, 1), dy, wt, dx, prev_y, mean, rstd, gamma, beta, 1, 0.0, bs)
+        K.conv2d_dgrad_bnreduce(dk, z512(1, 16, 16, 512), z512(512, 3, 3, 512), z512(1, 16, 16, 512), z512(1, 16, 16, 512), z512(512),
+                                z512(512), z512(512), z512(512), 1, 0.0, torch.zeros(R * 2 * 512, dtype=torch.float64, device="cuda"))
+    # ... and operands that do not fit the descriptor never reach it (the binding's operand table, _operands.py)
+    with pytest.raises(ValueError, match="too short"):
+        K.conv2d_dgrad_bnreduce(dk, dy, wt, dx, prev_y, mean, rstd, gamma, beta, 1, 0.0, bs)

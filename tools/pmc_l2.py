@@ -1,6 +1,6 @@
 """Reduce one rocprofv3 PMC pass (--pmc TCC_HIT_sum TCC_MISS_sum) to the L2 hit rate of every conv / BatchNorm kernel symbol.
 
-    python tools/pmc_l2.py <counter_collection.csv> <out.json>
+    python tools/pmc_l2.py <counter_collection.csv> <out.json> [workload text]
 
 hit rate = TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum)  (MI355X_MICROARCH.md, L2 section), summed over the launches of a symbol.
 """
@@ -33,7 +33,8 @@ def main():
         h, m = v.get("TCC_HIT_sum", 0.0), v.get("TCC_MISS_sum", 0.0)
         out[k] = {"launches": cnt[k], "tcc_hit_per_launch": round(h / max(cnt[k], 1)), "tcc_miss_per_launch": round(m / max(cnt[k], 1)),
                   "l2_hit_rate": round(h / (h + m), 4) if h + m else None}
-    json.dump({"note": "rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum, single stream; requests of 128 B", "kernels": out}, open(sys.argv[2], "w"),
+    leg = sys.argv[3] if len(sys.argv) > 3 else "workload not stated"
+    json.dump({"note": "rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum, " + leg + ", single stream; requests of 128 B", "kernels": out}, open(sys.argv[2], "w"),
               indent=1)
     for k, v in sorted(out.items(), key=lambda kv: -(kv[1]["tcc_hit_per_launch"] + kv[1]["tcc_miss_per_launch"]) * kv[1]["launches"]):
         print(f"{k:60s} n={v['launches']:4d} hit rate {v['l2_hit_rate']}")

@@ -1,7 +1,7 @@
 """Reduce one rocprofv3 PMC pass (--pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA) to the
 matrix-pipe utilisation of every conv kernel symbol.
 
-    python tools/pmc_mfma.py <counter_collection.csv> <out.json>
+    python tools/pmc_mfma.py <counter_collection.csv> <out.json> [workload text]
 
 SQ_VALU_MFMA_BUSY_CYCLES is summed over the chip's 1024 SIMDs; GRBM_GUI_ACTIVE is reported as the sum over the 8 XCDs
 (MI355X_MICROARCH.md, DVFS section), so   mfma_busy = BUSY_CYCLES / (1024 * GUI_ACTIVE / 8)   is the fraction of SIMD cycles
@@ -44,8 +44,9 @@ def main():
                   "mfma_busy": round(busy / (1024 * gui / 8), 4) if gui else None,
                   "valu_per_mfma": round((v.get("SQ_INSTS_VALU", 0.0) - mf) / mf, 2) if mf else None,
                   "clock_ghz": round(gui / 8 / v["_ns"], 3) if v["_ns"] else None}
-    json.dump({"note": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA, r18-Unet "
-                       "8x3x512x512 fp32 train step, single stream; mfma_busy = fraction of SIMD cycles with the matrix pipe busy",
+    leg = sys.argv[3] if len(sys.argv) > 3 else "r18-Unet 8x3x512x512 fp32 train step (BASELINE cfg 2)"
+    json.dump({"note": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA, " + leg +
+                       ", single stream; mfma_busy = fraction of SIMD cycles with the matrix pipe busy",
                "kernels": out}, open(sys.argv[2], "w"), indent=1)
     for k, v in sorted(out.items(), key=lambda kv: -kv[1]["avg_us"] * kv[1]["launches"]):
         print(f"{k:52s} n={v['launches']:4d} {v['avg_us']:8.1f} us  mfma_busy {v['mfma_busy']}  valu/mfma {v['valu_per_mfma']}  clk {v['clock_ghz']}")
