@@ -339,3 +339,85 @@ def test_wgrad_halo_over_fused_upsample_concat(K, n, h, w, ca, cb, co):
     wr = torch.zeros(co, ca + cb, 3, 3, requires_grad=True)
     F.conv2d(cat, wr, None, padding=1).backward(dy)
     close(dw.cpu().permute(0, 3, 1, 2), wr.grad, "fused-input halo wgrad vs torch", 1e-4)
+
+
+def pack_s2(K, wt):
+    """wt: [co][ci][4][4] -> (forward fragments: 2x2 window over 4 ci phase-major channels; data-gradient fragments of the four
+    input parity classes), through the batched packer's modes 2 and 3..6 as engine.build_arena lays them out."""
+    co, ci, k, _ = wt.shape
+    assert k == 4
+    w16 = wt.permute(0, 2, 3, 1).contiguous().to("cuda", bf)           # OHWI
+    wt16 = wt.permute(1, 2, 3, 0).contiguous().to("cuda", bf)          # [ci][kh][kw][co]
+    nf, fe = K.frag_elems(co, 4 * ci, 2), K.frag_elems(ci, co, 2)
+    packed = torch.full((nf + 4 * fe,), float("nan"), device="cuda", dtype=bf)
+    rows = [[2, 0, 0, co, ci, 4]] + [[3 + e, 0, nf + e * fe, ci, co, 4] for e in range(4)]
+    K.pack_frag_batched(w16, wt16, packed, torch.tensor(rows, dtype=torch.int32, device="cuda"))
+    assert torch.isfinite(packed.float()).all()
+    return packed[:nf], packed[nf:]
+
+
+S2_CASES = [(2, 64, 64, 8, 64), (2, 32, 32, 64, 128), (1, 16, 48, 128, 256), (2, 8, 8, 256, 512), (1, 20, 36, 64, 64),
+            (3, 6, 10, 64, 96), (8, 64, 64, 64, 128)]
+
+
+@pytest.mark.parametrize("case", S2_CASES, ids=[("n%d_%dx%d_ci%d_co%d" % c) for c in S2_CASES])
+def test_conv4x4_stride2_fwd_dgrad(K, case):
+    """The discriminator's 4x4 / stride 2 / pad 1 convolutions on the halo kernel (2x2 window over the input's parity phases;
+    reference src/models/discriminator.py:15-34) against torch's fp32 CPU convolution on the bf16-rounded operands: forward with
+    bias + LeakyReLU(0.2) and with BatchNorm statistics, data gradient (four parity classes), its accumulation form and the
+    BatchNorm-backward sums of the layer behind it; next to the shared implicit-GEMM kernel on the same operands."""
+    n, h, w, ci, co = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = rb(torch.randn(n, ci, h, w, generator=g))
+    if ci == 8:
+        x[:, 3:] = 0                                                     # an RGB image in 8 physical channels
+    wt = rb(torch.randn(co, ci, 4, 4, generator=g) / math.sqrt(ci * 16))
+    bias = torch.randn(co, generator=g)
+    xr = x.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, wt, bias, stride=2, padding=1)
+    dy = rb(torch.randn(y_ref.shape, generator=g))
+    y_ref.backward(dy)
+    d = K.conv_desc(n, h, w, ci, co, 4, 2, 1)
+    assert (d.ho, d.wo) == (h // 2, w // 2)
+    assert K.conv_frag_ok(d) and K.conv_frag_ok(d, dgrad=True)
+    assert K.conv_frag_preferred(d) == (n * ((h // 2 + 7) // 8) * ((w // 2 + 31) // 32) * ((co + 127) // 128 if co > 64 else 1) >= 200)
+    wf, wfd = pack_s2(K, wt)
+    xd = nhwc(x)
+    R = K.bn_replicas()
+    y = torch.full((n, d.ho, d.wo, co), float("nan"), device="cuda", dtype=bf)
+    st = torch.zeros(R * 2 * co, dtype=torch.float64, device="cuda")
+    K.conv2d_fwd_frag(d, xd, None, wf, bias.cuda(), y, stats=st)
+    close(nchw32(y), y_ref.detach(), "4x4/s2 fwd")
+    tot = st.view(R, 2, co).sum(0).cpu()
+    yd = y_ref.detach().double().permute(0, 2, 3, 1).reshape(-1, co)
+    assert (tot[0] - yd.sum(0)).abs().max().item() <= 1e-4 * yd.abs().sum(0).max().item(), "fused sum"
+    close(tot[1], (yd * yd).sum(0), "fused sum of squares", 1e-3)
+    y_old = torch.empty_like(y)
+    K.conv2d_fwd_bf16(d, xd, wt.permute(0, 2, 3, 1).contiguous().to("cuda", bf), bias.cuda(), None, y_old)
+    close(y.float().cpu(), y_old.float().cpu(), "4x4/s2 fwd vs implicit-GEMM kernel", 2.0 ** -7)
+    y2 = torch.full_like(y, float("nan"))
+    K.conv2d_fwd_frag(d, xd, None, wf, bias.cuda(), y2, act=1, slope=0.2)
+    close(nchw32(y2), F.leaky_relu(y_ref.detach(), 0.2), "4x4/s2 fwd + LeakyReLU")
+    # data gradient: four parity classes of dx
+    dyd = nhwc(dy)
+    dx = torch.full((n, h, w, ci), float("nan"), device="cuda", dtype=bf)
+    K.conv2d_dgrad_frag(d, dyd, wfd, dx)
+    close(nchw32(dx), xr.grad, "4x4/s2 dgrad")
+    base = rb(torch.randn(n, ci, h, w, generator=g))
+    dxa = nhwc(base)
+    K.conv2d_dgrad_frag(d, dyd, wfd, dxa, accumulate=True)
+    close(nchw32(dxa), xr.grad + base, "4x4/s2 dgrad + acc")
+    # BatchNorm-backward sums of the producer in the same launches == the stand-alone reduce on what was stored
+    prev_y = torch.randn(n, h, w, ci, generator=g).to(bf).cuda()
+    mean, rstd = torch.randn(ci, generator=g).cuda() * 0.1, (torch.rand(ci, generator=g) + 0.5).cuda()
+    gamma, beta = (torch.rand(ci, generator=g) + 0.5).cuda(), (torch.randn(ci, generator=g) * 0.3).cuda()
+    t = prev_y.float() * (gamma * rstd) + (beta - mean * (gamma * rstd))
+    z = torch.where(t > 0, t, 0.2 * t).to(bf)
+    bs_ref = torch.zeros(R * 2 * ci, dtype=torch.float64, device="cuda")
+    K.bn_bwd_reduce(dx, z, prev_y, mean, rstd, bs_ref, 1, 0.2)
+    dx3 = torch.full_like(dx, float("nan"))
+    bs = torch.zeros_like(bs_ref)
+    K.conv2d_dgrad_frag(d, dyd, wfd, dx3, bn=(prev_y, mean, rstd, gamma, beta, 1, 0.2, bs))
+    assert torch.equal(dx3, dx)
+    s, s_ref = bs.view(R, 2, ci).sum(0), bs_ref.view(R, 2, ci).sum(0)
+    assert ((s - s_ref).abs() / s_ref.abs().max(dim=1, keepdim=True).values).max().item() < 3e-5

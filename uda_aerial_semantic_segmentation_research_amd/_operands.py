@@ -126,11 +126,11 @@ OPERANDS = {
     "udaseg_pack_frag_batched_bf16": [T("w16", bf16, 1, True), T("wt16", bf16, 1, True), T("packed", bf16, 1),
                                       T("table", i32, "6*entries"), I("entries"), S],
     "udaseg_conv2d_fwd_frag_bf16": [D, T("x", bf16, "(" + _HALF + "*up_ca if up_ca else X)"),
-                                    T("skip", bf16, "n*hi*wi*(ci-up_ca)", True), I("up_ca"), T("wfrag", bf16, "frag(co,ci,kh)"),
+                                    T("skip", bf16, "n*hi*wi*(ci-up_ca)", True), I("up_ca"), T("wfrag", bf16, "(frag(co,4*ci,2) if kh == 4 else frag(co,ci,kh))"),
                                     T("bias", f32, "co", True), T("in_scale", f32, "ci", True), T("in_shift", f32, "ci", True),
                                     I("in_act"), F("in_slope"), T("y", _ACT_BF, "Y"), I("out_f32"), I("act"), F("slope"),
                                     T("stats", f64, "2*co*R", True), S],
-    "udaseg_conv2d_dgrad_frag_bf16": [D, T("dy", bf16, "Y"), T("wfrag_t", bf16, "frag(ci,co,kh)"),
+    "udaseg_conv2d_dgrad_frag_bf16": [D, T("dy", bf16, "Y"), T("wfrag_t", bf16, "(4*frag(ci,co,2) if kh == 4 else frag(ci,co,kh))"),
                                       T("dx", bf16, "n*hi*wi*(split if split else ci)"), T("dx2", bf16, "n*hi*wi*(ci-split)", True),
                                       I("split"), T("prev_y", bf16, "X", True), T("save_mean", f32, "ci", True),
                                       T("save_rstd", f32, "ci", True), T("gamma", f32, "ci", True), T("beta", f32, "ci", True),

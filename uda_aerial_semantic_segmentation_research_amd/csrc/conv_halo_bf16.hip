@@ -19,6 +19,15 @@
 //     normalised activation of a single-consumer layer is then never written to HBM.
 // FLOP per L2 byte rises from 32 to 160-200; the kernels are then bound by HBM (most layers) or by the weight stream from L2
 // (the deep, low-resolution layers).
+//
+// Round 4: the discriminator's 4 x 4 / stride 2 / pad 1 convolutions (reference src/models/discriminator.py:15-34, called
+// src/models/adversarial_trainer.py:87,88,108) run here too, as the KS = 2 window of the same kernel:
+//   forward      y[oy][ox] = sum_{a,b in {0,1}} sum_{p,q in {0,1}} W[2a+p][2b+q] . x[2(oy-1+a)+1+p][2(ox-1+b)+1+q]
+//                -- a stride-1 2 x 2 window (offsets -1, 0) over the four PARITY PHASES of the input, which the staging loop
+//                gathers as 4 ci "virtual" channels (phase-major): the halo of a chunk is de-interleaved by input parity while it
+//                is staged, so every fragment read is the conflict-free stride-1 read of the 3 x 3 kernel;
+//   data grad    the four parity classes of dx are four stride-1 2 x 2 windows over dy (offsets -1, 0 for even input rows /
+//                columns, 0, +1 for odd ones) written with stride 2 into dx: four launches of the same instantiation.
 #include <stdlib.h>
 
 #include "common.h"
@@ -61,6 +70,13 @@ struct HaloArgs {
   int nk16;             // ci / 16
   unsigned x_bytes, x2_bytes, w_bytes, y_bytes, y2_bytes, bnb_bytes;
   unsigned long long* timeline;   // udaseg_debug_set_timeline: per block {entry, first chunk staged, end of K loop, exit} + HW_ID + XCC_ID
+  // KS = 2 launches only (4 x 4 / stride 2 convolutions):
+  int s2;               // forward: the gathered tensor is the REAL input [n][2h][2w][cr]; ci = 4 cr virtual channels (phase-major)
+  int cr, cr_log2;      // real gathered channels (a power of two)
+  int pady, padx;       // window offset of tap 0 along y / x: 1 (rows o - 1, o) or 0 (rows o, o + 1)
+  int out_h, out_w, out_sy, out_oy, out_sx, out_ox;   // produced pixel (oy, ox) is stored at (oy out_sy + out_oy, ox out_sx + out_ox) of [n][out_h][out_w]
+  int ncls;             // 4: the four parity classes of a stride-2 data gradient in ONE launch (class = block index % 4: window offsets,
+  unsigned cls_wbytes;  //    output offsets and the class's fragment packing, cls_wbytes apart, follow from it)
 };
 extern unsigned long long* g_timeline;
 extern int g_timeline_blocks;
@@ -108,6 +124,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_halo_bf16_kernel(const H
     const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
+  int pady = a.pady, padx = a.padx, out_oy = a.out_oy, out_ox = a.out_ox;
+  unsigned wcls = 0;
+  if constexpr (KS == 2) {
+    if (a.ncls > 1) {
+      const int e = bid % a.ncls;
+      bid /= a.ncls;
+      pady = (e >> 1) ? 0 : 1; padx = (e & 1) ? 0 : 1;      // even input rows read output rows (i - 1, i), odd ones (i, i + 1)
+      out_oy = e >> 1; out_ox = e & 1;
+      wcls = (unsigned)e * a.cls_wbytes;
+    }
+  }
   const int cb = bid % a.ncb;
   int t = bid / a.ncb;
   const int tx = t % a.ntx;
@@ -120,6 +147,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_halo_bf16_kernel(const H
   // ---- staging slots: piece = tid + i * NT -> (halo pixel, octet)
   const int oct = tid % C::OCT;
   unsigned voff[C::NI], voff2[C::NI];
+  unsigned s2ok[KS == 2 ? C::NI : 1];
   unsigned okbits = 0;
   const bool UPC = a.up_ca > 0;
   const int cx = UPC ? a.up_ca : a.ci, cx2 = a.ci - a.up_ca;
@@ -128,8 +156,25 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_halo_bf16_kernel(const H
     const int piece = tid + i * C::NT;
     const int pix = piece / C::OCT;
     const int hy = pix / C::HWD, hx = pix - hy * C::HWD;
-    const int iy = y0 + hy - C::PAD, ix = x0 + hx - C::PAD;
-    const bool ok = piece < C::NPIECE && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+    const int iy = y0 + hy - (KS == 2 ? pady : C::PAD), ix = x0 + hx - (KS == 2 ? padx : C::PAD);
+    bool ok = piece < C::NPIECE && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+    if constexpr (KS == 2) {
+      if (a.s2) {
+        // phase (p, q) of virtual pixel (iy, ix) is the real pixel (2 iy + 1 + p, 2 ix + 1 + q): the offset of phase (0, 0) and one
+        // validity bit per phase (virtual row -1 is real row 0 for p = 1; virtual row h - 1 is past the end for p = 1)
+        const int ry = 2 * iy + 1, rx = 2 * ix + 1, HR2 = 2 * H, WR2 = 2 * W;
+        unsigned m = 0;
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph)
+          m |= (piece < C::NPIECE && (unsigned)(ry + (ph >> 1)) < (unsigned)HR2 && (unsigned)(rx + (ph & 1)) < (unsigned)WR2 ? 1u : 0u) << ph;
+        s2ok[i] = m;
+        voff[i] = (unsigned)((((img * HR2 + ry) * WR2 + rx) * a.cr) * 2);      // may wrap for ry = -1: only used with its phase offset added
+        voff2[i] = 0x80000000u;
+        ok = m != 0;
+        okbits |= (ok ? 1u : 0u) << i;
+        continue;
+      }
+    }
     okbits |= (ok ? 1u : 0u) << i;
     if (UPC) {
       voff[i] = ok ? (unsigned)((((img * (H >> 1) + (iy >> 1)) * (W >> 1) + (ix >> 1)) * cx + oct * 8) * 2) : 0x80000000u;
@@ -163,7 +208,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_halo_bf16_kernel(const H
     const int dx = g / (CK / 16), k = g - dx * (CK / 16);
     int nbq = cb * WN + wq;
     const bool live = q < WN * C::FPC && nbq < nblocks32;
-    wvoff[i] = live ? (nbq * frag_per_nb + (dx * a.nk16 + k) * KS + dy) * 1024 : -1;
+    wvoff[i] = live ? (int)wcls + (nbq * frag_per_nb + (dx * a.nk16 + k) * KS + dy) * 1024 : -1;
   }
   char* wlds = smem + C::LDS_HALO;
   const int wrd = (wn * C::FPC) * 1024 + lane * 16;     // this wave's fragments in the weight region
@@ -187,6 +232,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_halo_bf16_kernel(const H
     // channel tail (gathered channels not a multiple of the chunk, e.g. the 24-channel logits gradient): octets past the last
     // channel read zeros instead of the next pixel (their weights are zero, but 0 x NaN is not)
     const unsigned kill = (cbeg + oct * 8 < a.ci) ? 0u : 0x80000000u;
+    if constexpr (KS == 2) {
+      if (a.s2) {
+        // this thread's octet of the chunk: virtual channel -> (phase, real channel); one phase per thread per chunk
+        const int vch = cbeg + oct * 8, ph = vch >> a.cr_log2, cc = vch - (ph << a.cr_log2);
+        const unsigned poff = (unsigned)((((ph >> 1) * 2 * W + (ph & 1)) * a.cr + cc) * 2);
+#pragma unroll
+        for (int i = 0; i < C::NI; ++i)
+          stage[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)((((s2ok[i] >> ph) & 1u) ? voff[i] + poff : 0x80000000u) | kill), 0, 0);
+        return;
+      }
+    }
     if (second) {
 #pragma unroll
       for (int i = 0; i < C::NI; ++i) stage[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x2, (int)(voff2[i] | kill), soff, 0);
@@ -314,7 +370,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_halo_bf16_kernel(const H
   for (int r = 0; r < RPW; ++r) {
     const int oy = y0 + (wm * RPW + r) * C::RB + ly, ox = x0 + lx;
     const bool pv = wave_live && oy < H && ox < W;
-    const unsigned pixoff = (unsigned)((img * H + oy) * W + ox);
+    const unsigned pixoff = KS == 2 ? (unsigned)((img * a.out_h + oy * a.out_sy + out_oy) * a.out_w + ox * a.out_sx + out_ox)
+                                    : (unsigned)((img * H + oy) * W + ox);
     unsigned dw[8];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -979,10 +1036,52 @@ __global__ __launch_bounds__(512, 2) void conv1x1_gemm_bf16_kernel(const HaloArg
 // directions: the forward reads the OHWI weights (N = co, K = ci, tap = dy * KS + dx), the data gradient reads the dgrad
 // packing [ci][taps][co] (N = ci, K = co) with the window flipped (tap = KS*KS - 1 - (dy * KS + dx)).
 // table row (int32 x 6): {mode (0 forward / 1 data gradient), src element offset, dst element offset, N, K, KS}
+// 4 x 4 / stride 2 convolutions (KS = 4 in the row; packed as the 2 x 2 window the kernel runs, see the head of this file):
+//   mode 2      forward: N = co, K = ci; packed K' = 4 K virtual channels, phase-major: W'[n][(a, b)][(2p + q) K + c] = W[n][2a + p][2b + q][c]
+//   mode 3 + e  data gradient of input parity class e = 2 ey + ex, from the dgrad packing wt[ci][16][co] (N = ci, K = co):
+//               W'[n][(a, b)][k] = wt[n][ky][kx][k],  ky = (ey ? 2 : 3) - 2a,  kx = (ex ? 2 : 3) - 2b
 __global__ void pack_frag_batched_bf16_kernel(const __bf16* __restrict__ w16, const __bf16* __restrict__ wt16,
                                               __bf16* __restrict__ packed, const int* __restrict__ table) {
   const int* e = table + 6 * blockIdx.y;
-  const int mode = e[0], N = e[3], K = e[4], KS = e[5];
+  const int mode = e[0], N = e[3];
+  if (mode >= 2) {
+    const int Kr = e[4];                               // real K of the source
+    const __bf16* src = (mode == 2 ? w16 : wt16) + e[1];
+    __bf16* dst = packed + e[2];
+    const int Kv = mode == 2 ? 4 * Kr : Kr;            // K of the packed 2 x 2 window
+    const int nb = (N + 31) >> 5, nk16 = (Kv + 15) >> 4;
+    const int ey = (mode - 3) >> 1, ex = (mode - 3) & 1;
+    const long long total = (long long)nb * 2 * nk16 * 2 * 64;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+      const int lane = (int)(i & 63);
+      long long f = i >> 6;
+      const int ta = (int)(f % 2);                     // window row (dy)
+      f /= 2;
+      const int kk = (int)(f % nk16);
+      f /= nk16;
+      const int tb = (int)(f % 2);                     // window column (dx)
+      const int b = (int)(f / 2);
+      const int n = b * 32 + (lane & 31), k0 = kk * 16 + 8 * (lane >> 5);
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (n < N && k0 < Kv) {
+        int ky, kx, c0;
+        if (mode == 2) {
+          const int ph = k0 / Kr;
+          c0 = k0 - ph * Kr;
+          ky = 2 * ta + (ph >> 1);
+          kx = 2 * tb + (ph & 1);
+        } else {
+          c0 = k0;
+          ky = (ey ? 2 : 3) - 2 * ta;
+          kx = (ex ? 2 : 3) - 2 * tb;
+        }
+        v = *reinterpret_cast<const u32x4*>(src + ((size_t)n * 16 + ky * 4 + kx) * Kr + c0);
+      }
+      *reinterpret_cast<u32x4*>(dst + i * 8) = v;
+    }
+    return;
+  }
+  const int K = e[4], KS = e[5];
   const __bf16* src = (mode ? wt16 : w16) + e[1];
   __bf16* dst = packed + e[2];
   const int T = KS * KS, nb = (N + 31) >> 5, nk16 = (K + 15) >> 4;
@@ -1065,7 +1164,7 @@ static int launch_halo_t(HaloArgs a, hipStream_t s, double flops) {
   a.nty = cdiv(a.h, C::TH);
   a.ncb = cdiv(a.co, 32 * WN);
   a.nk16 = (a.ci + 15) / 16;
-  const long long blocks = (long long)a.n * a.nty * a.ntx * a.ncb;
+  const long long blocks = (long long)a.n * a.nty * a.ntx * a.ncb * (KS == 2 && a.ncls > 1 ? a.ncls : 1);
   if (blocks <= 0) return UDASEG_OK;
   a.timeline = (g_timeline && blocks <= g_timeline_blocks) ? g_timeline : nullptr;
   a.sscr = nullptr;
@@ -1226,6 +1325,15 @@ bool halo_applicable(const udaseg_conv_desc* d, int gathered, int produced, int 
   static int off = -1;   // UDASEG_NO_HALO=1: keep every layer on the shared implicit-GEMM source (A/B, cross-check)
   if (off < 0) off = getenv("UDASEG_NO_HALO") != nullptr ? 1 : 0;
   if (off) return false;
+  if (d->kh == 4 && d->kw == 4 && d->stride == 2 && d->pad == 1) {
+    // the discriminator's convolutions, as 2 x 2 windows over parity phases (forward) / parity classes (data gradient)
+    static int s2off = -1;   // UDASEG_NO_HALO_S2=1: they stay on the shared implicit-GEMM source (A/B)
+    if (s2off < 0) s2off = getenv("UDASEG_NO_HALO_S2") != nullptr ? 1 : 0;
+    if (s2off || up_ca != 0 || d->hi % 2 != 0 || d->wi % 2 != 0 || d->ho * 2 != d->hi || d->wo * 2 != d->wi) return false;
+    if (d->ci % 8 != 0 || d->co % 8 != 0 || (d->ci & (d->ci - 1)) != 0) return false;      // real input channels: a power of two
+    const long long pin = (long long)d->n * d->hi * d->wi, pout = (long long)d->n * d->ho * d->wo;
+    return pin * d->ci * 2 < (1LL << 31) && pout * d->co * 4 < (1LL << 31);
+  }
   if (d->kh != d->kw || (d->kh != 3 && d->kh != 1) || d->stride != 1 || d->pad != d->kh / 2) return false;
   if (gathered % 8 != 0 || produced % 8 != 0) return false;
   if (up_ca > 0 && (up_ca % 16 != 0 || (gathered - up_ca) % 16 != 0 || d->hi % 2 != 0 || d->wi % 2 != 0)) return false;
@@ -1248,6 +1356,15 @@ bool halo_applicable(const udaseg_conv_desc* d, int gathered, int produced, int 
 //     192^2: 246 -> 126 us; the old kernel's one-K-tile launches), slower or equal in the forward direction.
 static int halo_choice(int ks, int h, int w, int n, int gathered, int produced, bool dgrad) {
   const int ov = halo_cfg_override();
+  if (ks == 2 || ks == 4) {
+    // 4 x 4 / stride 2 (2 x 2 window; h, w: the convolution's INPUT extent): where the launch has a block per CU.  Per call, us,
+    // this kernel / the shared source (bench.py --layer-table, cfg 3, profiles/r04_halo_s2.txt): forward 64 -> 128 at 256^2 67 / 79,
+    // 128 -> 256 at 128^2 55 / 73, 256 -> 512 at 64^2 79 / 72 (128 blocks); data gradient (four parity classes in one launch)
+    // 73 / 88, 58 / 75, 54 / 71
+    const long long blocks = (long long)n * cdiv(h / 2, 8) * cdiv(w / 2, 32) * cdiv(produced, produced <= 64 ? 64 : 128) * (dgrad ? 4 : 1);
+    if (ov == 0 && blocks < 200) return 0;
+    return produced <= 64 ? 2 : 3;
+  }
   if (ov > 0) return ov > 6 ? 3 : ov;
   const long long tiles = (long long)n * cdiv(h, 8) * cdiv(w, 32);
   if (ks == 1) {
@@ -1278,6 +1395,23 @@ static int halo_choice(int ks, int h, int w, int n, int gathered, int produced, 
 }
 
 int launch_halo(const udaseg_conv_desc* d, HaloArgs a, hipStream_t s, bool dgrad) {
+  if (d->kh == 4) {
+    // one 2 x 2-window launch of a 4 x 4 / stride 2 convolution (the forward, or one parity class of the data gradient); a.ci / a.co
+    // are the launch's (virtual) channel counts; the FLOPs of the whole convolution are booked by the caller
+    const double fl = 2.0 * (double)a.n * a.h * a.w * (double)a.co * (double)a.ci * 4.0 * (a.ncls > 1 ? a.ncls : 1);
+    if (a.ci % 32 != 0) { set_error("conv_halo (4x4 / stride 2): gathered channels must be a multiple of 32"); return UDASEG_E_UNSUPPORTED; }
+    static int ck64 = -1;       // UDASEG_HALO_S2_CK = 32 | 64 (A/B): channels per staged chunk
+    if (ck64 < 0) {
+      const char* e = getenv("UDASEG_HALO_S2_CK");
+      ck64 = (e && atoi(e) == 32) ? 0 : 1;
+    }
+    if (ck64 && a.ci % 64 == 0) {
+      if (a.co <= 64) return launch_halo_t<2, 64, 2, 2, 4, 32>(a, s, fl);
+      return launch_halo_t<2, 64, 2, 4, 4, 32>(a, s, fl);
+    }
+    if (a.co <= 64) return launch_halo_t<2, 32, 2, 2, 4, 32>(a, s, fl);
+    return launch_halo_t<2, 32, 2, 4, 4, 32>(a, s, fl);
+  }
   const double flops = 2.0 * (double)a.n * a.h * a.w * (double)a.co * (double)a.ci * d->kh * d->kw;
   // chunk: 32 channels (64 for the 1x1 kernels) when that divides the gathered channels and both sources of a fused input
   int ck = 32;
@@ -1347,9 +1481,13 @@ extern "C" int udaseg_conv_frag_preferred(const udaseg_conv_desc* d, int dgrad, 
 
 static int frag_common(const udaseg_conv_desc* d, HaloArgs& a, const char* who) {
   UDASEG_CHECK_ARG(d != nullptr, "%s: conv desc is NULL", who);
-  UDASEG_CHECK_ARG(d->n > 0 && d->hi > 0 && d->wi > 0 && d->ho == d->hi && d->wo == d->wi && d->ci > 0 && d->co > 0,
-                   "%s: stride-1 'same' convolutions only (hi=%d wi=%d ho=%d wo=%d)", who, d->hi, d->wi, d->ho, d->wo);
-  a.n = d->n; a.h = d->hi; a.w = d->wi;
+  const bool s2 = d->kh == 4 && d->stride == 2;
+  UDASEG_CHECK_ARG(d->n > 0 && d->hi > 0 && d->wi > 0 && d->ci > 0 && d->co > 0 &&
+                       (s2 ? (d->ho * 2 == d->hi && d->wo * 2 == d->wi) : (d->ho == d->hi && d->wo == d->wi)),
+                   "%s: stride-1 'same' convolutions or 4x4 / stride 2 / pad 1 (hi=%d wi=%d ho=%d wo=%d)", who, d->hi, d->wi, d->ho, d->wo);
+  a.n = d->n; a.h = d->ho; a.w = d->wo;
+  a.pady = a.padx = 1;
+  a.out_h = d->ho; a.out_w = d->wo; a.out_sy = a.out_sx = 1; a.out_oy = a.out_ox = 0;
   return UDASEG_OK;
 }
 
@@ -1369,11 +1507,23 @@ extern "C" int udaseg_conv2d_fwd_frag_bf16(const udaseg_conv_desc* d, const void
     set_error("conv2d_fwd_frag_bf16: geometry not supported (ask udaseg_conv_frag_ok first)");
     return UDASEG_E_UNSUPPORTED;
   }
-  const long long px = (long long)d->n * d->hi * d->wi;
+  const long long px = (long long)d->n * d->ho * d->wo;
   a.x = x; a.x2 = skip; a.wf = wfrag; a.bias = bias; a.y = y;
   a.ci = d->ci; a.co = d->co; a.up_ca = up_ca;
   a.out_f32 = out_f32; a.act = act; a.slope = slope; a.stats = stats;
   a.in_scale = in_scale; a.in_shift = in_shift; a.in_act = in_act; a.in_slope = in_slope;
+  if (d->kh == 4) {
+    UDASEG_CHECK_ARG(in_scale == nullptr, "conv2d_fwd_frag_bf16: no input transform in front of a 4x4 / stride 2 convolution");
+    a.s2 = 1; a.cr = d->ci; a.cr_log2 = __builtin_ctz((unsigned)d->ci); a.ci = 4 * d->ci;
+    a.x_bytes = (unsigned)((long long)d->n * d->hi * d->wi * d->ci * 2);
+    a.w_bytes = (unsigned)(udaseg_frag_elems(d->co, 4 * d->ci, 2) * 2);
+    a.y_bytes = (unsigned)(px * d->co * (out_f32 ? 4 : 2));
+    hipStream_t st = as_stream(stream);
+    prof_begin(0, st);
+    rc = launch_halo(d, a, st, false);
+    prof_end(0, st, udaseg_conv_flops(d), 0, d);
+    return rc;
+  }
   a.x_bytes = (unsigned)(up_ca > 0 ? (long long)d->n * (d->hi / 2) * (d->wi / 2) * up_ca * 2 : px * d->ci * 2);
   a.x2_bytes = (unsigned)(up_ca > 0 ? px * (d->ci - up_ca) * 2 : 0);
   a.w_bytes = (unsigned)(udaseg_frag_elems(d->co, d->ci, d->kh) * 2);
@@ -1408,6 +1558,28 @@ extern "C" int udaseg_conv2d_dgrad_frag_bf16(const udaseg_conv_desc* d, const vo
   a.ci = d->co; a.co = d->ci;        // the launch gathers dy (co channels) and produces dx (ci channels)
   a.act = UDASEG_ACT_NONE;
   a.accumulate = accumulate ? 1 : 0;
+  if (d->kh == 4) {
+    // four parity classes of dx, each a 2 x 2 window over dy written with stride 2; their fragment packings follow one another
+    UDASEG_CHECK_ARG(split == 0, "conv2d_dgrad_frag_bf16: no split destination behind a 4x4 / stride 2 convolution");
+    const long long pout = (long long)d->n * d->ho * d->wo;
+    a.x_bytes = (unsigned)(pout * d->co * 2);
+    a.y_bytes = (unsigned)(px * d->ci * 2);
+    const long long fe = udaseg_frag_elems(d->ci, d->co, 2);
+    a.w_bytes = (unsigned)(4 * fe * 2);
+    a.out_h = d->hi; a.out_w = d->wi; a.out_sy = a.out_sx = 2;
+    a.ncls = 4; a.cls_wbytes = (unsigned)(fe * 2);
+    if (prev_y) {
+      a.bnb_y = prev_y; a.bnb_mean = save_mean; a.bnb_rstd = save_rstd; a.bnb_gamma = gamma; a.bnb_beta = beta;
+      a.bnb_act = bn_act; a.bnb_slope = bn_slope; a.stats = bsums;
+      a.bnb_bytes = (unsigned)(px * d->ci * 2);
+    }
+    hipStream_t st = as_stream(stream);
+    prof_begin(0, st);
+    rc = launch_halo(d, a, st, true);      // ONE launch, class = block index % 4 (four launches of a quarter each left the deep layers
+                                           // with 64 blocks at a time: 256 -> 512 at 64^2 170 us against 71 for the shared source)
+    prof_end(0, st, udaseg_conv_flops(d), 1, d);
+    return rc;
+  }
   a.x_bytes = (unsigned)(px * d->co * 2);
   a.w_bytes = (unsigned)(udaseg_frag_elems(d->ci, d->co, d->kh) * 2);
   a.y_bytes = (unsigned)(px * (split > 0 ? split : d->ci) * 2);

@@ -294,6 +294,21 @@ class ArenaModule(nn.Module):
                         ent[2], ent[3] = foff, nd
                         foff += nd
                     self._frag_off[id(m)] = tuple(ent)
+                elif (isinstance(m, ConvP) and not f32 and m.k == 4 and m.stride == 2 and m.pad == 1
+                      and m.cin_p & (m.cin_p - 1) == 0):
+                    # the discriminator's 4x4 / stride 2 convolutions as 2x2 windows: the forward over 4 cin phase-major "virtual"
+                    # channels (pack mode 2), the data gradient as four parity classes (modes 3..6), see csrc/conv_halo_bf16.hip
+                    nf = K.frag_elems(m.cout_p, 4 * m.cin_p, 2)
+                    frows.append([2, self._idx[(id(m), "weight")][0], foff, m.cout_p, m.cin_p, 4])
+                    ent = [foff, nf, None, 0]
+                    foff += nf
+                    if m.needs_dgrad:
+                        fe = K.frag_elems(m.cin_p, m.cout_p, 2)
+                        for e in range(4):
+                            brows.append([3 + e, self._wt_off[id(m)], foff + e * fe, m.cin_p, m.cout_p, 4])
+                        ent[2], ent[3] = foff, 4 * fe
+                        foff += 4 * fe
+                    self._frag_off[id(m)] = tuple(ent)
             if frows:
                 self._frag_arena = torch.empty(foff, device=device, dtype=torch.bfloat16)
                 self._frag_fwd_table = torch.tensor(frows, dtype=torch.int32, device=device)
