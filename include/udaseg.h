@@ -345,7 +345,12 @@ int udaseg_pack_dgrad_batched_bf16(const float* arena, void* packed, const int* 
  *      network in one launch: table[i] = {mode (0 forward from w16 / 1 data gradient from wt16), source element offset,
  *      destination element offset, N, K, ks} (int32 x 6, device memory). ---- */
 int64_t udaseg_frag_elems(int n_out, int k_in, int ks);
-/* Optional caller-owned f64 scratch (bound to the current device; the caller ZEROES it once, the library leaves it zeroed after
+/* STREAM CONTRACT of the two per-device scratch bindings (udaseg_set_workspace, udaseg_set_stats_scratch): they are keyed by
+ * DEVICE, not by stream.  Launches that use them -- K-sliced / split partial results, and the statistics of launches with more
+ * than 1024 blocks -- must all be issued on ONE compute stream per device (or be ordered by the caller): two such launches on
+ * different streams of one device would add into the same scratch and the first fold would take the second's partials.  The
+ * weight-gradient side stream of the Python host (engine.py) only issues launches that use neither.
+ * Optional caller-owned f64 scratch (bound to the current device; the caller ZEROES it once, the library leaves it zeroed after
  * every use): launches of more than 1024 blocks put their per-channel statistics there (256 replicas) and a fold kernel adds
  * them into `stats` -- otherwise hundreds of same-address f64 atomics per accumulator bound the low-channel full-resolution
  * layers.  Needs 256 * 2 * co * 8 bytes for a layer with co output channels (256 KiB covers co <= 64); NULL unbinds. */
@@ -366,10 +371,11 @@ int udaseg_bn_bwd_apply_recompute_bf16(const void* dz, const void* y, const floa
                                        const float* save_mean, const float* save_rstd, const float* gamma, const double* bsums,
                                        void* dy, float* dgamma, float* dbeta, int64_t pixels, int c, int act, float slope,
                                        void* stream);
-/* Weight gradient of a stride-1 3x3 / pad 1 convolution whose channel counts are multiples of 64, bf16 operands, fp32 dW
- * ACCUMULATED onto (caller-zeroed arena): a block owns a 64 x 64 channel block of all nine taps and walks pixel tiles, x halo
- * and dy tile staged once per tile; few long-lived blocks, one set of atomics per block.  skip / up_ca: the two sources of a
- * fused decoder input in ONE launch.  loss.backward() at reference src/models/train.py:343. */
+/* Weight gradient of a stride-1 3x3 / pad 1 convolution, bf16 operands, fp32 dW ACCUMULATED onto (caller-zeroed arena): a block
+ * owns a 64 x 64 (or 32 x 64, 32 x 32) channel block of all nine taps and walks pixel tiles, x halo and dy tile staged once per
+ * tile; few long-lived blocks, one set of atomics per wave (round 4: csrc/conv_wgrad_halo2.hip, shared with the fp32 split form
+ * below; channel counts multiples of 32, images >= 32 pixels wide or 16-pixel-wide with 64-multiples).  skip / up_ca: the two
+ * sources of a fused decoder input in ONE launch.  loss.backward() at reference src/models/train.py:343. */
 int udaseg_conv2d_wgrad_halo_bf16_ok(const udaseg_conv_desc* d, int up_ca);
 int udaseg_conv2d_wgrad_halo_bf16(const udaseg_conv_desc* d, const void* x, const void* skip, int up_ca, const void* dy, float* dw,
                                   void* stream);
@@ -384,7 +390,14 @@ int udaseg_conv_frag_preferred(const udaseg_conv_desc* d, int dgrad, int up_ca);
 /* y = act(conv(X, w) + bias) (+ BatchNorm statistics of conv(X, w) + bias into stats, as udaseg_conv2d_fwd_bnstats).
  * X = x [n][h][w][ci], or with up_ca > 0 the virtual cat([nearest_x2(x [n][h/2][w/2][up_ca]), skip [n][h][w][ci - up_ca]]), or with
  * in_scale / in_shift (fp32 [ci]) the producer's BatchNorm + activation applied on the fly: X = in_act(x * in_scale + in_shift)
- * rounded to bf16 -- the normalised activation of a single-consumer layer never reaches HBM.  out_f32: y is fp32 (logits). */
+ * rounded to bf16 -- the normalised activation of a single-consumer layer never reaches HBM.  out_f32: y is fp32 (logits).
+ * Round 4: (1) 1x1 / stride-1 launches that are small GEMMs (ci, co multiples of 64 and >= 128, at most 73728 pixels: r50's
+ * bottleneck projections from 96^2 down, reference smp.Unet("resnet50"), src/test_system.py:90-95) run on conv1x1_gemm_bf16_kernel
+ * (LDS-DMA ring, persistent blocks), same epilogue options; (2) the descriptor may be the discriminator's 4x4 / stride 2 / pad 1
+ * convolution (reference src/models/discriminator.py:15-34): x is [n][hi][wi][ci] with ci a power of two, y [n][hi/2][wi/2][co],
+ * wfrag the 2x2-window packing over the input's four parity phases (table row mode 2: udaseg_frag_elems(co, 4 * ci, 2) elements);
+ * no skip / in_scale there.  The data gradient takes the same descriptor with wfrag_t = the four parity-class packings (modes
+ * 3, 4, 5, 6 = input row / column parity (0,0), (0,1), (1,0), (1,1)), udaseg_frag_elems(ci, co, 2) elements each, one after the other. */
 int udaseg_conv2d_fwd_frag_bf16(const udaseg_conv_desc* d, const void* x, const void* skip, int up_ca, const void* wfrag,
                                 const float* bias, const float* in_scale, const float* in_shift, int in_act, float in_slope,
                                 void* y, int out_f32, int act, float slope, double* stats, void* stream);
@@ -419,9 +432,13 @@ int udaseg_conv2d_dgrad_f32x3(const udaseg_conv_desc* d, const float* dy, const 
                               const float* prev_y, const float* save_mean, const float* save_rstd, const float* gamma,
                               const float* beta, int bn_act, float bn_slope, double* bsums, int accumulate, void* stream);
 
-/* dW[co][9][ci] += weight gradient of a stride-1 3x3 layer with channel counts that are multiples of 64, fp32 x / dy with the
- * same three-term split (csrc/conv_wgrad.hip: conv_wgrad_halo_f32x3_kernel; the blocking of udaseg_conv2d_wgrad_halo_bf16).
- * up_ca > 0: x is the half-resolution tensor of a fused decoder input, skip the other source. */
+/* dW[co][9][ci] += weight gradient of a stride-1 3x3 layer, fp32 x / dy with the same three-term split (round 4:
+ * csrc/conv_wgrad_halo2.hip, conv_wgrad_h2_kernel -- conflict-free 32-channel LDS sub-planes, one x fragment shared by the three
+ * taps of a kernel column, double-buffered 2-row tiles; UDASEG_WGRAD_V1=1 keeps round 3's conv_wgrad_halo_f32x3_kernel).  Channel
+ * blocks: 64 x 64, 32 produced x 64 gathered, 32 x 32 (co % 32 == 0 and ci % 32 == 0); images at least 32 pixels wide, or 16-pixel-
+ * wide ones with 64-multiples (8 x 16 tiles).  Reference: loss.backward(), src/models/train.py:343.
+ * up_ca > 0: x is the half-resolution tensor of a fused decoder input, skip the other source (up_ca a multiple of the gathered
+ * channel block). */
 int udaseg_conv2d_wgrad_halo_f32x3_ok(const udaseg_conv_desc* d, int up_ca);
 int udaseg_conv2d_wgrad_halo_f32x3(const udaseg_conv_desc* d, const float* x, const float* skip, int up_ca, const float* dy,
                                    float* dw, void* stream);

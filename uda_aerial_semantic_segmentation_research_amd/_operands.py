@@ -233,11 +233,11 @@ OPERANDS = {
     "udaseg_focal_bwd": [T("logits", f32, "pixels*ldc"), T("target", i64, "pixels"), T("class_weights", f32, "classes", True),
                          F("alpha"), F("gamma"), T("grad_out", f32, 1, True), F("weight"), I("pixels"), I("classes"), I("ldc"),
                          T("dlogits", f32, "pixels*ldc"), I("accumulate"), S],
-    "udaseg_consistency_fwd": [T("z1", f32, "batch*pixels*ldc"), T("z2", f32, "batch*pixels*ldc"), F("temperature"), I("batch"),
+    "udaseg_consistency_fwd": [T("z1", f32, "pixels*ldc"), T("z2", f32, "pixels*ldc"), F("temperature"), I("batch"),
                                I("pixels"), I("classes"), I("ldc"), T("partials", f64, "seg_partials()"), T("loss", f32, 1), S],
-    "udaseg_consistency_bwd": [T("z1", f32, "batch*pixels*ldc"), T("z2", f32, "batch*pixels*ldc"), F("temperature"),
+    "udaseg_consistency_bwd": [T("z1", f32, "pixels*ldc"), T("z2", f32, "pixels*ldc"), F("temperature"),
                                T("grad_out", f32, 1, True), F("weight"), I("batch"), I("pixels"), I("classes"), I("ldc"),
-                               T("d1", f32, "batch*pixels*ldc", True), T("d2", f32, "batch*pixels*ldc", True), I("accumulate"), S],
+                               T("d1", f32, "pixels*ldc", True), T("d2", f32, "pixels*ldc", True), I("accumulate"), S],
     # ---- discriminator tail
     "udaseg_gap_linear_sigmoid_fwd": [T("z", f32, "n*hw*c"), T("w", f32, "c"), T("b", f32, 1), T("partial", f32, "n*gap_splits(hw)*c"),
                                       T("pooled", f32, "n*c"), T("p", f32, "n"), I("n"), I("hw"), I("c"), S],

@@ -1,5 +1,6 @@
 // Library-level entry points: version, thread-local error text, device probe, live launch timing.
 #include <string.h>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -54,10 +55,23 @@ static std::vector<KRec> g_krecs[PROF_MAX_KERNELS];
 static char g_knames_dyn[PROF_MAX_KERNELS][160];
 static int g_nkernels = PROF_NKERNELS;
 
+// Launches come from the compute and the weight-gradient streams, possibly from different host threads: registration is
+// serialised (callers cache the id in a function-local static; a racing first call of two threads registers the name once and
+// both get the same id).  A full table is reported, not silently aliased: the bench's per-kernel figures must not mix symbols.
+static std::mutex g_kprof_mutex;
 int kprof_id(const char* name) {
+  std::lock_guard<std::mutex> lock(g_kprof_mutex);
   for (int k = PROF_NKERNELS; k < g_nkernels; ++k)
     if (strcmp(g_knames_dyn[k], name) == 0) return k;
-  if (g_nkernels >= PROF_MAX_KERNELS) return PROF_NKERNELS;   // table full: lump into the first dynamic entry
+  if (g_nkernels >= PROF_MAX_KERNELS) {
+    static bool warned = false;
+    if (!warned) {
+      fprintf(stderr, "libudaseg_hip: kernel-timing table full (%d symbols); '%s' and later symbols are booked under '%s'\n",
+              PROF_MAX_KERNELS, name, g_knames_dyn[PROF_NKERNELS]);
+      warned = true;
+    }
+    return PROF_NKERNELS;
+  }
   strncpy(g_knames_dyn[g_nkernels], name, sizeof(g_knames_dyn[0]) - 1);
   return g_nkernels++;
 }

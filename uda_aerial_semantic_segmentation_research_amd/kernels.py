@@ -587,11 +587,26 @@ def bce_logits_target_bwd(x, target, weight, grad_out, dx, accumulate=False, st=
           "bce_logits_target_bwd")
 
 
+def _storage_order(t, who):
+    """A flat view of ``t`` in the order of its storage: ``t`` itself when contiguous, the underlying run of elements when ``t`` is a
+    dense permutation (an [N,C,H,W]-shaped view of an NHWC buffer) -- an element-wise kernel does not care about the order."""
+    if t.is_contiguous():
+        return t
+    st = sorted(zip(t.stride(), t.shape), reverse=True)
+    run = 1
+    for stride, size in reversed(st):
+        if size != 1 and stride != run:
+            raise ValueError(f"{who}: tensor must be dense (contiguous or a permutation of a contiguous tensor), strides {t.stride()}")
+        run *= size
+    return t.as_strided((t.numel(),), (1,), t.storage_offset())
+
+
 def scale(x, alpha, out=None, st=None):
-    """out = alpha * x (dense fp32)."""
+    """out = alpha * x (fp32; x dense in any dimension order, out with the same strides)."""
     out = torch.empty_like(x) if out is None else out
-    check(ops.udaseg_scale_f32(x, out, x.numel(), float(alpha),
-                                        st), "scale_f32")
+    if out.stride() != x.stride() or out.shape != x.shape:
+        raise ValueError("scale: out must have x's shape and strides")
+    check(ops.udaseg_scale_f32(_storage_order(x, "scale"), _storage_order(out, "scale"), x.numel(), float(alpha), st), "scale_f32")
     return out
 
 
