@@ -434,7 +434,7 @@ int udaseg_conv2d_dgrad_f32x3(const udaseg_conv_desc* d, const float* dy, const 
 
 /* dW[co][9][ci] += weight gradient of a stride-1 3x3 layer, fp32 x / dy with the same three-term split (round 4:
  * csrc/conv_wgrad_halo2.hip, conv_wgrad_h2_kernel -- conflict-free 32-channel LDS sub-planes, one x fragment shared by the three
- * taps of a kernel column, double-buffered 2-row tiles; UDASEG_WGRAD_V1=1 keeps round 3's conv_wgrad_halo_f32x3_kernel).  Channel
+ * taps of a kernel column, double-buffered 2-row tiles).  Channel
  * blocks: 64 x 64, 32 produced x 64 gathered, 32 x 32 (co % 32 == 0 and ci % 32 == 0); images at least 32 pixels wide, or 16-pixel-
  * wide ones with 64-multiples (8 x 16 tiles).  Reference: loss.backward(), src/models/train.py:343.
  * up_ca > 0: x is the half-resolution tensor of a fused decoder input, skip the other source (up_ca a multiple of the gathered

@@ -639,415 +639,9 @@ static int launch_wgrad(WgradArgs a, int accumulate, hipStream_t s, bool bf16 = 
 }
 
 
-// ------------------------------------------------------------------------------------------- halo weight gradient (bf16)
-// The per-tap split-K kernel above gathers every x row nine times (once per tap tile) and every dy row once per channel
-// tile, from blocks on eight different XCDs: at bf16 rates its launches are bound by that traffic and by latency (0.10
-// matrix-pipe busy, profiles/r03_bf16_cfg3_pmc_*.json) and they occupy the whole chip while the main stream's kernels wait.
-// Here a block owns a 64 x 64 (co, ci) block of ALL NINE taps and walks 8 x 32 pixel tiles: the x halo (10 x 34) and the dy
-// tile are staged once per tile, the nine taps are nine shifted transposed reads of the halo, 9 x 16 accumulator registers
-// per wave (one wave per SIMD, 512 registers available), next tile prefetched into registers during the MFMAs.  The partial
-// 64 x 9 x 64 tile leaves with fp32 atomics ONCE per block: few, long-lived blocks (default 96) keep that volume small
-// (blocks x 147 KB at ~1.3 TB/s) and leave most CUs to whatever else is running -- weight gradients run beside the main
-// stream's chain.  Stride-1 3x3 / pad 1 layers whose channel counts are multiples of 64 (both sources of a fused decoder
-// input included: the source is a block-uniform choice).
-struct WgradHaloArgs {
-  const void* x;      // [n][h][w][cx] bf16, or the half-resolution a [n][h/2][w/2][up_ca] of a fused decoder input
-  const void* x2;     // fused decoder input: the skip tensor [n][h][w][ci - up_ca]
-  const void* dy;     // [n][h][w][co]
-  float* dw;          // [co][9][ci] fp32, accumulated onto
-  int n, h, w, ci, co, up_ca;
-  int ntx, nty, ntiles, ncib, pairs, P;
-  unsigned x_bytes, x2_bytes, dy_bytes;
-};
-
-constexpr int WH_LD = 96;                 // elements per LDS pixel row: 64 channels + 32 pad (192 B: four consecutive rows of a
-                                          // transposed read fall on four different bank quarters)
-constexpr int WH_HR = 10, WH_HWD = 34, WH_TP = 256;
-constexpr int WH_NX = (WH_HR * WH_HWD * 8 + 255) / 256, WH_ND = WH_TP * 8 / 256;
-constexpr int WH_LDS = (WH_HR * WH_HWD + WH_TP) * WH_LD * 2;
-
-__global__ __launch_bounds__(256, 1) void conv_wgrad_halo_bf16_kernel(const WgradHaloArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char whs[];
-  unsigned short* Xs = reinterpret_cast<unsigned short*>(whs);                          // [340][WH_LD]
-  unsigned short* Ds = Xs + WH_HR * WH_HWD * WH_LD;                                      // [256][WH_LD]
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lr = lane & 31, lh = lane >> 5;
-  const int grp = lane >> 4, cb = 16 * (grp & 1), hk = grp >> 1, tq = (lane & 15) >> 2, tp = lane & 3;
-  const int wco = wave >> 1, wci = wave & 1;
-  const int pair = (int)blockIdx.x % a.pairs, split = (int)blockIdx.x / a.pairs;
-  const int cob = pair / a.ncib, cib = pair % a.ncib;
-  const int H = a.h, W = a.w;
-
-  // gathered source of this block's 64 input channels (fused decoder input: block-uniform)
-  const bool UPC = a.up_ca > 0;
-  const bool second = UPC && cib * 64 >= a.up_ca;
-  const int cx = UPC ? (second ? a.ci - a.up_ca : a.up_ca) : a.ci;          // channels of the tensor read
-  const int c0 = second ? cib * 64 - a.up_ca : cib * 64;
-  const bool half_res = UPC && !second;
-  __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(second ? a.x2 : a.x), 0,
-                                                                  (int)(second ? a.x2_bytes : a.x_bytes), 0x00020000);
-  __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dy), 0, (int)a.dy_bytes, 0x00020000);
-
-  const int oct = tid & 7;
-  typedef unsigned u32x4h __attribute__((ext_vector_type(4)));
-  u32x4h sx[WH_NX], sd[WH_ND];
-  auto load_tile = [&](int tile) {
-    const int tx = tile % a.ntx;
-    const int t2 = tile / a.ntx;
-    const int ty = t2 % a.nty, img = t2 / a.nty;
-    const int y0 = ty * 8, x0 = tx * 32;
-#pragma unroll
-    for (int i = 0; i < WH_NX; ++i) {
-      const int pix = (tid + i * 256) >> 3;
-      const int hy = pix / WH_HWD, hx = pix - hy * WH_HWD;
-      const int iy = y0 + hy - 1, ix = x0 + hx - 1;
-      const bool ok = pix < WH_HR * WH_HWD && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-      const int p = half_res ? (img * (H >> 1) + (iy >> 1)) * (W >> 1) + (ix >> 1) : (img * H + iy) * W + ix;
-      const unsigned off = ok ? (unsigned)((p * cx + c0 + oct * 8) * 2) : 0x80000000u;
-      sx[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)off, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < WH_ND; ++i) {
-      const int pix = (tid + i * 256) >> 3;
-      const int oy = y0 + (pix >> 5), ox = x0 + (pix & 31);
-      const bool ok = oy < H && ox < W;
-      const unsigned off = ok ? (unsigned)((((img * H + oy) * W + ox) * a.co + cob * 64 + oct * 8) * 2) : 0x80000000u;
-      sd[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_d, (int)off, 0, 0);
-    }
-  };
-  auto store_tile = [&]() {
-#pragma unroll
-    for (int i = 0; i < WH_NX; ++i) {
-      const int pix = (tid + i * 256) >> 3;
-      if (i < WH_NX - 1 || pix < WH_HR * WH_HWD) *reinterpret_cast<u32x4h*>(Xs + pix * WH_LD + oct * 8) = sx[i];
-    }
-#pragma unroll
-    for (int i = 0; i < WH_ND; ++i) *reinterpret_cast<u32x4h*>(Ds + ((tid + i * 256) >> 3) * WH_LD + oct * 8) = sd[i];
-  };
-
-  f32x16 acc[9];
-#pragma unroll
-  for (int t = 0; t < 9; ++t)
-#pragma unroll
-    for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
-
-  // this lane's address inside a 16-pixel K step of either tile (transposed reads: tr_fragment)
-  const int a_lane = (8 * hk + tq) * WH_LD + wco * 32 + cb + 4 * tp;
-  const int b_lane = (8 * hk + tq) * WH_LD + wci * 32 + cb + 4 * tp;
-
-  if (split < a.ntiles) load_tile(split);
-  for (int tile = split; tile < a.ntiles; tile += a.P) {
-    store_tile();
-    __syncthreads();
-    if (tile + a.P < a.ntiles) load_tile(tile + a.P);
-#pragma unroll 4
-    for (int ks = 0; ks < 16; ++ks) {
-      const int r = ks >> 1, hf = ks & 1;
-      const bf16x8w af = tr_fragment(Ds + (r * 32 + 16 * hf) * WH_LD + a_lane, WH_LD);
-#pragma unroll
-      for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-          const bf16x8w bf = tr_fragment(Xs + ((r + dy) * WH_HWD + 16 * hf + dx) * WH_LD + b_lane, WH_LD);
-          acc[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[dy * 3 + dx], 0, 0, 0);
-        }
-    }
-    __syncthreads();
-  }
-
-  // dW[co][tap][ci] += acc: register v of a tap = one co row, 32 consecutive ci per half-wave (two 128-byte segments per
-  // wave-instruction: the full-rate shape of the memory-side float atomics)
-  const int ci_g = cib * 64 + wci * 32 + lr;
-#pragma unroll
-  for (int t = 0; t < 9; ++t)
-#pragma unroll
-    for (int v = 0; v < 16; ++v) {
-      const int co_g = cob * 64 + wco * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
-      atomicAdd(a.dw + ((size_t)co_g * 9 + t) * a.ci + ci_g, acc[t][v]);
-    }
-}
-
-bool wgrad_halo_applicable(const udaseg_conv_desc* d, int up_ca) {
-  static int off = -1;   // UDASEG_NO_WGRAD_HALO=1: A/B against the per-tap split-K kernel
-  if (off < 0) off = getenv("UDASEG_NO_WGRAD_HALO") != nullptr ? 1 : 0;
-  if (off || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1) return false;
-  if (d->ci % 64 != 0 || d->co % 64 != 0) return false;
-  // images narrower than the 32-pixel tile waste its lanes and leave a block per channel pair walking every tile alone:
-  // measured slower there (512 -> 512 at 16^2: 54 -> 84 us, at 24^2: 94 -> 117 us; profiles/r03_wgrad_halo.txt)
-  if (d->wi < 32) return false;
-  if (up_ca > 0 && (up_ca % 64 != 0 || up_ca >= d->ci || d->hi % 2 != 0 || d->wi % 2 != 0)) return false;
-  const long long px = (long long)d->n * d->hi * d->wi;
-  return px * d->ci * 2 < (1LL << 31) && px * d->co * 2 < (1LL << 31);
-}
-
-int launch_wgrad_halo(const udaseg_conv_desc* d, const void* x, const void* x2, int up_ca, const void* dy, float* dw, hipStream_t s) {
-  WgradHaloArgs a = {};
-  a.x = x; a.x2 = x2; a.dy = dy; a.dw = dw;
-  a.n = d->n; a.h = d->hi; a.w = d->wi; a.ci = d->ci; a.co = d->co; a.up_ca = up_ca;
-  a.ntx = cdiv(d->wi, 32); a.nty = cdiv(d->hi, 8); a.ntiles = d->n * a.ntx * a.nty;
-  a.ncib = d->ci / 64; a.pairs = a.ncib * (d->co / 64);
-  static int target = -1;      // blocks per launch (UDASEG_WGRAD_HALO_BLOCKS: tuning aid)
-  if (target < 0) {
-    const char* e = getenv("UDASEG_WGRAD_HALO_BLOCKS");
-    target = e ? atoi(e) : 96;
-    if (target < 1) target = 96;
-  }
-  int P = target / a.pairs;
-  if (P < 1) P = 1;
-  if (P > a.ntiles) P = a.ntiles;
-  a.P = P;
-  const long long px = (long long)d->n * d->hi * d->wi;
-  a.x_bytes = (unsigned)(up_ca > 0 ? (long long)d->n * (d->hi / 2) * (d->wi / 2) * up_ca * 2 : px * d->ci * 2);
-  a.x2_bytes = (unsigned)(up_ca > 0 ? px * (d->ci - up_ca) * 2 : 0);
-  a.dy_bytes = (unsigned)(px * d->co * 2);
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_halo_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WH_LDS);
-    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv_wgrad_halo_bf16)");
-    attr_done = true;
-  }
-  static int kid = -1;
-  if (kid < 0) kid = kprof_id("conv_wgrad_halo_bf16_kernel");
-  hipEvent_t ev = kprof_begin(s);
-  hipLaunchKernelGGL(conv_wgrad_halo_bf16_kernel, dim3((unsigned)(a.pairs * P)), dim3(256), WH_LDS, s, a);
-  kprof_end(kid, ev, s, 2.0 * (double)px * d->co * 9.0 * d->ci);
-  UDASEG_LAUNCH_CHECK("conv_wgrad_halo_bf16 launch");
-  return UDASEG_OK;
-}
-
-// --------------------------------------------------------------------------- halo weight gradient, fp32 on the bf16 matrix pipe
-// The same blocking for fp32 tensors with the exact three-term split of conv_halo_f32x3.hip: x halo and dy tile are loaded as
-// fp32, split in registers into three bf16 planes each in LDS; per (16-pixel K step, tap) the six products with i + j <= 2.
-// Against the bf16 kernel above the LDS traffic per MFMA halves (three plane reads feed six MFMAs), which is what bounded it;
-// the tile shrinks to TR x 32 pixels so that three planes of halo + dy fit the 160 KB.  dW is fp32 either way.
-// (Measured and not kept, tools/micro/conv_wgrad_halo_f32x3_ws.hip.txt: loader waves + MFMA waves as in conv3x3_f32x3_ws_kernel --
-// two LDS buffers only fit one-row tiles, whose 3 x 34 halo triples the x traffic and the split work: 2.53 against 2.14 ms per step.)
-struct WgradHaloF3Args {
-  const float* x;     // [n][h][w][cx] fp32, or the half-resolution a [n][h/2][w/2][up_ca] of a fused decoder input
-  const float* x2;    // fused decoder input: the skip tensor [n][h][w][ci - up_ca]
-  const float* dy;    // [n][h][w][co]
-  float* dw;          // [co][9][ci] fp32, accumulated onto
-  int n, h, w, ci, co, up_ca;
-  int ntx, nty, ntiles, ncib, pairs, P;
-  unsigned x_bytes, x2_bytes, dy_bytes;
-};
-
-template <int TR, int NWV>
-struct WF3 {
-  static constexpr int NT = 64 * NWV;                  // 4 waves: each owns all nine taps of its 32 x 32 (co, ci) block; 8 waves: waves
-                                                       // 0-3 taps 0-4, waves 4-7 taps 5-8 (two waves per SIMD cover each other's stalls)
-  static constexpr int HR = TR + 2, HWD = 34, TP = TR * 32;
-  // elements per LDS pixel row: 64 channels + pad.  96 (192 B, WH_LD) for the 2-row tile; 72 (144 B) for the 4-row tile -- the four
-  // rows of a transposed read then start at bytes 0, 144, 32, 176 (mod 256): still four disjoint 32-byte bank ranges, and three
-  // planes of a 6 x 34 halo + 128 dy pixels fit the 160 KB (143 KB)
-  static constexpr int LD = TR >= 4 ? 72 : 96;
-  static constexpr int XPL = HR * HWD * LD, DPL = TP * LD;     // elements per plane
-  static constexpr int NX = (HR * HWD * 8 + NT - 1) / NT, ND = (TP * 8 + NT - 1) / NT;
-  static constexpr int LDS = 3 * (XPL + DPL) * 2;
-  static constexpr int NACC = NWV == 4 ? 9 : 5;
-};
-
-template <int TR, int NWV>
-__global__ __launch_bounds__(64 * NWV, NWV / 4) void conv_wgrad_halo_f32x3_kernel(const WgradHaloF3Args a) {
-  using C = WF3<TR, NWV>;
-  extern __shared__ __attribute__((aligned(16))) char whs3[];
-  unsigned short* Xs = reinterpret_cast<unsigned short*>(whs3);                         // [3][HR * 34][LD]
-  unsigned short* Ds = Xs + 3 * C::XPL;                                                  // [3][TP][LD]
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lr = lane & 31, lh = lane >> 5;
-  const int grp = lane >> 4, cb = 16 * (grp & 1), hk = grp >> 1, tq = (lane & 15) >> 2, tp = lane & 3;
-  const int wq = wave & 3, tg = wave >> 2;             // 32 x 32 quadrant of the block's 64 x 64; tap group
-  const int wco = wq >> 1, wci = wq & 1;
-  const int pair = (int)blockIdx.x % a.pairs, split = (int)blockIdx.x / a.pairs;
-  const int cob = pair / a.ncib, cib = pair % a.ncib;
-  const int H = a.h, W = a.w;
-
-  const bool UPC = a.up_ca > 0;
-  const bool second = UPC && cib * 64 >= a.up_ca;
-  const int cx = UPC ? (second ? a.ci - a.up_ca : a.up_ca) : a.ci;
-  const int c0 = second ? cib * 64 - a.up_ca : cib * 64;
-  const bool half_res = UPC && !second;
-  __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(second ? a.x2 : a.x), 0,
-                                                                  (int)(second ? a.x2_bytes : a.x_bytes), 0x00020000);
-  __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, (int)a.dy_bytes, 0x00020000);
-
-  const int oct = tid & 7;
-  u32x4 sx[C::NX][2], sd[C::ND][2];
-  auto load_tile = [&](int tile) {
-    const int tx = tile % a.ntx;
-    const int t2 = tile / a.ntx;
-    const int ty = t2 % a.nty, img = t2 / a.nty;
-    const int y0 = ty * TR, x0 = tx * 32;
-#pragma unroll
-    for (int i = 0; i < C::NX; ++i) {
-      const int pix = (tid + i * C::NT) >> 3;
-      const int hy = pix / C::HWD, hx = pix - hy * C::HWD;
-      const int iy = y0 + hy - 1, ix = x0 + hx - 1;
-      const bool ok = pix < C::HR * C::HWD && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-      const int p = half_res ? (img * (H >> 1) + (iy >> 1)) * (W >> 1) + (ix >> 1) : (img * H + iy) * W + ix;
-      const unsigned off = ok ? (unsigned)((p * cx + c0 + oct * 8) * 4) : 0x80000000u;
-      sx[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)off, 0, 0);
-      sx[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)off, 16, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < C::ND; ++i) {
-      const int pix = (tid + i * C::NT) >> 3;
-      const int oy = y0 + (pix >> 5), ox = x0 + (pix & 31);
-      const bool ok = pix < C::TP && oy < H && ox < W;
-      const unsigned off = ok ? (unsigned)((((img * H + oy) * W + ox) * a.co + cob * 64 + oct * 8) * 4) : 0x80000000u;
-      sd[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_d, (int)off, 0, 0);
-      sd[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_d, (int)off, 16, 0);
-    }
-  };
-  auto store_tile = [&]() {
-#pragma unroll
-    for (int i = 0; i < C::NX; ++i) {
-      const int pix = (tid + i * C::NT) >> 3;
-      if (i < C::NX - 1 || pix < C::HR * C::HWD) {
-        u32x4 p0, p1, p2;
-        split3(sx[i][0], sx[i][1], p0, p1, p2);
-        unsigned short* q = Xs + pix * C::LD + oct * 8;
-        *reinterpret_cast<u32x4*>(q) = p0;
-        *reinterpret_cast<u32x4*>(q + C::XPL) = p1;
-        *reinterpret_cast<u32x4*>(q + 2 * C::XPL) = p2;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < C::ND; ++i) {
-      const int pix = (tid + i * C::NT) >> 3;
-      if (i < C::ND - 1 || pix < C::TP) {
-        u32x4 p0, p1, p2;
-        split3(sd[i][0], sd[i][1], p0, p1, p2);
-        unsigned short* q = Ds + pix * C::LD + oct * 8;
-        *reinterpret_cast<u32x4*>(q) = p0;
-        *reinterpret_cast<u32x4*>(q + C::DPL) = p1;
-        *reinterpret_cast<u32x4*>(q + 2 * C::DPL) = p2;
-      }
-    }
-  };
-
-  f32x16 acc[C::NACC];
-#pragma unroll
-  for (int t = 0; t < C::NACC; ++t)
-#pragma unroll
-    for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
-
-  const int a_lane = (8 * hk + tq) * C::LD + wco * 32 + cb + 4 * tp;
-  const int b_lane = (8 * hk + tq) * C::LD + wci * 32 + cb + 4 * tp;
-
-  // the nine taps (T0 .. T0 + NTAP) of one 16-pixel K step: three plane reads per operand feed six MFMAs
-  auto taps = [&](auto t0c, auto ntc, const bf16x8w (&af)[3], int r, int hf) {
-    constexpr int T0 = decltype(t0c)::value, NTAP = decltype(ntc)::value;
-#pragma unroll
-    for (int tt = 0; tt < NTAP; ++tt) {
-      const int t = T0 + tt, dy = t / 3, dx = t % 3;
-      bf16x8w bf[3];
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
-        bf[pl] = tr_fragment(Xs + pl * C::XPL + ((r + dy) * C::HWD + 16 * hf + dx) * C::LD + b_lane, C::LD);
-#pragma unroll
-      for (int ij = 2; ij >= 0; --ij)
-#pragma unroll
-        for (int i = 0; i <= ij; ++i) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[ij - i], acc[tt], 0, 0, 0);
-    }
-  };
-
-  if (split < a.ntiles) load_tile(split);
-  for (int tile = split; tile < a.ntiles; tile += a.P) {
-    store_tile();
-    __syncthreads();
-    if (tile + a.P < a.ntiles) load_tile(tile + a.P);
-#pragma unroll 2
-    for (int ks = 0; ks < 2 * TR; ++ks) {
-      const int r = ks >> 1, hf = ks & 1;
-      bf16x8w af[3];
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) af[pl] = tr_fragment(Ds + pl * C::DPL + (r * 32 + 16 * hf) * C::LD + a_lane, C::LD);
-      if constexpr (NWV == 4) {
-        taps(std::integral_constant<int, 0>{}, std::integral_constant<int, 9>{}, af, r, hf);
-      } else {
-        if (tg == 0) taps(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{}, af, r, hf);
-        else taps(std::integral_constant<int, 5>{}, std::integral_constant<int, 4>{}, af, r, hf);
-      }
-    }
-    __syncthreads();
-  }
-
-  const int ci_g = cib * 64 + wci * 32 + lr;
-  const int tbase = NWV == 4 ? 0 : 5 * tg, ntap = NWV == 4 ? 9 : (tg == 0 ? 5 : 4);
-#pragma unroll
-  for (int tt = 0; tt < C::NACC; ++tt) {
-    if (tt < ntap) {
-#pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        const int co_g = cob * 64 + wco * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
-        atomicAdd(a.dw + ((size_t)co_g * 9 + tbase + tt) * a.ci + ci_g, acc[tt][v]);
-      }
-    }
-  }
-}
-
-bool wgrad_halo_f3_applicable(const udaseg_conv_desc* d, int up_ca) {
-  static int off = -1;   // UDASEG_F32_SPLIT=0 / UDASEG_NO_WGRAD_HALO=1: the fp32-MFMA split-K kernel everywhere
-  if (off < 0) {
-    const char* e = getenv("UDASEG_F32_SPLIT");
-    off = ((e && atoi(e) == 0) || getenv("UDASEG_NO_WGRAD_HALO") != nullptr) ? 1 : 0;
-  }
-  if (off || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1) return false;
-  if (d->ci % 64 != 0 || d->co % 64 != 0 || d->wi < 32) return false;
-  if (up_ca > 0 && (up_ca % 64 != 0 || up_ca >= d->ci || d->hi % 2 != 0 || d->wi % 2 != 0)) return false;
-  const long long px = (long long)d->n * d->hi * d->wi;
-  return px * d->ci * 4 < (1LL << 31) && px * d->co * 4 < (1LL << 31);
-}
-
-template <int TR, int NWV>
-static int launch_wgrad_halo_f3_t(const udaseg_conv_desc* d, const float* x, const float* x2, int up_ca, const float* dy, float* dw,
-                                  hipStream_t s) {
-  using C = WF3<TR, NWV>;
-  WgradHaloF3Args a = {};
-  a.x = x; a.x2 = x2; a.dy = dy; a.dw = dw;
-  a.n = d->n; a.h = d->hi; a.w = d->wi; a.ci = d->ci; a.co = d->co; a.up_ca = up_ca;
-  a.ntx = cdiv(d->wi, 32); a.nty = cdiv(d->hi, TR); a.ntiles = d->n * a.ntx * a.nty;
-  a.ncib = d->ci / 64; a.pairs = a.ncib * (d->co / 64);
-  static int target = -1;      // blocks per launch (UDASEG_WGRAD_F3_BLOCKS: tuning aid)
-  if (target < 0) {
-    const char* e = getenv("UDASEG_WGRAD_F3_BLOCKS");
-    target = e ? atoi(e) : 120;      // r18 8 x 512^2 step, 8-wave blocks: 64 / 96 / 112 / 128 / 144 blocks = 741 / 823 / 845 / 840 / 826
-                                     // images/s (the kernel alone keeps getting faster with more blocks -- 2.5 / 2.3 / 2.2 / 1.9 ms
-                                     // per step -- but it runs beside the main stream's chain and takes its CUs);
-                                     // 4-wave blocks: 96 / 128 / 192 / 256 = 782 / 819 / 820 / 812 (profiles/r03_f32x3.txt)
-    if (target < 1) target = 120;
-  }
-  int P = target / a.pairs;
-  if (P < 1) P = 1;
-  if (P > a.ntiles) P = a.ntiles;
-  a.P = P;
-  const long long px = (long long)d->n * d->hi * d->wi;
-  a.x_bytes = (unsigned)(up_ca > 0 ? (long long)d->n * (d->hi / 2) * (d->wi / 2) * up_ca * 4 : px * d->ci * 4);
-  a.x2_bytes = (unsigned)(up_ca > 0 ? px * (d->ci - up_ca) * 4 : 0);
-  a.dy_bytes = (unsigned)(px * d->co * 4);
-  auto kern = conv_wgrad_halo_f32x3_kernel<TR, NWV>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
-    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv_wgrad_halo_f32x3)");
-    attr_done = true;
-  }
-  static int kid = -1;
-  if (kid < 0) {
-    char nm[64];
-    snprintf(nm, sizeof(nm), "conv_wgrad_halo_f32x3_kernel<%d, %d>", TR, NWV);
-    kid = kprof_id(nm);
-  }
-  hipEvent_t ev = kprof_begin(s);
-  hipLaunchKernelGGL(kern, dim3((unsigned)(a.pairs * P)), dim3(C::NT), C::LDS, s, a);
-  kprof_end(kid, ev, s, 2.0 * (double)px * d->co * 9.0 * d->ci);
-  UDASEG_LAUNCH_CHECK("conv_wgrad_halo_f32x3 launch");
-  return UDASEG_OK;
-}
-
+// The halo-resident weight gradients (bf16 and the fp32 three-term split) live in conv_wgrad_halo2.hip since round 4; round 3's
+// kernels (conv_wgrad_halo_bf16_kernel, conv_wgrad_halo_f32x3_kernel: 64 x 64 blocks only, one x fragment read per tap, a 144-byte LDS
+// pitch with two-way bank conflicts on every transposed read) were removed when the second form had replaced them on every shape.
 }  // namespace udaseg
 
 using namespace udaseg;
@@ -1124,17 +718,12 @@ extern "C" int udaseg_conv2d_wgrad_bnin_bf16(const udaseg_conv_desc* d, const vo
   return conv2d_wgrad_impl(d, x, d->ci, 0, 0, dy, dw, accumulate, stream, 1, in_scale, in_shift, in_act, in_slope);
 }
 
-// second form of the halo kernels (conv_wgrad_halo2.hip); UDASEG_WGRAD_V1=1 keeps round 3's kernels (A/B)
+// halo-resident weight gradients (conv_wgrad_halo2.hip)
 namespace udaseg {
 bool wgrad_h2_applicable(const udaseg_conv_desc* d, int up_ca, bool f32);
 int launch_wgrad_h2(const udaseg_conv_desc* d, const void* x, const void* x2, int up_ca, const void* dy, float* dw, bool f32, hipStream_t s);
-static bool wgrad_v1() {
-  static int v = -1;
-  if (v < 0) v = getenv("UDASEG_WGRAD_V1") != nullptr ? 1 : 0;
-  return v != 0;
-}
 static bool wgrad_halo_off(bool f32) {
-  static int off = -1, off3 = -1;
+  static int off = -1, off3 = -1;   // UDASEG_NO_WGRAD_HALO=1: the per-tap split-K kernels everywhere; UDASEG_F32_SPLIT=0: no fp32 split
   if (off < 0) {
     const char* e = getenv("UDASEG_F32_SPLIT");
     off = getenv("UDASEG_NO_WGRAD_HALO") != nullptr ? 1 : 0;
@@ -1145,9 +734,7 @@ static bool wgrad_halo_off(bool f32) {
 }  // namespace udaseg
 
 extern "C" int udaseg_conv2d_wgrad_halo_bf16_ok(const udaseg_conv_desc* d, int up_ca) {
-  if (d == nullptr) return 0;
-  if (wgrad_v1()) return wgrad_halo_applicable(d, up_ca) ? 1 : 0;
-  return !wgrad_halo_off(false) && wgrad_h2_applicable(d, up_ca, false) ? 1 : 0;
+  return d != nullptr && !wgrad_halo_off(false) && wgrad_h2_applicable(d, up_ca, false) ? 1 : 0;
 }
 
 extern "C" int udaseg_conv2d_wgrad_halo_bf16(const udaseg_conv_desc* d, const void* x, const void* skip, int up_ca, const void* dy,
@@ -1161,20 +748,19 @@ extern "C" int udaseg_conv2d_wgrad_halo_bf16(const udaseg_conv_desc* d, const vo
   }
   hipStream_t st = as_stream(stream);
   prof_begin(1, st);
-  const int rc = wgrad_v1() ? launch_wgrad_halo(d, x, skip, up_ca, dy, dw, st) : launch_wgrad_h2(d, x, skip, up_ca, dy, dw, false, st);
+  const int rc = launch_wgrad_h2(d, x, skip, up_ca, dy, dw, false, st);
   prof_end(1, st, udaseg_conv_flops(d), 2, d);
   return rc;
 }
 
 extern "C" int udaseg_conv2d_wgrad_halo_f32x3_ok(const udaseg_conv_desc* d, int up_ca) {
-  if (d == nullptr) return 0;
-  if (wgrad_v1()) return wgrad_halo_f3_applicable(d, up_ca) ? 1 : 0;
-  return !wgrad_halo_off(true) && wgrad_h2_applicable(d, up_ca, true) ? 1 : 0;
+  return d != nullptr && !wgrad_halo_off(true) && wgrad_h2_applicable(d, up_ca, true) ? 1 : 0;
 }
 
 extern "C" int udaseg_conv2d_wgrad_halo_f32x3(const udaseg_conv_desc* d, const float* x, const float* skip, int up_ca, const float* dy,
                                               float* dw, void* stream) {
   UDASEG_CHECK_ARG(d && x && dy && dw, "conv2d_wgrad_halo_f32x3: NULL pointer");
+  UDASEG_CHECK_ARG(d->n > 0 && d->hi > 0 && d->wi > 0 && d->ho == d->hi && d->wo == d->wi, "conv2d_wgrad_halo_f32x3: bad extents");
   UDASEG_CHECK_ARG((up_ca > 0) == (skip != nullptr), "conv2d_wgrad_halo_f32x3: up_ca=%d, skip %s", up_ca, skip ? "given" : "NULL");
   if (!udaseg_conv2d_wgrad_halo_f32x3_ok(d, up_ca)) {
     set_error("conv2d_wgrad_halo_f32x3: geometry not supported (ask udaseg_conv2d_wgrad_halo_f32x3_ok first)");
@@ -1182,24 +768,7 @@ extern "C" int udaseg_conv2d_wgrad_halo_f32x3(const udaseg_conv_desc* d, const f
   }
   hipStream_t st = as_stream(stream);
   prof_begin(1, st);
-  if (!wgrad_v1()) {
-    const int rc2 = launch_wgrad_h2(d, x, skip, up_ca, dy, dw, true, st);
-    prof_end(1, st, udaseg_conv_flops(d), 2, d);
-    return rc2;
-  }
-  static int waves = -1;       // UDASEG_WGRAD_F3_WAVES = 4 | 8 (A/B)
-  if (waves < 0) {
-    const char* e = getenv("UDASEG_WGRAD_F3_WAVES");
-    waves = (e && atoi(e) == 4) ? 4 : 8;
-  }
-  static int rows = -1;        // UDASEG_WGRAD_F3_ROWS = 2 | 4 (A/B)
-  if (rows < 0) {
-    const char* e = getenv("UDASEG_WGRAD_F3_ROWS");
-    rows = (e && atoi(e) == 2) ? 2 : 4;      // 4 x 32 pixel tiles: 2.16 against 2.24 ms per r18 step for the 2-row tile (half the barriers per MFMA)
-  }
-  const int rc = waves == 4 ? launch_wgrad_halo_f3_t<2, 4>(d, x, skip, up_ca, dy, dw, st)
-                 : rows == 4 ? launch_wgrad_halo_f3_t<4, 8>(d, x, skip, up_ca, dy, dw, st)
-                             : launch_wgrad_halo_f3_t<2, 8>(d, x, skip, up_ca, dy, dw, st);
+  const int rc = launch_wgrad_h2(d, x, skip, up_ca, dy, dw, true, st);
   prof_end(1, st, udaseg_conv_flops(d), 2, d);
   return rc;
 }

@@ -3,7 +3,7 @@
 //
 //   dW[co][tap][ci] += sum over pixels p of dy[p][co] * x[p + tap][ci]        (reference: loss.backward(), src/models/train.py:343)
 //
-// What round 3's kernels (conv_wgrad.hip: conv_wgrad_halo_bf16_kernel / conv_wgrad_halo_f32x3_kernel) left on the table, measured
+// What round 3's kernels (conv_wgrad_halo_bf16_kernel / conv_wgrad_halo_f32x3_kernel, removed from conv_wgrad.hip) left on the table, measured
 // (profiles/r04_wgrad_v2.txt): (1) the 4-row tile's 144-byte LDS pitch put two of the four pixel rows of every transposed fragment
 // read on the same banks -- rocprofv3 SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.447 on the dominant symbol; (2) every tap
 // re-read its own x fragment: 36 LDS reads for 30 MFMAs per 16-pixel K step; (3) the two tap groups of a wave pair shared one
