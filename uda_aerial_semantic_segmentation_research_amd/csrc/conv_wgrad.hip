@@ -632,7 +632,18 @@ static int launch_wgrad(WgradArgs a, int accumulate, hipStream_t s, bool bf16 = 
       hipLaunchKernelGGL((conv_wgrad_kernel<BMW, BNW, WAVES_M, WAVES_N, true>), grid, block, 0, s, a);
     else
       hipLaunchKernelGGL((conv_wgrad_kernel<BMW, BNW, WAVES_M, WAVES_N, false>), grid, block, 0, s, a);
-    kprof_end((a.row_uniform ? 18 : 7) + (BMW == 64 ? 0 : 1), ev, s, 2.0 * (double)a.M * a.co * a.J);
+    int kid32 = (a.row_uniform ? 18 : 7) + (BMW == 64 ? 0 : 1);      // the fixed table knows the 64 x 64 and 32 x 128 symbols
+    if (BMW == 128) {
+      static int kid128[2] = {-1, -1};
+      int& k = kid128[a.row_uniform ? 1 : 0];
+      if (k < 0) {
+        char nm[96];
+        snprintf(nm, sizeof(nm), "conv_wgrad_kernel<%d, %d, %d, %d, %s>", BMW, BNW, WAVES_M, WAVES_N, a.row_uniform ? "true" : "false");
+        k = kprof_id(nm);
+      }
+      kid32 = k;
+    }
+    kprof_end(kid32, ev, s, 2.0 * (double)a.M * a.co * a.J);
   }
   UDASEG_LAUNCH_CHECK("conv_wgrad launch");
   return UDASEG_OK;
@@ -689,11 +700,18 @@ static int conv2d_wgrad_impl(const udaseg_conv_desc* d, const void* x, int src_c
   udaseg_conv_desc dp = *d;     // FLOPs of this launch: the slice's share
   dp.ci = src_c;
   if (bf16)   // co <= 32: the 32 x 128 tile, as in fp32 (three J-tiles instead of five re-reading dy, no half-empty co tile)
-    rc = d->co > 32 ? launch_wgrad<64, 64, 2, 2>(a, accumulate, st, true) : launch_wgrad<32, 128, 1, 4>(a, accumulate, st, true);
+    // >= 128 produced channels: 128 x 64 tiles (a wave 64 x 32: two MFMAs per 16-pixel step and fragment pair instead of one, half
+    // the gathered bytes per FLOP).  Same box, single-stream ms per step, 128 x 64 / 64 x 64: cfg 5 (r50's 1x1 and strided layers)
+    // 1.94 / 2.17, cfg 3 (the discriminator's 4x4 / stride 2 layers) 1.06 / 1.24 -- cfg 3 1028 against 982 images/s
+    // (profiles/r04_wgrad_tile.txt)
+    rc = d->co >= 128 ? launch_wgrad<128, 64, 2, 2>(a, accumulate, st, true)
+       : d->co > 32   ? launch_wgrad<64, 64, 2, 2>(a, accumulate, st, true)
+                      : launch_wgrad<32, 128, 1, 4>(a, accumulate, st, true);
   else if (whole && d->kh == d->kw &&
            small_wgrad_applicable(d->kh, d->stride, d->pad, d->ci, d->co, d->n * cdiv(d->hi, 16) * cdiv(d->wi, 16)))
     rc = launch_small_wgrad(static_cast<const float*>(x), static_cast<const float*>(dy), dw, d->n, d->hi, d->wi, d->ci, d->co,
                             accumulate, st, up);
+  // (fp32: the 128 x 64 tile buys nothing -- 0.449 against 0.433 ms per cfg 2 step for the seven layers left here)
   else if (d->co > 32) rc = launch_wgrad<64, 64, 2, 2>(a, accumulate, st);
   else rc = launch_wgrad<32, 128, 1, 4>(a, accumulate, st);
   prof_end(1, st, udaseg_conv_flops(&dp), 2, &dp);
