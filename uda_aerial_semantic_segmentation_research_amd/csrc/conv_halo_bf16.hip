@@ -1391,6 +1391,19 @@ static int halo_choice(int ks, int h, int w, int n, int gathered, int produced, 
   }
   if (tiles * cdiv(produced, 128) >= 192) return 3;
   if (tiles * cdiv(produced, 64) >= 256) return 2;
+  {
+    // deep low-resolution layers, where 32-pixel tiles leave under a block per CU: the 8 x 16-pixel x 64-channel tile again, when it
+    // reaches 256 blocks and at most a quarter of its columns are outside the image.  Forward, us per launch, this tile / the shared
+    // source (tools/halo_deep_probe.py, profiles/r04_halo_deep.txt): 256 -> 256 at 8 x 32^2 19.5 / 24.0, 768 -> 256 at 32^2
+    // 44.7 / 54.3, 512 -> 512 at 24^2 43.6 / 48.1; 512 -> 512 at 16^2 (128 blocks) 29.7 / 28.7 stays on the shared source
+    static int deep = -1;      // UDASEG_HALO_DEEP=0 (A/B)
+    if (deep < 0) {
+      const char* e = getenv("UDASEG_HALO_DEEP");
+      deep = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    const int wt = cdiv(w, 16);
+    if (deep && gathered % 32 == 0 && 4 * w >= 3 * 16 * wt && (long long)n * cdiv(h, 8) * wt * cdiv(produced, 64) >= 256) return 6;
+  }
   return 0;
 }
 
