@@ -39,8 +39,13 @@ int udaseg_version(void);
 /* runtime switches for cross-checks and tuning.  UDASEG_OPT_GENERIC_GATHER: 1 keeps the convolution kernels on their generic
  * gather loops, 0 allows the uniform-tap / row-uniform loops, -1 restores the environment default
  * (UDASEG_IGEMM_GENERIC / UDASEG_WGRAD_GENERIC).  Both loops accumulate in the same order: forward and dgrad results are
- * bit-identical between them. */
+ * bit-identical between them.
+ * UDASEG_OPT_F32_SPLIT: 0 keeps the shared-source fp32 kernels (udaseg_conv2d_fwd / _dgrad / _wgrad and their variants) on the
+ * fp32 matrix pipe, 1 allows the three-term bf16 split there (conv_igemm_kernel X3, conv_wgrad_x3_kernel), -1 restores the
+ * environment default (UDASEG_F32_SPLIT, UDASEG_IGEMM_X3, UDASEG_WGRAD_X3).  The halo-resident fp32 kernels (udaseg_conv2d_*_f32x3)
+ * are entry points of their own and are not affected. */
 #define UDASEG_OPT_GENERIC_GATHER 0
+#define UDASEG_OPT_F32_SPLIT 1
 int udaseg_set_option(int key, int value);
 const char* udaseg_last_error(void);
 /* number of HIP devices visible to the library (0 on a CPU-only box; never initialises a context) */

@@ -28,6 +28,16 @@ def K():
     return kernels
 
 
+@pytest.fixture(autouse=True)
+def native_reference(K):
+    """The "fp32-MFMA kernel" these tests measure against is the shared-source kernel ON THE fp32 MATRIX PIPE: since round 4 that
+    source has a three-term mode of its own (conv_igemm_kernel X3, conv_wgrad_x3_kernel), switched off here and graded by
+    test_shared_source_split_fp32_grade below."""
+    K.set_f32_split(0)
+    yield
+    K.set_f32_split(-1)
+
+
 def nhwc(t):
     return t.permute(0, 2, 3, 1).contiguous().to("cuda", f32)
 
@@ -253,6 +263,7 @@ def test_network_step_matches_fp32_mfma_path(K, monkeypatch):
     outs = []
     for split in (True, False):
         monkeypatch.setattr(engine, "USE_F32_SPLIT", split)
+        K.set_f32_split(-1 if split else 0)          # the strided / stem layers' shared-source kernels follow
         torch.manual_seed(11)
         net = Unet("resnet18", encoder_weights=None, in_channels=3, classes=23).cuda().train()
         assert (getattr(net, "_frag_arena", None) is not None) == split
@@ -359,3 +370,46 @@ def test_special_values(K):
     yc = nchw(y).double()
     keep = ~want.expand(co, h, w).unsqueeze(0)
     assert ((yc - y_ref).abs()[keep].max() / y_ref.abs().max()).item() <= 3e-6
+
+
+X3_CASES = [  # n, h, w, ci, co, k, stride, pad: the fp32 layers the halo kernels do not take
+    (2, 64, 64, 4, 64, 7, 2, 3),        # stem (3 channels padded to 4: the generic gather, 8-wide pieces straddle taps in the wgrad)
+    (2, 32, 32, 64, 128, 3, 2, 1),      # 3x3 / stride 2 (four parity classes in the data gradient)
+    (2, 16, 16, 128, 256, 3, 2, 1),
+    (2, 32, 32, 64, 128, 1, 2, 0),      # 1x1 / stride 2 down-sample
+    (2, 32, 32, 64, 128, 4, 2, 1),      # the discriminator's 4x4 / stride 2
+    (1, 20, 28, 40, 72, 3, 1, 1),       # channels that 32 does not divide, ragged tiles
+    (8, 128, 128, 64, 128, 3, 2, 1),    # the headline's first strided layer at its own size
+]
+
+
+@pytest.mark.parametrize("case", X3_CASES, ids=["n%d_%dx%d_ci%d_co%d_k%d_s%d_p%d" % c for c in X3_CASES])
+def test_shared_source_split_fp32_grade(K, case):
+    """udaseg_conv2d_fwd / _dgrad / _wgrad with the three-term split (UDASEG_OPT_F32_SPLIT 1) against f64, next to the same entry
+    points on the fp32 matrix pipe (option 0) on the same operands."""
+    n, h, w, ci, co, k, s, p = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(n, ci, h, w, generator=g)
+    wt = torch.randn(co, ci, k, k, generator=g) / math.sqrt(ci * k * k)
+    d = K.conv_desc(n, h, w, ci, co, k, s, p)
+    y_ref = F.conv2d(x.double(), wt.double(), None, s, p)
+    dy = torch.randn(y_ref.shape, generator=g)
+    dx_ref = torch.nn.grad.conv2d_input(x.shape, wt.double(), dy.double(), s, p)
+    dw_ref = torch.nn.grad.conv2d_weight(x.double(), wt.shape, dy.double(), s, p)
+    xd, wd, dyd = nhwc(x), wt.permute(0, 2, 3, 1).contiguous().cuda(), nhwc(dy)
+    wtp = torch.empty((ci, k, k, co), device="cuda")
+    K.pack_dgrad_weights(d, wd, wtp)
+    res = {}
+    for mode in (1, 0):
+        K.set_f32_split(mode)
+        y = torch.empty((n, d.ho, d.wo, co), device="cuda")
+        K.conv2d_fwd(d, xd, wd, None, y)
+        dx = torch.empty((n, h, w, ci), device="cuda")
+        K.conv2d_dgrad(d, dyd, wtp, dx)
+        dw = torch.empty((co, k, k, ci), device="cuda")
+        K.conv2d_wgrad(d, xd, dyd, dw)
+        res[mode] = (nchw(y), nchw(dx), dw.cpu().permute(0, 3, 1, 2).contiguous())
+    K.set_f32_split(0)
+    grade(res[1][0], res[0][0], y_ref, "forward")
+    grade(res[1][1], res[0][1], dx_ref, "data gradient")
+    grade(res[1][2], res[0][2], dw_ref, "weight gradient", cap=5e-6, k2=1.6)

@@ -299,7 +299,11 @@ def test_conv_identity_weights_asymmetric(K):
     y = torch.empty((n, h, w, c), device="cuda")
     K.conv2d_fwd(d, x.cuda(), wt.cuda(), None, y)
     ref = torch.stack([x[..., (o + 5) % c] * (1.0 + o) for o in range(c)], dim=-1)
-    assert torch.equal(y.cpu(), ref)
+    # since round 4 this launch runs on the bf16 matrix pipe (three-term split, conv_igemm_kernel X3): x * w arrives as three exact
+    # partial products whose sum the MFMA adder rounds in its own order -- within one unit in the last place of the fp32 product,
+    # which still separates every (pixel, channel) from its neighbours (the values are distinct multiples of 1e-3 x (1 + o))
+    err = ((y.cpu() - ref).abs() / ref.abs().clamp_min(1e-30)).max().item()
+    assert err <= 2.0 ** -22, err
 
 
 def test_conv_large_tiles(K):

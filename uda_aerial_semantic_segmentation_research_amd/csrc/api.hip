@@ -203,12 +203,16 @@ extern "C" int udaseg_prof_records(int family, int max_records, double* ms, doub
   return n;
 }
 
-namespace udaseg { int g_opt_generic_gather = -1; }
+namespace udaseg {
+int g_opt_generic_gather = -1;
+int g_opt_f32_split = -1;
+}
 
 extern "C" int udaseg_set_option(int key, int value) {
-  UDASEG_CHECK_ARG(key == UDASEG_OPT_GENERIC_GATHER, "set_option: unknown key %d", key);
+  UDASEG_CHECK_ARG(key == UDASEG_OPT_GENERIC_GATHER || key == UDASEG_OPT_F32_SPLIT, "set_option: unknown key %d", key);
   UDASEG_CHECK_ARG(value >= -1 && value <= 1, "set_option: value must be -1 (environment default), 0 or 1");
-  udaseg::g_opt_generic_gather = value;
+  if (key == UDASEG_OPT_GENERIC_GATHER) udaseg::g_opt_generic_gather = value;
+  else udaseg::g_opt_f32_split = value;
   return UDASEG_OK;
 }
 

@@ -12,6 +12,7 @@ namespace udaseg {
 void set_error(const char* fmt, ...);
 // runtime switches (udaseg_set_option): -1 = take the environment default
 extern int g_opt_generic_gather;   // 1: igemm / wgrad keep the generic gather loops (cross-check of the uniform paths)
+extern int g_opt_f32_split;        // 0: shared-source fp32 kernels stay on the fp32 matrix pipe (udaseg_set_option)
 int hip_fail(hipError_t e, const char* what);
 
 #define UDASEG_CHECK_ARG(cond, ...)                 \

@@ -22,6 +22,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "halo_common.h"
 
 namespace udaseg {
 
@@ -100,10 +101,9 @@ constexpr int STATS_REPLICAS = 16;  // == udaseg_bn_replicas() (norm_act.hip)
 constexpr int BK = 32;
 constexpr int LDS_LD = BK + 4;
 
-template <int BM, int BN>
-constexpr int igemm_lds_bytes() { return 2 * (BM + BN) * LDS_LD * 4 + 3 * 64 * 4; }
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// X3 (fp32 storage on the bf16 matrix pipe): a K-tile of 32 fp32 per row is kept as three bf16 planes of 64-byte rows
+template <int BM, int BN, bool X3 = false>
+constexpr int igemm_lds_bytes() { return (X3 ? 2 * 3 * (BM + BN) * 64 : 2 * (BM + BN) * LDS_LD * 4) + 3 * 64 * 4; }
 
 // BF = false: fp32 storage, v_mfma_f32_32x32x2_f32, 32 K-elements per tile.
 // BF = true : bf16 storage, v_mfma_f32_32x32x16_bf16, 64 K-elements per tile, fp32 accumulation / bias / statistics.
@@ -116,9 +116,16 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // offsets into range-checked buffer loads (a masked-out lane gets bit 31 set and reads zeros): 3 VALU per A row-load,
 // 1 per B row-load.
 // UP = true (with UNI): the fused upsample + concat gather described at IgemmArgs::x2.
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool BF, bool UNI, bool UP>
+// X3 = true (with BF = false; round 4): fp32 storage in and out, the products on v_mfma_f32_32x32x16_bf16 -- every staged operand is
+// split EXACTLY into three bf16 terms (halo_common.h split3_4) on its way into LDS, six MFMAs per fragment pair (conv_halo_f32x3.hip
+// has the arithmetic).  The layers the halo kernels do not take (stride 2, 7x7 stem, 1x1 / stride 2, 4x4 / stride 2 in fp32) leave the
+// fp32 matrix pipe this way.  LDS: per buffer three planes of A and of B, 64-byte rows (32 bf16), the four 16-byte units of a row
+// XOR-swizzled with bits 2..3 of the row so that the 16 lanes of a ds_read_b128 phase cover all 64 banks without padding.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool BF, bool UNI, bool UP, bool X3 = false>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
   static_assert(UNI || !UP, "the fused gather lives in the uniform-tap loop");
+  static_assert(!X3 || !BF, "the three-term split reads fp32 operands");
+  constexpr int X3_BUF = 3 * (BM + BN) * 64;     // bytes of one X3 stage
   constexpr int ES = BF ? 2 : 4;        // element bytes
   constexpr int EPV = 16 / ES;          // elements per 16-byte vector
   constexpr int BKE = BK * 4 / ES;      // K elements per tile
@@ -133,7 +140,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* As = reinterpret_cast<float*>(smem_raw);          // [2][BM][LDS_LD]
   float* Bs = As + 2 * BM * LDS_LD;                         // [2][BN][LDS_LD]
-  int* taps = reinterpret_cast<int*>(Bs + 2 * BN * LDS_LD);  // [3][64]: dy, dx, wt
+  int* taps = X3 ? reinterpret_cast<int*>(smem_raw + 2 * X3_BUF) : reinterpret_cast<int*>(Bs + 2 * BN * LDS_LD);  // [3][64]: dy, dx, wt
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -241,6 +248,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+  // X3: the bf16 MFMA's adder TRUNCATES toward minus infinity where the fp32 one rounds to nearest (measured, tools/x3_bias_check.py:
+  // mean signed error -3.8e-8 of mean |y| on a 64-channel 3x3 layer against 1e-10 on the fp32 pipe; the l2 error is the same).  A
+  // bias is what an ill-conditioned sum downstream amplifies (the stem's weight gradient, tests/test_gpu_suites.py), so odd K-tiles
+  // are staged with the sign of A flipped and accumulate into a second set: y = acc - acc2, both sets biased the same way.
+  constexpr int NACC2 = X3 ? TM : 0;
+  f32x16 acc2[NACC2 > 0 ? NACC2 : 1][TN];
+  if constexpr (X3) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc2[i][j][v] = 0.f;
+  }
 
   // Two register stages (S0, S1): the global loads of K-tile kt+2 are issued before the MFMA phase of tile kt and are only
   // waited for one whole iteration later (just before they are written to LDS), so two tiles' loads are in flight per
@@ -349,7 +370,36 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
       rb[p] = *reinterpret_cast<gvec_t>(ok ? wb + off * ES : zp);
     }
   };
+  // X3: this thread's 8-byte slot of a row (4 K-values of the 16-byte unit kq >> 1) and a lane's fragment row
+  const int x3_woff = lrow * 64 + ((((kq >> 1) ^ ((lrow >> 2) & 3))) << 4) + (kq & 1) * 8;
+  const int x3_swz = (lr >> 2) & 3;
   auto store_tile = [&](int buf, const f32x4* ra, const f32x4* rb) {
+    if constexpr (X3) {
+      char* Ad = smem_raw + buf * X3_BUF + x3_woff;
+      char* Bd = Ad + 3 * BM * 64;
+#pragma unroll
+      for (int p = 0; p < A_PASS; ++p) {
+        u32x2 q0, q1, q2;
+        split3_4(ra[p], q0, q1, q2);
+        if (buf) {             // odd K-tiles live in buffer 1: -A (see acc2)
+          q0 ^= 0x80008000u;
+          q1 ^= 0x80008000u;
+          q2 ^= 0x80008000u;
+        }
+        *reinterpret_cast<u32x2*>(Ad + p * 32 * 64) = q0;
+        *reinterpret_cast<u32x2*>(Ad + BM * 64 + p * 32 * 64) = q1;
+        *reinterpret_cast<u32x2*>(Ad + 2 * BM * 64 + p * 32 * 64) = q2;
+      }
+#pragma unroll
+      for (int p = 0; p < B_PASS; ++p) {
+        u32x2 q0, q1, q2;
+        split3_4(rb[p], q0, q1, q2);
+        *reinterpret_cast<u32x2*>(Bd + p * 32 * 64) = q0;
+        *reinterpret_cast<u32x2*>(Bd + BN * 64 + p * 32 * 64) = q1;
+        *reinterpret_cast<u32x2*>(Bd + 2 * BN * 64 + p * 32 * 64) = q2;
+      }
+      return;
+    }
     float* Ad = As + buf * BM * LDS_LD;
     float* Bd = Bs + buf * BN * LDS_LD;
 #pragma unroll
@@ -359,6 +409,39 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
     for (int p = 0; p < B_PASS; ++p) *reinterpret_cast<f32x4*>(Bd + (lrow + 32 * p) * LDS_LD + kq * 4) = rb[p];
   };
   auto mfma_tile = [&](int buf) {
+    if constexpr (X3) {
+      const char* Ac = smem_raw + buf * X3_BUF + (wm + lr) * 64;
+      const char* Bc = smem_raw + buf * X3_BUF + 3 * BM * 64 + (wn + lr) * 64;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {               // two 16-deep MFMA steps per 32-element K-tile: k = 16 s + 8 lh + j
+        const int uo = ((2 * s + lh) ^ x3_swz) << 4;
+        u32x4 af[3][TM], bf[3][TN];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) af[pl][i] = *reinterpret_cast<const u32x4*>(Ac + pl * BM * 64 + i * 32 * 64 + uo);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) bf[pl][j] = *reinterpret_cast<const u32x4*>(Bc + pl * BN * 64 + j * 32 * 64 + uo);
+        }
+        // smallest terms first (piece p of A x piece q of B, p + q <= 2); consecutive MFMAs go to different accumulators
+#pragma unroll
+        for (int pq = 2; pq >= 0; --pq)
+#pragma unroll
+          for (int pa = 0; pa <= pq; ++pa)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j) {
+                if (buf)
+                  acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[pa][i]),
+                                                                       __builtin_bit_cast(bf16x8, bf[pq - pa][j]), acc2[i][j], 0, 0, 0);
+                else
+                  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[pa][i]),
+                                                                      __builtin_bit_cast(bf16x8, bf[pq - pa][j]), acc[i][j], 0, 0, 0);
+              }
+      }
+      return;
+    }
     const float* Ac = As + buf * BM * LDS_LD + (wm + lr) * LDS_LD + lh * 4;
     const float* Bc = Bs + buf * BN * LDS_LD + (wn + lr) * LDS_LD + lh * 4;
 #pragma unroll
@@ -430,6 +513,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
   }
   __syncthreads();   // every wave is done with the LDS tiles (the statistics epilogue reuses them)
   if (a.timeline) tl2 = wall_clock64();
+  if constexpr (X3) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] -= acc2[i][j];
+  }
 
   // ---- epilogue: D[i][j] reg v of lane (lr, lh) = C[row = (v&3) + 8*(v>>2) + 4*lh][col = lr]
   const int ccy = a.cy[cls], ccx = a.cx[cls];
@@ -733,11 +822,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
 unsigned long long* g_timeline = nullptr;     // also read by conv_halo_bf16.hip
 int g_timeline_blocks = 0;
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool BF, bool UNI, bool UP>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool BF, bool UNI, bool UP, bool X3 = false>
 static int launch_cfg_t(const IgemmArgs& a, hipStream_t s) {
   static bool attr_done = false;
-  constexpr int lds = igemm_lds_bytes<BM, BN>();
-  auto kern = conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, BF, UNI, UP>;
+  constexpr int lds = igemm_lds_bytes<BM, BN, X3>();
+  auto kern = conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, BF, UNI, UP, X3>;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv_igemm)");
@@ -761,12 +850,12 @@ static int launch_cfg_t(const IgemmArgs& a, hipStream_t s) {
   dim3 grid((unsigned)b.tile_begin[a.nclass]), block(256);
   constexpr int tile_id = (BM == 128 && BN == 128) ? 0 : (BM == 128 && BN == 64) ? 1 : (BM == 64) ? 2 : 3;
   int kid = UP ? 20 + tile_id : (UNI ? 14 + tile_id : tile_id);
-  if constexpr (BF) {      // bf16 instantiations report under their own rocprofv3 symbol (round 2 lumped them into one id)
+  if constexpr (BF || X3) {      // bf16 / X3 instantiations report under their own rocprofv3 symbol (round 2 lumped them into one id)
     static int bf_kid = -1;
     if (bf_kid < 0) {
       char nm[96];
-      snprintf(nm, sizeof(nm), "conv_igemm_kernel<%d, %d, %d, %d, true, %s, %s>", BM, BN, WAVES_M, WAVES_N, UNI ? "true" : "false",
-               UP ? "true" : "false");
+      snprintf(nm, sizeof(nm), "conv_igemm_kernel<%d, %d, %d, %d, %s, %s, %s%s>", BM, BN, WAVES_M, WAVES_N, BF ? "true" : "false",
+               UNI ? "true" : "false", UP ? "true" : "false", X3 ? ", true" : "");
       bf_kid = kprof_id(nm);
     }
     kid = bf_kid;
@@ -845,10 +934,44 @@ static int tile_override() {
   return v;
 }
 
+// fp32 launches on the bf16 matrix pipe (conv_igemm_kernel X3): > 32 produced channels.  UDASEG_IGEMM_X3 = 0 (off) | 1 (64 x 64 tile)
+// | 2 (128 x 64) | 3 (128 x 128); UDASEG_F32_SPLIT=0 switches every three-term kernel off.  Per call, us, fp32 pipe / X3 64 x 64 /
+// X3 128 x 64 (bench.py --layer-table, cfg 2, profiles/r04_igemm_x3.txt): 7x7 / stride 2 stem 164 / 130 / 126; 3x3 / stride 2 forward
+// 58 / 53 / 52, 58 / 50 / 50, 62 / 54 / 55; their data gradients (four parity classes, short K loops) 82 / 77 / 90, 70 / 65 / 73,
+// 77 / 69 / 81; 1x1 / stride 2 unchanged (24-38 us, latency).  The split is VALU work every block repeats for its A rows AND the weights
+// (88 vector instructions per thread and K-tile beside 12 MFMAs per wave): these layers gain 10-25 %, not the 2.7x of the matrix rate.
+static int x3_tile() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("UDASEG_IGEMM_X3");
+    v = e ? atoi(e) : 1;
+    if (v < 0 || v > 3) v = 1;
+  }
+  return f32_split_enabled() ? v : 0;
+}
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+static int launch_cfg_x3(const IgemmArgs& a, hipStream_t s) {
+  if (a.up_ca > 0) {
+    if (!a.uniform) {
+      set_error("conv_igemm: the fused upsample+concat input needs channel counts that are multiples of the K-tile");
+      return UDASEG_E_UNSUPPORTED;
+    }
+    return launch_cfg_t<BM, BN, WAVES_M, WAVES_N, false, true, true, true>(a, s);
+  }
+  if (a.uniform) return launch_cfg_t<BM, BN, WAVES_M, WAVES_N, false, true, false, true>(a, s);
+  return launch_cfg_t<BM, BN, WAVES_M, WAVES_N, false, false, false, true>(a, s);
+}
+
 static int launch_igemm(const IgemmArgs& a, hipStream_t s) {
   long long rows = 0;
   for (int c = 0; c < a.nclass; ++c) rows += a.M[c];
   if (rows <= 0) return UDASEG_OK;
+  if (!a.bf16 && a.co > 32 && x3_tile() != 0) {
+    const int t = x3_tile();
+    if (t == 1) return launch_cfg_x3<64, 64, 2, 2>(a, s);
+    if (t == 3) return launch_cfg_x3<128, 128, 2, 2>(a, s);
+    return launch_cfg_x3<128, 64, 2, 2>(a, s);
+  }
   const long long tiles128 = (rows + 127) / 128;
   switch (tile_override()) {
     case 1: return launch_cfg<128, 128, 2, 2>(a, s);

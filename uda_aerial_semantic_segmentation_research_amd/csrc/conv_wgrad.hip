@@ -538,6 +538,349 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------- fp32 on the bf16 pipe
+// The same GEMM with fp32 x / dy / dW and the products on v_mfma_f32_32x32x16_bf16 (round 4): a staged 8-channel piece (two 16-byte
+// fp32 loads) is split exactly into three bf16 terms (halo_common.h split3) and written to three LDS planes laid out like the bf16
+// kernel's tiles; fragments are the bf16 kernel's transposed reads, once per plane, six MFMAs per fragment pair (smallest terms first).
+// For the weight gradients conv_wgrad_halo2.hip does not take: stride 2, the 7x7 stem, 1x1 / stride 2, produced channels that 32 does
+// not divide.  K-tile: 32 pixels (two 16-deep steps = 12 MFMAs per wave and barrier; 55 KB of LDS for the 64 x 64 tile).
+constexpr int WBKX = 32;
+
+template <int BMW, int BNW, int WAVES_M, int WAVES_N, bool ROWU>
+__global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(const WgradArgs a) {
+  constexpr int WM = BMW / WAVES_M, WN = BNW / WAVES_N;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int LDA = BMW + 8, LDB = BNW + 8;         // bf16 elements per LDS row (16-byte pad)
+  constexpr int AQ = BMW / 8, BQ = BNW / 8;            // 8-channel pieces per row
+  constexpr int A_ROWS = 256 / AQ, B_ROWS = 256 / BQ;
+  constexpr int A_PASS = (WBKX + A_ROWS - 1) / A_ROWS, B_PASS = (WBKX + B_ROWS - 1) / B_ROWS;
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+  static_assert(!ROWU || (WBKX % A_ROWS == 0 && WBKX % B_ROWS == 0), "row-uniform passes must tile the K-tile");
+
+  __shared__ __attribute__((aligned(16))) unsigned short As[3][2][WBKX][LDA];
+  __shared__ __attribute__((aligned(16))) unsigned short Bs[3][2][WBKX][LDB];
+  const float* xg = reinterpret_cast<const float*>(a.x);
+  const float* dyg = reinterpret_cast<const float*>(a.dy);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int wm = (wave / WAVES_N) * WM, wn = (wave % WAVES_N) * WN;
+  const int grp = lane >> 4, cb = 16 * (grp & 1), hk = grp >> 1, tq = (lane & 15) >> 2, tp = lane & 3;
+
+  const int ntj = (a.J + BNW - 1) / BNW;
+  const int co0 = (blockIdx.x / ntj) * BMW;
+  const int j0 = (blockIdx.x % ntj) * BNW;
+  const int kbeg = blockIdx.y * a.kchunk;
+  const int kend = min(a.M, kbeg + a.kchunk);
+  if (kbeg >= a.M) return;
+
+  const int aq = tid % AQ, arow = tid / AQ;
+  const int a_co = co0 + aq * 8;
+  const bool a_ok = a_co < a.co;
+  const int bq = tid % BQ, brow = tid / BQ;
+  const int j = j0 + bq * 8;
+  const bool b_ok = j < a.J;
+  int b_dy = 0, b_dx = 0, b_c = 0;
+  if (b_ok) {
+    const int tap = fast_div(j, a.ci, a.inv_ci);
+    b_c = j - tap * a.ci;
+    const int r = fast_div(tap, a.kw, a.inv_kw);
+    b_dy = r - a.pad;
+    b_dx = (tap - r * a.kw) - a.pad;
+  }
+  // an 8-wide piece of the J axis may straddle two taps when ci is not a multiple of 8 (the stem's 4 padded channels): its two
+  // 4-channel halves are gathered separately
+  const bool b_two = (a.ci & 7) != 0;
+  int b2_dy = 0, b2_dx = 0, b2_c = 0;
+  const bool b2_ok = b_two && (j + 4) < a.J;
+  if (b2_ok) {
+    const int tap = fast_div(j + 4, a.ci, a.inv_ci);
+    b2_c = (j + 4) - tap * a.ci;
+    const int r = fast_div(tap, a.kw, a.inv_kw);
+    b2_dy = r - a.pad;
+    b2_dx = (tap - r * a.kw) - a.pad;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[i][jn][v] = 0.f;
+
+  // odd K-tiles (LDS buffer 1) carry -dy and accumulate into acc2, dW = acc - acc2: the bf16 MFMA adder truncates toward minus
+  // infinity, and a bias over up to 2^19 pixels is what this sum must not have (conv_igemm.hip, X3)
+  f32x16 acc2[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc2[i][jn][v] = 0.f;
+
+  u32x4 ra[A_PASS][2], rb[B_PASS][2];
+  const int nkt = (kend - kbeg + WBKX - 1) / WBKX;
+
+  unsigned u_ac[A_PASS], u_bc = 0;
+  int u_bdy = 0, u_bx = 0;
+  int s_ni[B_PASS], s_oy[B_PASS], s_ox[B_PASS];
+  unsigned s_dyoff = 0;
+  __amdgpu_buffer_rsrc_t rsrc_x, rsrc_dy;
+  if constexpr (ROWU) {
+    rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+    rsrc_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dy), 0, (int)a.dy_bytes, 0x00020000);
+#pragma unroll
+    for (int p = 0; p < A_PASS; ++p)
+      u_ac[p] = a_ok ? (unsigned)((arow + A_ROWS * p) * a.co + a_co) * 4u : 0x80000000u;
+    u_bdy = b_dy;
+    u_bx = brow * a.stride + b_dx;
+    u_bc = !b_ok ? 0x80000000u
+                 : a.up ? (unsigned)((u_bx >> 1) * a.ci + b_c) * 4u
+                        : (unsigned)((b_dy * a.wi + brow * a.stride + b_dx) * a.ci + b_c) * 4u;
+    s_dyoff = (unsigned)kbeg * (unsigned)a.co * 4u;
+#pragma unroll
+    for (int p = 0; p < B_PASS; ++p) {
+      const int m = kbeg + B_ROWS * p;
+      const int t1 = m / a.wo;
+      s_ox[p] = m - t1 * a.wo;
+      s_ni[p] = t1 / a.ho;
+      s_oy[p] = t1 - s_ni[p] * a.ho;
+    }
+  }
+
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  auto load_tile = [&](int kt) {
+    if constexpr (ROWU) {      // host: ci a multiple of 8 (a piece never straddles taps)
+#pragma unroll
+      for (int p = 0; p < A_PASS; ++p) {
+        ra[p][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_dy, (int)(u_ac[p] + s_dyoff), 0, 0);
+        ra[p][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_dy, (int)(u_ac[p] + s_dyoff), 16, 0);
+      }
+      s_dyoff += (unsigned)(WBKX * 4) * (unsigned)a.co;
+#pragma unroll
+      for (int p = 0; p < B_PASS; ++p) {
+        const int oys = s_oy[p] * a.stride, oxs = s_ox[p] * a.stride;
+        const bool ok = (unsigned)(oys + u_bdy) < (unsigned)a.hi && (unsigned)(oxs + u_bx) < (unsigned)a.wi;
+        unsigned voff;
+        if (a.up) {   // uniform branch
+          const int w2 = a.wi >> 1;
+          const unsigned s_off = (unsigned)((s_ni[p] * (a.hi >> 1) * w2 + (oxs >> 1)) * a.ci) * 4u;
+          voff = u_bc + s_off + (unsigned)(((oys + u_bdy) >> 1) * w2 * a.ci) * 4u;
+        } else {
+          const unsigned s_off = (unsigned)(((s_ni[p] * a.hi + oys) * a.wi + oxs) * a.ci) * 4u;
+          voff = u_bc + s_off;
+        }
+        voff = ok ? voff : 0x80000000u;
+        rb[p][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)voff, 0, 0);
+        rb[p][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)voff, 16, 0);
+        s_ox[p] += WBKX;
+        while (s_ox[p] >= a.wo) {
+          s_ox[p] -= a.wo;
+          if (++s_oy[p] == a.ho) {
+            s_oy[p] = 0;
+            ++s_ni[p];
+          }
+        }
+      }
+      return;
+    }
+    const int mb = kbeg + kt * WBKX;
+#pragma unroll
+    for (int p = 0; p < A_PASS; ++p) {
+      const int row = arow + A_ROWS * p, m = mb + row;
+      u32x4 v0 = zero4, v1 = zero4;
+      if (a_ok && row < WBKX && m < kend) {
+        const u32x4* src = reinterpret_cast<const u32x4*>(dyg + (size_t)m * a.co + a_co);
+        v0 = src[0];
+        if (a_co + 4 < a.co) v1 = src[1];
+      }
+      ra[p][0] = v0;
+      ra[p][1] = v1;
+    }
+#pragma unroll
+    for (int p = 0; p < B_PASS; ++p) {
+      const int row = brow + B_ROWS * p, m = mb + row;
+      u32x4 v0 = zero4, v1 = zero4;
+      if (b_ok && row < WBKX && m < kend) {
+        const int t1 = fast_div(m, a.wo, a.inv_wo);
+        const int ox = m - t1 * a.wo;
+        const int ni = fast_div(t1, a.ho, a.inv_ho);
+        const int oy = t1 - ni * a.ho;
+        {
+          const int iy = oy * a.stride + b_dy, ix = ox * a.stride + b_dx;
+          if ((unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi) {
+            const size_t pix = a.up ? (size_t)(ni * (a.hi >> 1) + (iy >> 1)) * (a.wi >> 1) + (ix >> 1) : (size_t)(ni * a.hi + iy) * a.wi + ix;
+            const u32x4* src = reinterpret_cast<const u32x4*>(xg + pix * (size_t)a.ci + b_c);
+            v0 = src[0];
+            if (!b_two && j + 4 < a.J) v1 = src[1];
+          }
+        }
+        if (b2_ok) {
+          const int iy = oy * a.stride + b2_dy, ix = ox * a.stride + b2_dx;
+          if ((unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi) {
+            const size_t pix = a.up ? (size_t)(ni * (a.hi >> 1) + (iy >> 1)) * (a.wi >> 1) + (ix >> 1) : (size_t)(ni * a.hi + iy) * a.wi + ix;
+            v1 = *reinterpret_cast<const u32x4*>(xg + pix * (size_t)a.ci + b2_c);
+          }
+        }
+      }
+      rb[p][0] = v0;
+      rb[p][1] = v1;
+    }
+  };
+  auto store_tile = [&](auto BUF) {
+    constexpr int buf = decltype(BUF)::value;
+#pragma unroll
+    for (int p = 0; p < A_PASS; ++p)
+      if (arow + A_ROWS * p < WBKX) {
+        u32x4 p0, p1, p2;
+        split3(ra[p][0], ra[p][1], p0, p1, p2);
+        if constexpr (buf != 0) {
+          p0 ^= 0x80008000u;
+          p1 ^= 0x80008000u;
+          p2 ^= 0x80008000u;
+        }
+        *reinterpret_cast<u32x4*>(&As[0][buf][arow + A_ROWS * p][aq * 8]) = p0;
+        *reinterpret_cast<u32x4*>(&As[1][buf][arow + A_ROWS * p][aq * 8]) = p1;
+        *reinterpret_cast<u32x4*>(&As[2][buf][arow + A_ROWS * p][aq * 8]) = p2;
+      }
+#pragma unroll
+    for (int p = 0; p < B_PASS; ++p)
+      if (brow + B_ROWS * p < WBKX) {
+        u32x4 p0, p1, p2;
+        split3(rb[p][0], rb[p][1], p0, p1, p2);
+        *reinterpret_cast<u32x4*>(&Bs[0][buf][brow + B_ROWS * p][bq * 8]) = p0;
+        *reinterpret_cast<u32x4*>(&Bs[1][buf][brow + B_ROWS * p][bq * 8]) = p1;
+        *reinterpret_cast<u32x4*>(&Bs[2][buf][brow + B_ROWS * p][bq * 8]) = p2;
+      }
+  };
+  // one K-tile: request the next tile, multiply the one in LDS buffer CUR (even tiles -> acc, odd tiles -> acc2), stage the next
+  auto step = [&](auto CUR, int kt) {
+    constexpr int cur = decltype(CUR)::value;
+    const bool more = (kt + 1) < nkt;
+    if (more) load_tile(kt + 1);
+#pragma unroll
+    for (int ks = 0; ks < WBKX / 16; ++ks) {
+      bf16x8w af[3][TM], bfr[3][TN];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[pl][i] = tr_fragment(&As[pl][cur][16 * ks + 8 * hk + tq][wm + 32 * i + cb + 4 * tp], LDA);
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) bfr[pl][jn] = tr_fragment(&Bs[pl][cur][16 * ks + 8 * hk + tq][wn + 32 * jn + cb + 4 * tp], LDB);
+      }
+#pragma unroll
+      for (int pq = 2; pq >= 0; --pq)
+#pragma unroll
+        for (int pa = 0; pa <= pq; ++pa)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn) {
+              if constexpr (cur != 0)
+                acc2[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa][i], bfr[pq - pa][jn], acc2[i][jn], 0, 0, 0);
+              else
+                acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa][i], bfr[pq - pa][jn], acc[i][jn], 0, 0, 0);
+            }
+    }
+    if (more) store_tile(std::integral_constant<int, cur ^ 1>{});
+    __syncthreads();
+  };
+
+  if (nkt > 0) {
+    load_tile(0);
+    store_tile(std::integral_constant<int, 0>{});
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nkt; kt += 2) {
+    step(std::integral_constant<int, 0>{}, kt);
+    if (kt + 1 < nkt) step(std::integral_constant<int, 1>{}, kt + 1);
+  }
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) acc[i][jn] -= acc2[i][jn];
+  int col[TN];
+#pragma unroll
+  for (int jn = 0; jn < TN; ++jn) {
+    const int jj = j0 + wn + jn * 32 + lr;
+    const int tap = fast_div(jj, a.ci, a.inv_ci);
+    col[jn] = jj < a.J ? tap * a.ci_full + a.c_off + (jj - tap * a.ci) : -1;
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int co = co0 + wm + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
+      if (co >= a.co) continue;
+#pragma unroll
+      for (int jn = 0; jn < TN; ++jn) {
+        if (col[jn] >= 0) {
+          float* dst = a.dw + (size_t)co * a.J_ld + col[jn];
+          if (a.use_atomic) atomicAdd(dst, acc[i][jn][v]);
+          else *dst = acc[i][jn][v];
+        }
+      }
+    }
+}
+
+// blocks of an X3 launch: the MFMA phase of a split is ~2.5x shorter than on the fp32 pipe, the fp32 atomics of the partial tiles
+// are not -- fewer, longer splits than launch_wgrad's 3072 (UDASEG_WGRAD_X3_BLOCKS; sweep in profiles/r04_wgrad_x3.txt)
+template <int BMW, int BNW, int WAVES_M, int WAVES_N>
+static int launch_wgrad_x3(WgradArgs a, int accumulate, hipStream_t s) {
+  const int tiles = cdiv(a.co, BMW) * cdiv(a.J, BNW);
+  static int target = -1;
+  if (target < 0) {
+    const char* e = getenv("UDASEG_WGRAD_X3_BLOCKS");
+    target = e ? atoi(e) : 1024;
+    if (target < 64) target = 1024;
+  }
+  int splits = cdiv(target, tiles);
+  const int max_splits = cdiv(a.M, 256);
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  if (splits > 65535) splits = 65535;
+  const int kchunk = cdiv(cdiv(a.M, splits), WBKX) * WBKX;
+  splits = cdiv(a.M, kchunk);
+  a.kchunk = kchunk;
+  a.use_atomic = (splits > 1 || accumulate) ? 1 : 0;
+  if (a.use_atomic && !accumulate) {
+    if (a.J != a.J_ld) {
+      set_error("conv2d_wgrad_part: a channel slice of dW must be accumulated onto a caller-zeroed gradient");
+      return UDASEG_E_BADARG;
+    }
+    hipError_t e = hipMemsetAsync(a.dw, 0, (size_t)a.co * a.J * sizeof(float), s);
+    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(dw)");
+  }
+  dim3 grid((unsigned)tiles, (unsigned)splits), block(256);
+  a.xcd_tiles = a.xcd_splits = 0;
+  constexpr int b_rows = 256 / (BNW / 8);
+  const long long xb = (long long)a.M / (a.ho * a.wo) * (a.up ? (a.hi >> 1) * (a.wi >> 1) : a.hi * a.wi) * a.ci * 4,
+                  dyb = (long long)a.M * a.co * 4;
+  static int generic = -1;
+  if (generic < 0) generic = getenv("UDASEG_WGRAD_GENERIC") != nullptr ? 1 : 0;
+  a.row_uniform = !(g_opt_generic_gather >= 0 ? g_opt_generic_gather : generic) && a.wo % b_rows == 0 && a.ci % 8 == 0 && a.co % 8 == 0 &&
+                  xb <= (1LL << 30) && dyb <= (1LL << 30);
+  a.x_bytes = (unsigned)xb;
+  a.dy_bytes = (unsigned)dyb;
+  hipEvent_t ev = kprof_begin(s);
+  if (a.row_uniform)
+    hipLaunchKernelGGL((conv_wgrad_x3_kernel<BMW, BNW, WAVES_M, WAVES_N, true>), grid, block, 0, s, a);
+  else
+    hipLaunchKernelGGL((conv_wgrad_x3_kernel<BMW, BNW, WAVES_M, WAVES_N, false>), grid, block, 0, s, a);
+  static int kidx[2] = {-1, -1};
+  int& kid = kidx[a.row_uniform ? 1 : 0];
+  if (kid < 0) {
+    char nm[96];
+    snprintf(nm, sizeof(nm), "conv_wgrad_x3_kernel<%d, %d, %d, %d, %s>", BMW, BNW, WAVES_M, WAVES_N, a.row_uniform ? "true" : "false");
+    kid = kprof_id(nm);
+  }
+  kprof_end(kid, ev, s, 2.0 * (double)a.M * a.co * a.J);
+  UDASEG_LAUNCH_CHECK("conv_wgrad_x3 launch");
+  return UDASEG_OK;
+}
+
 template <int BMW, int BNW, int WAVES_M, int WAVES_N>
 static int launch_wgrad(WgradArgs a, int accumulate, hipStream_t s, bool bf16 = false) {
   const int tiles = cdiv(a.co, BMW) * cdiv(a.J, BNW);
@@ -657,6 +1000,15 @@ static int launch_wgrad(WgradArgs a, int accumulate, hipStream_t s, bool bf16 = 
 
 using namespace udaseg;
 
+static bool wgrad_x3_on() {      // UDASEG_WGRAD_X3=0 (A/B) or UDASEG_F32_SPLIT=0: the fp32-pipe kernel
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("UDASEG_WGRAD_X3");
+    v = (e && atoi(e) == 0) ? 0 : 1;
+  }
+  return v != 0 && udaseg::f32_split_enabled();
+}
+
 // One implementation behind the four entry points.  src_c / c_off / up describe a channel slice of dW (WgradArgs::ci_full):
 // the whole gradient is src_c == d->ci, c_off == 0, up == 0.
 static int conv2d_wgrad_impl(const udaseg_conv_desc* d, const void* x, int src_c, int c_off, int up, const void* dy, float* dw,
@@ -712,6 +1064,10 @@ static int conv2d_wgrad_impl(const udaseg_conv_desc* d, const void* x, int src_c
     rc = launch_small_wgrad(static_cast<const float*>(x), static_cast<const float*>(dy), dw, d->n, d->hi, d->wi, d->ci, d->co,
                             accumulate, st, up);
   // (fp32: the 128 x 64 tile buys nothing -- 0.449 against 0.433 ms per cfg 2 step for the seven layers left here)
+  // X3: per call, us, fp32 pipe / X3 (bench.py --layer-table, cfg 2, profiles/r04_igemm_x3.txt): 3x3 / stride 2 74 / 69, 69 / 58, 66 / 72;
+  // 1x1 / stride 2 unchanged; the 7x7 stem (4 padded channels: two gathers per 8-wide piece, generic loop) 174 / 215 -- it stays on the
+  // fp32 pipe.  What the split buys here is mostly the error (sign-alternated accumulators: l2 2.9e-7 against 3.5e-7 of the fp32 pipe)
+  else if (d->co > 32 && src_c % 8 == 0 && d->co % 8 == 0 && wgrad_x3_on()) rc = launch_wgrad_x3<64, 64, 2, 2>(a, accumulate, st);
   else if (d->co > 32) rc = launch_wgrad<64, 64, 2, 2>(a, accumulate, st);
   else rc = launch_wgrad<32, 128, 1, 4>(a, accumulate, st);
   prof_end(1, st, udaseg_conv_flops(&dp), 2, &dp);

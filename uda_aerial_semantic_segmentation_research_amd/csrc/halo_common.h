@@ -1,5 +1,7 @@
 // Pieces shared by the halo-resident convolution kernels (conv_halo_bf16.hip, conv_halo_f32x3.hip).
 #pragma once
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace udaseg {
@@ -87,6 +89,35 @@ __device__ __forceinline__ void split3(const u32x4 lo, const u32x4 hi, u32x4& p0
     p1[e] = m;
     p2[e] = cvt_pk_bf16(a, b);
   }
+}
+
+// four values (one 16-byte fp32 piece -> three 8-byte bf16x4 pieces): the shared implicit-GEMM kernels stage 16 bytes per thread and row
+__device__ __forceinline__ void split3_4(const f32x4 v, u32x2& p0, u32x2& p1, u32x2& p2) {
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    float a = v[2 * e], b = v[2 * e + 1];
+    const unsigned h = cvt_pk_bf16(a, b);
+    a = sub_f32(a, h << 16);
+    b = sub_f32(b, h & 0xffff0000u);
+    const unsigned m = cvt_pk_bf16(a, b);
+    a = sub_f32(a, m << 16);
+    b = sub_f32(b, m & 0xffff0000u);
+    p0[e] = h;
+    p1[e] = m;
+    p2[e] = cvt_pk_bf16(a, b);
+  }
+}
+
+// UDASEG_F32_SPLIT=0: every fp32 layer stays on the fp32-MFMA kernels (A/B, cross-check); udaseg_set_option(UDASEG_OPT_F32_SPLIT)
+// overrides it for the shared-source kernels that ask here
+inline bool f32_split_enabled() {
+  if (g_opt_f32_split >= 0) return g_opt_f32_split != 0;
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("UDASEG_F32_SPLIT");
+    v = (e && atoi(e) == 0) ? 0 : 1;
+  }
+  return v != 0;
 }
 
 // f64 partial-sum scratch of launches with more than 1024 blocks (udaseg_set_stats_scratch): the current device's, when it holds

@@ -629,6 +629,11 @@ def set_generic_gather(value):
     check(ops.udaseg_set_option(0, int(value)), "set_option")
 
 
+def set_f32_split(value):
+    """0: the shared-source fp32 kernels stay on the fp32 matrix pipe; 1: three-term bf16 split allowed; -1: environment."""
+    check(ops.udaseg_set_option(1, int(value)), "set_option")
+
+
 def prof_enable(on):
     check(ops.udaseg_prof_enable(int(on)))
 
