@@ -38,3 +38,12 @@ def six_products(a, b):
 def bf16_bits(t):
     """The 16 stored bits of bf16-representable fp32 values."""
     return (np.ascontiguousarray(t, dtype=np.float32).view(np.uint32) >> 16).astype(np.uint16)
+
+
+def negated_groups(nk16):
+    """The (16-channel chunk, dx) groups G = 3 * chunk + dx of a 3x3 layer's K loop that csrc/conv_halo_f32x3.hip multiplies with
+    negated weights on a negated accumulator (csrc/halo_common.h::f3_negated_groups: the bf16 MFMA adder truncates toward minus
+    infinity; + - - + over the quarter points cancels most of that bias).  Returns range(q1, q3)."""
+    ng = 3 * nk16
+    q1 = (ng + 2) // 4
+    return range(q1, ng - q1)

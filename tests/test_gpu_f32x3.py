@@ -81,6 +81,7 @@ def pack3(K, wt):
 
 def test_three_term_split_is_exact(K):
     """plane0 + plane1 + plane2 == the fp32 weight, bit for bit, across 60 binades (read back through the packing's layout)."""
+    from oracle.f32x3_ref import negated_groups
     g = torch.Generator().manual_seed(5)
     co, ci = 32, 16
     wt = torch.randn(co, ci, 3, 3, generator=g) * torch.exp2(torch.randint(-30, 30, (co, ci, 3, 3), generator=g).float())
@@ -95,6 +96,8 @@ def test_three_term_split_is_exact(K):
         for dy in range(3):
             got = total[0, dx, 0, dy]                            # [lane][j] = W[n = lane % 32][dy][dx][k = 8 * (lane // 32) + j]
             want = torch.stack([w[n_idx[l], 8 * k_half[l]:8 * k_half[l] + 8, dy, dx] for l in range(64)])
+            if dx in negated_groups(1):                          # one 16-channel chunk: groups G = dx; [q1, q3) hold -W
+                want = -want
             assert torch.equal(got, want), (dx, dy)
     # magnitudes: |plane1| <= 2^-8 |w|, |plane2| <= 2^-16 |w| (round to nearest: half a unit of the term above)
     p = wf.view(3, nf).float().cpu().abs()
@@ -328,7 +331,7 @@ def test_wgrad_halo_f32x3_fused_decoder_input(K, n, h, w, ca, cs, co):
 def test_packed_planes_equal_the_oracle_split_bit_for_bit(K):
     """The device split (csrc/halo_common.h::split3, here through the weight packer) against oracle/f32x3_ref.py::split3."""
     import numpy as np
-    from oracle.f32x3_ref import bf16_bits, split3
+    from oracle.f32x3_ref import bf16_bits, negated_groups, split3
     g = torch.Generator().manual_seed(21)
     co, ci = 64, 48
     wt = torch.randn(co, ci, 3, 3, generator=g) * torch.exp2(torch.randint(-40, 40, (co, ci, 3, 3), generator=g).float())
@@ -344,6 +347,8 @@ def test_packed_planes_equal_the_oracle_split_bit_for_bit(K):
                 for dy in range(3):
                     for dx in range(3):
                         ref = np.stack([want[32 * nb + (l & 31), 16 * k16 + 8 * (l >> 5):16 * k16 + 8 * (l >> 5) + 8, dy, dx] for l in lane])
+                        if 3 * k16 + dx in negated_groups(3):      # these groups are stored as -W (sign bit of every term)
+                            ref = ref ^ np.uint16(0x8000)
                         assert np.array_equal(got[pl, nb, dx, k16, dy], ref), (pl, nb, k16, dy, dx)
 
 

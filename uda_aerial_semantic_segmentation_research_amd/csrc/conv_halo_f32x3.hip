@@ -59,6 +59,7 @@ struct F3Args {
   int bnb_act;
   float bnb_slope;
   int ntx, nty, ncb, nk16;
+  int q1, q3;           // (chunk, dx) groups [q1, q3) run on negated weights and a negated accumulator (halo_common.h f3_negated_groups)
   unsigned x_bytes, x2_bytes, w_plane_bytes, y_bytes, y2_bytes, bnb_bytes;
   unsigned long long* timeline;   // diagnosis (udaseg_debug_set_timeline; stamped twin of the wave-specialised kernel only)
 };
@@ -228,6 +229,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_f32x3_kernel(const F3
     for (int dx = 0; dx < 3; ++dx) {
       store_w(gbuf);
       __syncthreads();               // this group's weights (and, at dx == 0, the chunk's halo) are visible
+      if (3 * c + dx == a.q1 || 3 * c + dx == a.q3) {
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) acc[r] = -acc[r];
+      }
       if (dx < 2) load_w(c, dx + 1);
       else if (c + 1 < nchunk) load_w(c + 1, 0);
       if (dx == 0 && c + 1 < nchunk) load_chunk(c + 1);
@@ -484,6 +489,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_f32x3_ws_kernel(const F3Args a
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) {
         const char* wb = wlds + ((3 * c + dx) & 1) * C::LDS_WBUF + wrd;
+        if (3 * c + dx == a.q1 || 3 * c + dx == a.q3) {
+#pragma unroll
+          for (int r = 0; r < RPW; ++r) acc[r] = -acc[r];
+        }
         u32x4 bf[3][3];
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
@@ -558,8 +567,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_f32x3_ws_kernel(const F3Args a
 // Wsrc[n = 32 nb + (lane & 31)][tap][k = 16 k16 + 8 (lane >> 5) + j].  Wsrc is [N][9][K] fp32: the OHWI weights (forward) or the
 // dgrad packing [ci][taps][co] with the window flipped (data gradient).
 // table row (int32 x 6): {mode, src element offset, dst element offset (plane 0), N, K, KS = 3}; plane stride = frag_elems(N, K, 3)
+// The fragments of the (k16, dx) groups [q1, q3) carry -W (halo_common.h f3_negated_groups).
 __global__ void pack_frag_batched_f32x3_kernel(const float* __restrict__ w32, const float* __restrict__ wt32,
-                                               __bf16* __restrict__ packed, const int* __restrict__ table) {
+                                               __bf16* __restrict__ packed, const int* __restrict__ table, int signs) {
   const int* e = table + 6 * blockIdx.y;
   const int mode = e[0], N = e[3], K = e[4], KS = e[5];
   const float* src = (mode ? wt32 : w32) + e[1];
@@ -567,6 +577,8 @@ __global__ void pack_frag_batched_f32x3_kernel(const float* __restrict__ w32, co
   const int T = KS * KS, nb = (N + 31) >> 5, nk16 = (K + 15) >> 4;
   const long long total = (long long)nb * KS * nk16 * KS * 64;     // one 16-byte item per (fragment, lane) per plane
   const long long plane = total * 8;
+  int q1 = 0, q3 = 0;
+  if (signs) f3_negated_groups(nk16, q1, q3);
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int lane = (int)(i & 63);
     long long f = i >> 6;
@@ -586,6 +598,11 @@ __global__ void pack_frag_batched_f32x3_kernel(const float* __restrict__ w32, co
     }
     u32x4 p0, p1, p2;
     split3(lo, hi, p0, p1, p2);
+    if (KS == 3 && 3 * kk + dx >= q1 && 3 * kk + dx < q3) {       // the negated groups of the kernels' K loop
+      p0 ^= 0x80008000u;
+      p1 ^= 0x80008000u;
+      p2 ^= 0x80008000u;
+    }
     *reinterpret_cast<u32x4*>(dst + i * 8) = p0;
     *reinterpret_cast<u32x4*>(dst + plane + i * 8) = p1;
     *reinterpret_cast<u32x4*>(dst + 2 * plane + i * 8) = p2;
@@ -607,6 +624,8 @@ static int launch_f3_ws_t(F3Args a, hipStream_t s, double flops) {
   a.nty = cdiv(a.h, C::TH);
   a.ncb = cdiv(a.co, 32 * C::WN);
   a.nk16 = (a.ci + 15) / 16;
+  a.q1 = a.q3 = -1;
+  if (f3_signs_on()) f3_negated_groups(a.nk16, a.q1, a.q3);
   const long long blocks = (long long)a.n * a.nty * a.ntx * a.ncb;
   if (blocks <= 0) return UDASEG_OK;
   a.sscr = nullptr;
@@ -655,6 +674,8 @@ static int launch_f3_t(F3Args a, hipStream_t s, double flops) {
   a.nty = cdiv(a.h, C::TH);
   a.ncb = cdiv(a.co, 32 * WN);
   a.nk16 = (a.ci + 15) / 16;
+  a.q1 = a.q3 = -1;
+  if (f3_signs_on()) f3_negated_groups(a.nk16, a.q1, a.q3);
   const long long blocks = (long long)a.n * a.nty * a.ntx * a.ncb;
   if (blocks <= 0) return UDASEG_OK;
   a.sscr = nullptr;
@@ -751,7 +772,7 @@ extern "C" int udaseg_pack_frag_batched_f32x3(const float* w32, const float* wt3
                                               void* stream) {
   UDASEG_CHECK_ARG(packed && table && entries > 0 && (w32 || wt32), "pack_frag_batched_f32x3: NULL pointer / no entries");
   hipLaunchKernelGGL(pack_frag_batched_f32x3_kernel, dim3(64, (unsigned)entries), dim3(256), 0, as_stream(stream), w32, wt32,
-                     static_cast<__bf16*>(packed), table);
+                     static_cast<__bf16*>(packed), table, f3_signs_on() ? 1 : 0);
   UDASEG_LAUNCH_CHECK("pack_frag_batched_f32x3 launch");
   return UDASEG_OK;
 }

@@ -108,6 +108,26 @@ __device__ __forceinline__ void split3_4(const f32x4 v, u32x2& p0, u32x2& p1, u3
   }
 }
 
+// Sign pattern of the halo-resident three-term kernels (conv_halo_f32x3.hip).  v_mfma_f32_32x32x16_bf16 TRUNCATES its sum toward minus
+// infinity where the fp32 MFMA rounds to nearest (measured, tools/x3_bias_check.py: mean signed error -3.8e-8 of mean |y| on a 64-channel
+// 3x3 layer, 1e-10 on the fp32 pipe).  A sum accumulated as -y is biased the other way, so the K loop of G = 3 x (16-channel chunks)
+// (chunk, dx) groups runs + - - +: the groups [q1, q3) are multiplied with NEGATED weights (the packer flips their sign bits, nothing
+// at run time) on an accumulator negated at q1 and again at q3 -- two 16-register sign flips per wave and kernel.  The partial sum grows
+// like sqrt(k), the truncation step with it: quarter points leave ~5 % of the bias of a long loop (30 % at 32 channels).
+__host__ __device__ inline void f3_negated_groups(int nk16, int& q1, int& q3) {
+  const int ng = 3 * nk16;
+  q1 = (ng + 2) / 4;
+  q3 = ng - q1;
+}
+inline bool f3_signs_on() {       // UDASEG_F3_SIGNS=0 (A/B, bias measurements): every group positive -- read by the packer AND the kernels
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("UDASEG_F3_SIGNS");
+    v = (e && atoi(e) == 0) ? 0 : 1;
+  }
+  return v != 0;
+}
+
 // UDASEG_F32_SPLIT=0: every fp32 layer stays on the fp32-MFMA kernels (A/B, cross-check); udaseg_set_option(UDASEG_OPT_F32_SPLIT)
 // overrides it for the shared-source kernels that ask here
 inline bool f32_split_enabled() {
