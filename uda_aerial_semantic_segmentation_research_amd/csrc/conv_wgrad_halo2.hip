@@ -142,10 +142,10 @@ __device__ __forceinline__ void wgrad_h2_role(const WgradH2Args& a, char* smem, 
       }
     }
   };
-  auto store_piece = [&](char* dst, int plane_bytes, const u32x4 (&v)[C::LPP]) {
+  auto store_piece = [&](char* dst, int plane_bytes, const u32x4 (&v)[C::LPP], unsigned sgn = 0u) {
     if constexpr (PL == 3) {
       u32x4 p0, p1, p2;
-      split3(v[0], v[C::LPP - 1], p0, p1, p2);
+      split3(v[0] ^ sgn, v[C::LPP - 1] ^ sgn, p0, p1, p2);      // sgn = 0x80000000: the terms of -v are minus the terms of v
       *reinterpret_cast<u32x4*>(dst) = p0;
       *reinterpret_cast<u32x4*>(dst + plane_bytes) = p1;
       *reinterpret_cast<u32x4*>(dst + 2 * plane_bytes) = p2;
@@ -153,7 +153,13 @@ __device__ __forceinline__ void wgrad_h2_role(const WgradH2Args& a, char* smem, 
       *reinterpret_cast<u32x4*>(dst) = v[0];
     }
   };
-  auto store_tile = [&](int bo) {          // bo: byte offset of the LDS buffer
+  // fp32 (PL == 3): the tiles [q1, q3) of this block's sequence are staged as -dy and accumulated on a negated accumulator, + - - +
+  // like the forward kernels' K loop (halo_common.h f3_negated_groups: the bf16 MFMA adder truncates toward minus infinity, and a
+  // weight gradient sums ~1000 pixels per block on top of the atomics)
+  const int nseq = split < a.ntiles ? (a.ntiles - split + a.P - 1) / a.P : 0;
+  const int sq1 = PL == 3 ? (nseq + 2) / 4 : 0, sq3 = PL == 3 ? nseq - sq1 : 0;
+  auto store_tile = [&](int bo, int seq) {          // bo: byte offset of the LDS buffer; seq: the staged tile's place in the sequence
+    const unsigned dsgn = (seq >= sq1 && seq < sq3) ? 0x80000000u : 0u;
     if constexpr (STG) {
 #pragma unroll
       for (int i = 0; i < C::NX; ++i) {
@@ -165,7 +171,7 @@ __device__ __forceinline__ void wgrad_h2_role(const WgradH2Args& a, char* smem, 
       for (int i = 0; i < C::ND; ++i) {
         const int pc = st + i * C::NST;
         const int pix = pc / C::DO, oct = pc % C::DO;
-        if (i < C::ND - 1 || pc < C::DPC) store_piece(Ds + bo + (oct >> 2) * C::DSP + pix * 64 + (oct & 3) * 16, C::DPLANE, sd[i]);
+        if (i < C::ND - 1 || pc < C::DPC) store_piece(Ds + bo + (oct >> 2) * C::DSP + pix * 64 + (oct & 3) * 16, C::DPLANE, sd[i], dsgn);
       }
     }
   };
@@ -194,20 +200,29 @@ __device__ __forceinline__ void wgrad_h2_role(const WgradH2Args& a, char* smem, 
   if constexpr (C::DB) {
     // two buffers: the staging waves split tile t + 1 into the OTHER buffer while every wave's MFMAs read tile t (their vector
     // instructions issue beside the older waves' MFMAs), and request tile t + 2; ONE barrier per tile
-    store_tile(0);
+    store_tile(0, 0);
     if (split + a.P < a.ntiles) load_tile(split + a.P);
     __syncthreads();
   }
-  for (int tile = split; tile < a.ntiles; tile += a.P) {
+  int seq = 0;
+  bool negated = false;
+  for (int tile = split; tile < a.ntiles; tile += a.P, ++seq) {
     if constexpr (TL) t0 = __builtin_amdgcn_s_memtime();
+    if constexpr (PL == 3) {
+      if ((seq >= sq1 && seq < sq3) != negated) {        // uniform; twice per block
+        negated = !negated;
+#pragma unroll
+        for (int t = 0; t < 3 * NDX; ++t) acc[t] = -acc[t];
+      }
+    }
     if constexpr (C::DB) {
       if (tile + a.P < a.ntiles) {
-        store_tile(cur ^ C::BUF);
+        store_tile(cur ^ C::BUF, seq + 1);
         if (tile + 2 * a.P < a.ntiles) load_tile(tile + 2 * a.P);
       }
       if constexpr (TL) t1 = t2 = __builtin_amdgcn_s_memtime();
     } else {
-      store_tile(0);
+      store_tile(0, seq);
       if constexpr (TL) t1 = __builtin_amdgcn_s_memtime();
       __syncthreads();
       if constexpr (TL) t2 = __builtin_amdgcn_s_memtime();
@@ -270,6 +285,10 @@ __device__ __forceinline__ void wgrad_h2_role(const WgradH2Args& a, char* smem, 
     }
   }
 
+  if (negated) {      // a sequence too short for the pattern to close (one or two tiles)
+#pragma unroll
+    for (int t = 0; t < 3 * NDX; ++t) acc[t] = -acc[t];
+  }
   // dW[co][tap][ci] += acc: register v of a tap = one co row, 32 consecutive ci per half-wave (two 128-byte segments per
   // wave-instruction: the full-rate shape of the memory-side float atomics)
   const int ci_g = cib * C::CIB + ciq * 32 + lr;
