@@ -40,6 +40,8 @@ python3 $ROOT/tools/wgrad_timeline.py > $OUT/${TAG}_wgrad_timeline.txt 2>&1
 python3 $ROOT/tools/f3_timeline.py > $OUT/${TAG}_f3_timeline.txt 2>&1
 python3 $ROOT/tools/gemm1x1_probe.py 2>&1 | grep "M=" > $OUT/${TAG}_gemm1x1_probe.txt
 UDASEG_GEMM_1X1=0 python3 $ROOT/tools/gemm1x1_probe.py 2>&1 | grep "M=" > $OUT/${TAG}_gemm1x1_probe_stream_only.txt
+python3 $ROOT/tools/x3_bias_check.py 2>&1 | grep "l2" > $OUT/${TAG}_mfma_bias.txt
+UDASEG_F3_SIGNS=0 python3 $ROOT/tools/x3_bias_check.py 2>&1 | grep "halo" > $OUT/${TAG}_mfma_bias_nosigns.txt
 echo "timelines done"
 # the bf16 legs (cfg 3, cfg 5): single-stream kernel statistics
 UDASEG_SERIAL=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_bf16_cfg3 -- python3 $ROOT/bench.py --steps 5 --warmup 2 \
