@@ -41,7 +41,11 @@ ARITHMETIC_FP32 = ("fp32 tensors, weights, gradients and accumulation.  Stride-1
                    "gradient where the channel counts allow) evaluate each fp32 product on the bf16 matrix pipe from an EXACT "
                    "three-term split of both operands (x = bf16(x) + bf16(x - x0) + bf16(x - x0 - x1); the six products with "
                    "i + j <= 2, fp32 accumulate; what is left out is <= 2^-23 of a product = one fp32 ulp; measured against f64 "
-                   "next to the fp32-MFMA kernels in tests/test_gpu_f32x3.py); every other layer on v_mfma_f32_32x32x2_f32.  "
+                   "next to the fp32-MFMA kernels in tests/test_gpu_f32x3.py).  The strided, 1x1 and 4x4 layers of more than 32 "
+                   "channels take the same split inside the shared implicit-GEMM kernels (round 4); the 7x7 stem's weight gradient, "
+                   "<= 32-channel shared-source launches and the small full-resolution weight gradients stay on "
+                   "v_mfma_f32_32x32x2_f32 / 16x16x4_f32.  The bf16 MFMA adder truncates toward minus infinity (measured): every "
+                   "split kernel runs its K loop + - - + (or alternates accumulators) so that the bias cancels.  "
                    "UDASEG_F32_SPLIT=0 runs everything on the fp32-MFMA kernels (also-leg 'fp32-MFMA kernels only').")
 WORKLOAD_TEXT = {
     "segmentation": "source-only CE train step (zero_grad,fwd,CE,bwd,allreduce,Adam)",
@@ -206,9 +210,10 @@ def build_leg(workload, encoder, dtype, batch, size, classes, dev, rank, world, 
 
 def pipe_of(symbol, dtype):
     """(bf16-MFMA products per counted product, peak TFLOP/s of the pipe the kernel symbol runs on).  The fp32 three-term-split
-    kernels (conv3x3_f32x3*, conv_wgrad_halo_f32x3*, conv_wgrad_h2_kernel<3, ...>) evaluate every fp32 product as SIX bf16 MFMA
+    kernels (conv3x3_f32x3*, conv_wgrad_h2_kernel<3, ...>, conv_wgrad_x3_kernel, conv_igemm_kernel<..., X3 = true>) evaluate every fp32 product as SIX bf16 MFMA
     products: the pipe that bounds them is the bf16 one and the work it does is 6 x the algorithmic FLOPs."""
-    split = "f32x3" in symbol or symbol.startswith("conv_wgrad_h2_kernel<3,")
+    x3_igemm = symbol.startswith("conv_igemm_kernel<") and symbol.count(",") == 7 and symbol.rstrip(">").rstrip().endswith("true")
+    split = "f32x3" in symbol or symbol.startswith("conv_wgrad_h2_kernel<3,") or symbol.startswith("conv_wgrad_x3_kernel") or x3_igemm
     if split:
         return F32X3_MFMA_PRODUCTS, BF16_MFMA_PEAK_TFLOPS
     return 1, (BF16_MFMA_PEAK_TFLOPS if dtype == "bf16" else FP32_MFMA_PEAK_TFLOPS)
@@ -378,9 +383,11 @@ def roofline_leg(step, model, trainer, dtype, psteps=3, layer_table=False, pmc_t
 def also_leg(name, workload, encoder, dtype, batch, size, classes, dev, steps=10, warmup=6, cpu=False, split=True):
     """A short informational leg of another BASELINE config in the same process (N=1 only).  split=False: the fp32 network
     built without the three-term-split kernels (what UDASEG_F32_SPLIT=0 gives)."""
-    from uda_aerial_semantic_segmentation_research_amd import engine as _engine
+    from uda_aerial_semantic_segmentation_research_amd import engine as _engine, kernels as _K
     was_split = _engine.USE_F32_SPLIT
     _engine.USE_F32_SPLIT = was_split and split
+    if not split:
+        _K.set_f32_split(0)            # the shared-source kernels' own three-term mode (conv_igemm X3, conv_wgrad_x3) too
     try:
         step, model, trainer = build_leg(workload, encoder, dtype, batch, size, classes, dev, 0, 1, False)
         dt, ev_ms, loss = timed_region(step, steps, warmup, 1, dev, False)
@@ -388,6 +395,8 @@ def also_leg(name, workload, encoder, dtype, batch, size, classes, dev, steps=10
                             pmc_tag="cfg3" if workload == "adversarial" else ("cfg5" if dtype == "bf16" else "fp32"))
     finally:
         _engine.USE_F32_SPLIT = was_split
+        if not split:
+            _K.set_f32_split(-1)
     value = batch * steps / dt
     gf = CONV_GFLOP_PER_IMAGE.get((workload, encoder, size))
     peak = BF16_MFMA_PEAK_TFLOPS if dtype == "bf16" else FP32_MFMA_PEAK_TFLOPS

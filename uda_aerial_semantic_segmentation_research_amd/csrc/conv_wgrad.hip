@@ -826,7 +826,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(const WgradArgs a) {
 }
 
 // blocks of an X3 launch: the MFMA phase of a split is ~2.5x shorter than on the fp32 pipe, the fp32 atomics of the partial tiles
-// are not -- fewer, longer splits than launch_wgrad's 3072 (UDASEG_WGRAD_X3_BLOCKS; sweep in profiles/r04_wgrad_x3.txt)
+// are not -- fewer, longer splits than launch_wgrad's 3072 (UDASEG_WGRAD_X3_BLOCKS; profiles/r04_igemm_x3.txt: 512 / 1024 / 2048 / 3072 blocks gave the same step)
 template <int BMW, int BNW, int WAVES_M, int WAVES_N>
 static int launch_wgrad_x3(WgradArgs a, int accumulate, hipStream_t s) {
   const int tiles = cdiv(a.co, BMW) * cdiv(a.J, BNW);
