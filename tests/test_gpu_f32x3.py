@@ -418,3 +418,85 @@ def test_shared_source_split_fp32_grade(K, case):
     grade(res[1][0], res[0][0], y_ref, "forward")
     grade(res[1][1], res[0][1], dx_ref, "data gradient")
     grade(res[1][2], res[0][2], dw_ref, "weight gradient", cap=5e-6, k2=1.6)
+
+
+BNIN_CASES = [(2, 40, 72, 16, 16), (1, 33, 50, 16, 24), (2, 24, 64, 32, 16), (1, 20, 36, 16, 32), (8, 128, 128, 16, 16)]
+
+
+@pytest.mark.parametrize("case", BNIN_CASES, ids=["n%d_%dx%d_ci%d_co%d" % c for c in BNIN_CASES])
+@pytest.mark.parametrize("act,slope", [(1, 0.0), (1, 0.2), (0, 0.0)])
+def test_unwritten_batchnorm_activation_fp32(K, case, act, slope):
+    """engine.LazyAct on fp32 (round 4): the forward convolution and the weight gradient that apply act(fma(y, scale, shift)) while
+    they stage y == the same kernels on the activation written out (LazyAct.materialize(): one rounding of the fused multiply-add,
+    what udaseg_bn_apply stores).  Forward and statistics bit for bit (same kernel, same operands after the transform, padding
+    stays zero); weight gradient up to the order of its fold's atomics."""
+    from uda_aerial_semantic_segmentation_research_amd.engine import LazyAct
+    n, h, w, ci, co = case
+    g = torch.Generator().manual_seed(sum(case) + act)
+    y_prev = (torch.randn(n, h, w, ci, generator=g) * 1.5 + 0.3).cuda()
+    sc = (torch.rand(ci, generator=g) + 0.5).cuda()
+    sh = (torch.randn(ci, generator=g) * 0.5).cuda()
+    z = LazyAct(y_prev, sc, sh, act, slope).materialize()
+    wt = torch.randn(co, ci, 3, 3, generator=g) / math.sqrt(9 * ci)
+    wf, _, _, _ = pack3(K, wt)
+    d = K.conv_desc(n, h, w, ci, co, 3, 1, 1)
+    assert K.conv_bnin_ok(d)
+    R = K.bn_replicas()
+    bias = torch.randn(co, generator=g).cuda()
+    outs = []
+    for lazy in (False, True):
+        y = torch.full((n, h, w, co), float("nan"), device="cuda")
+        st = torch.zeros(R * 2 * co, dtype=f64, device="cuda")
+        if lazy:
+            K.conv2d_fwd_frag(d, y_prev, None, wf, bias, y, stats=st, in_scale=sc, in_shift=sh, in_act=act, in_slope=slope)
+        else:
+            K.conv2d_fwd_frag(d, z, None, wf, bias, y, stats=st)
+        outs.append((y, st.view(R, 2, co).sum(0)))
+    assert torch.equal(outs[0][0], outs[1][0]), "forward differs from the forward on the written activation"
+    assert torch.equal(outs[0][1], outs[1][1]), "statistics differ"
+    y_ref = F.conv2d(nchw(z).double(), wt.double(), bias.cpu().double(), padding=1)
+    assert err2(nchw(outs[1][0]), y_ref) <= 1e-6
+    dy = torch.randn(n, h, w, co, generator=g).cuda()
+    dw_z = torch.zeros(co, 3, 3, ci, device="cuda")
+    K.conv2d_wgrad(d, z, dy, dw_z, False)
+    dw_l = torch.full((co, 3, 3, ci), float("nan"), device="cuda")
+    K.conv2d_wgrad_bnin(d, y_prev, sc, sh, act, slope, dy, dw_l, False)
+    dw_ref = torch.nn.grad.conv2d_weight(nchw(z).double(), wt.shape, nchw(dy).double(), padding=1)
+    assert err2(dw_l.cpu().permute(0, 3, 1, 2), dw_ref) <= 2e-6
+    assert err2(dw_l.cpu(), dw_z.cpu().double()) <= 1e-6
+    base = torch.randn(co, 3, 3, ci, generator=g).cuda()
+    dw_a = base.clone()
+    K.conv2d_wgrad_bnin(d, y_prev, sc, sh, act, slope, dy, dw_a, True)
+    assert err2((dw_a - base).cpu(), dw_l.cpu().double()) <= 1e-5
+
+
+def test_network_step_with_and_without_unwritten_activations_fp32(K, monkeypatch):
+    """One r18-Unet training step with the last decoder block's BatchNorm activations unwritten (engine.FUSE_BN_APPLY_F32) against the
+    same step with the stand-alone passes: logits bit for bit (the transform reproduces bn_apply's stores), gradients to atomics order."""
+    from uda_aerial_semantic_segmentation_research_amd import engine
+    from uda_aerial_semantic_segmentation_research_amd.losses import CrossEntropyLoss
+    from uda_aerial_semantic_segmentation_research_amd.unet import Unet
+    K.set_f32_split(-1)
+    torch.manual_seed(3)
+    x = torch.randn(2, 3, 64, 96, device="cuda")
+    yl = torch.randint(0, 23, (2, 64, 96), device="cuda")
+    outs = []
+    for lazy in (True, False):
+        monkeypatch.setattr(engine, "FUSE_BN_APPLY_F32", lazy)
+        torch.manual_seed(11)
+        net = Unet("resnet18", encoder_weights=None, in_channels=3, classes=23).cuda().train()
+        net.debug_keep_tape = True
+        logits = net(x)
+        lazies = sum(isinstance(t, engine.LazyAct) for blk, rec, out in net._last_tape[1] if hasattr(blk, "relu_outputs")
+                     for t in (rec[3], out))
+        assert (lazies >= 2) == lazy, lazies
+        loss = CrossEntropyLoss()(logits, yl)
+        loss.backward()
+        outs.append((logits.detach().clone(), {k: p.grad.detach().clone() for k, p in net.named_parameters()},
+                     {k: b.detach().clone() for k, b in net.named_buffers()}))
+    (la, ga, ba), (lb, gb, bb) = outs
+    assert torch.equal(la, lb), "logits differ"
+    for k in bb:
+        assert torch.equal(ba[k], bb[k]), k            # running statistics
+    worst = max(((ga[k] - gb[k]).norm() / gb[k].norm().clamp_min(1e-30)).item() for k in ga)
+    assert worst <= 2e-5, worst

@@ -205,8 +205,10 @@ int launch_small_conv(const float* x, const float* w, const float* bias, float* 
                       int flip, int accumulate, int act, float slope, double* stats, const float* residual, hipStream_t s,
                       int up = 0);
 bool small_wgrad_applicable(int k, int stride, int pad, int ci, int co, int ntiles);
+// in_scale != null: x is an unwritten BatchNorm activation, act(fma(x, in_scale[c], in_shift[c])) is applied while staging
 int launch_small_wgrad(const float* x, const float* dy, float* dw, int n, int h, int wd, int ci, int co, int accumulate,
-                       hipStream_t s, int up = 0);
+                       hipStream_t s, int up = 0, const float* in_scale = nullptr, const float* in_shift = nullptr,
+                       int in_act = 0, float in_slope = 0.f);
 
 // live launch timing (bench.py roofline leg): per API call (prof_*) and per kernel launch (kprof_*)
 constexpr int PROF_NKERNELS = 24;

@@ -60,6 +60,14 @@ struct F3Args {
   float bnb_slope;
   int ntx, nty, ncb, nk16;
   int q1, q3;           // (chunk, dx) groups [q1, q3) run on negated weights and a negated accumulator (halo_common.h f3_negated_groups)
+  // x is the raw output of a conv + training-mode BatchNorm + activation layer whose activation was never written (round 4,
+  // engine.LazyAct on fp32): the staging applies act(fma(x, in_scale[c], in_shift[c])) -- bn_apply's own fused multiply-add and
+  // coefficients, so the value is bit for bit what the stand-alone pass would have stored -- before the split; padding stays zero.
+  // conv3x3_f32x3_kernel only (<= 32 produced channels), no fused decoder input.  null: x is used as it is.
+  const float* in_scale;
+  const float* in_shift;
+  int in_act;
+  float in_slope;
   unsigned x_bytes, x2_bytes, w_plane_bytes, y_bytes, y2_bytes, bnb_bytes;
   unsigned long long* timeline;   // diagnosis (udaseg_debug_set_timeline; stamped twin of the wave-specialised kernel only)
 };
@@ -193,12 +201,46 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_f32x3_kernel(const F3
       }
     }
   };
-  auto store_chunk = [&]() {
+  const bool XF = a.in_scale != nullptr;                    // uniform: the gathered tensor is an unwritten BatchNorm activation
+  const bool xf_relu = a.in_act == UDASEG_ACT_LEAKY && a.in_slope == 0.f;
+  auto store_chunk = [&](int c) {
+    f32x4 sc0 = {0.f, 0.f, 0.f, 0.f}, sc1 = sc0, sh0 = sc0, sh1 = sc0;
+    if (XF) {                                                // this thread's 8 channels of chunk c (its octet is fixed)
+      const int ch = c * 16 + oct * 8;
+      if (ch < a.ci) {
+        sc0 = *reinterpret_cast<const f32x4*>(a.in_scale + ch);
+        sh0 = *reinterpret_cast<const f32x4*>(a.in_shift + ch);
+        if (ch + 4 < a.ci) {
+          sc1 = *reinterpret_cast<const f32x4*>(a.in_scale + ch + 4);
+          sh1 = *reinterpret_cast<const f32x4*>(a.in_shift + ch + 4);
+        }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < C::NI; ++i) {
       if (i < C::NI - 1 || tid + i * C::NT < C::NPIECE) {
+        u32x4 lo = stage[i][0], hi = stage[i][1];
+        if (XF) {
+          const bool inside = voff[i] != 0x80000000u;        // zero padding is padding of the ACTIVATION: stays zero
+          f32x4 l = __builtin_bit_cast(f32x4, lo), h = __builtin_bit_cast(f32x4, hi);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float t0 = __builtin_fmaf(l[e], sc0[e], sh0[e]), t1 = __builtin_fmaf(h[e], sc1[e], sh1[e]);
+            if (xf_relu) {
+              t0 = t0 > 0.f ? t0 : 0.f;
+              t1 = t1 > 0.f ? t1 : 0.f;
+            } else {
+              t0 = act_apply(t0, a.in_act, a.in_slope);
+              t1 = act_apply(t1, a.in_act, a.in_slope);
+            }
+            l[e] = inside ? t0 : 0.f;
+            h[e] = inside ? t1 : 0.f;
+          }
+          lo = __builtin_bit_cast(u32x4, l);
+          hi = __builtin_bit_cast(u32x4, h);
+        }
         u32x4 p0, p1, p2;
-        split3(stage[i][0], stage[i][1], p0, p1, p2);
+        split3(lo, hi, p0, p1, p2);
         *reinterpret_cast<u32x4*>(smem + soffl[i]) = p0;
         *reinterpret_cast<u32x4*>(smem + C::PLANE + soffl[i]) = p1;
         *reinterpret_cast<u32x4*>(smem + 2 * C::PLANE + soffl[i]) = p2;
@@ -224,7 +266,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_f32x3_kernel(const F3
   load_chunk(0);
   int gbuf = 0;
   for (int c = 0; c < nchunk; ++c) {
-    store_chunk();
+    store_chunk(c);
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) {
       store_w(gbuf);
@@ -750,6 +792,7 @@ static int f3_choice(int h, int w, int n, int gathered, int produced) {
 static int launch_f3(F3Args a, hipStream_t s, double flops) {
   int choice = f3_choice(a.h, a.w, a.n, a.ci, a.co);
   if (choice == 0) choice = a.co <= 32 ? 1 : 6;
+  if (a.in_scale != nullptr) choice = 1;       // the in-staging transform lives in the one-role kernel (host-checked: <= 32 produced channels)
   if (choice == 1) return launch_f3_t<4, 1, 2>(a, s, flops);
   if (choice == 3) return launch_f3_t<2, 2, 2>(a, s, flops);      // 4 x 32 pixels x 64 channels
   if (choice == 4) return launch_f3_t<4, 2, 4>(a, s, flops);      // 16 x 32 pixels x 64 channels, 8 waves
@@ -819,6 +862,37 @@ extern "C" int udaseg_conv2d_fwd_f32x3(const udaseg_conv_desc* d, const float* x
   a.act = act; a.slope = slope; a.stats = stats;
   a.x_bytes = (unsigned)(up_ca > 0 ? (long long)d->n * (d->hi / 2) * (d->wi / 2) * up_ca * 4 : px * d->ci * 4);
   a.x2_bytes = (unsigned)(up_ca > 0 ? px * (d->ci - up_ca) * 4 : 0);
+  a.w_plane_bytes = (unsigned)(udaseg_frag_elems(d->co, d->ci, 3) * 2);
+  a.y_bytes = (unsigned)(px * d->co * 4);
+  hipStream_t st = as_stream(stream);
+  prof_begin(0, st);
+  rc = launch_f3(a, st, udaseg_conv_flops(d));
+  prof_end(0, st, udaseg_conv_flops(d), 0, d);
+  return rc;
+}
+
+extern "C" int udaseg_conv2d_fwd_f32x3_bnin_ok(const udaseg_conv_desc* d) {
+  return d && d->co <= 32 && f3_applicable(d, d->ci, d->co, 0) ? 1 : 0;
+}
+
+extern "C" int udaseg_conv2d_fwd_f32x3_bnin(const udaseg_conv_desc* d, const float* x, const float* in_scale, const float* in_shift,
+                                            int in_act, float in_slope, const void* wfrag3, const float* bias, float* y, int act,
+                                            float slope, double* stats, void* stream) {
+  F3Args a = {};
+  int rc = f3_common(d, a, "conv2d_fwd_f32x3_bnin");
+  if (rc) return rc;
+  UDASEG_CHECK_ARG(x && in_scale && in_shift && wfrag3 && y, "conv2d_fwd_f32x3_bnin: NULL pointer");
+  UDASEG_CHECK_ARG(in_act == UDASEG_ACT_NONE || in_act == UDASEG_ACT_LEAKY, "conv2d_fwd_f32x3_bnin: unknown activation %d", in_act);
+  if (!udaseg_conv2d_fwd_f32x3_bnin_ok(d)) {
+    set_error("conv2d_fwd_f32x3_bnin: geometry not supported (<= 32 produced channels; ask udaseg_conv2d_fwd_f32x3_bnin_ok)");
+    return UDASEG_E_UNSUPPORTED;
+  }
+  const long long px = (long long)d->n * d->hi * d->wi;
+  a.x = x; a.wf = wfrag3; a.bias = bias; a.y = y;
+  a.in_scale = in_scale; a.in_shift = in_shift; a.in_act = in_act; a.in_slope = in_slope;
+  a.ci = d->ci; a.co = d->co;
+  a.act = act; a.slope = slope; a.stats = stats;
+  a.x_bytes = (unsigned)(px * d->ci * 4);
   a.w_plane_bytes = (unsigned)(udaseg_frag_elems(d->co, d->ci, 3) * 2);
   a.y_bytes = (unsigned)(px * d->co * 4);
   hipStream_t st = as_stream(stream);

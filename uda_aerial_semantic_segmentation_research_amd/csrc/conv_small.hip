@@ -52,9 +52,11 @@ struct HaloRegs {
   static constexpr int TOTAL = SH * SH * Q;
   static constexpr int ITER = (TOTAL + 255) / 256;
   f32x4 v[ITER];
+  unsigned inside = 0;     // bit it: piece it of the tile in the registers lies inside the image (issue() only)
 
   // up: the tensor behind x is [n][h/2][w/2][ci] and halo pixel (gy, gx) reads its pixel (gy >> 1, gx >> 1)
   __device__ __forceinline__ void issue(const float* __restrict__ x, int ni, int ty0, int tx0, int h, int w, int ci, int up = 0) {
+    inside = 0;
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
       const int idx = threadIdx.x + 256 * it;
@@ -65,8 +67,30 @@ struct HaloRegs {
       if (idx < TOTAL && (unsigned)gy < (unsigned)h && (unsigned)gx < (unsigned)w && cq * 4 < ci) {
         const size_t pix = up ? (size_t)(ni * (h >> 1) + (gy >> 1)) * (w >> 1) + (gx >> 1) : (size_t)(ni * h + gy) * w + gx;
         t = *reinterpret_cast<const f32x4*>(x + pix * (size_t)ci + cq * 4);
+        inside |= 1u << it;
       }
       v[it] = t;
+    }
+  }
+  // The tile in the registers is the RAW output of a conv + BatchNorm + activation layer whose activation was never written
+  // (engine.LazyAct on fp32): apply act(fma(v, scale[c], shift[c])) -- bn_apply's own arithmetic -- to the pieces inside the image
+  // (padding is padding of the activation and stays zero).  A thread's channel quad is the same for every piece (256 % Q == 0).
+  __device__ __forceinline__ void transform(const float* __restrict__ scale, const float* __restrict__ shift, int ci, int act, float slope) {
+    static_assert(256 % Q == 0, "one channel quad per thread");
+    const int cq = threadIdx.x % Q;
+    f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = sc;
+    if (cq * 4 < ci) {
+      sc = *reinterpret_cast<const f32x4*>(scale + cq * 4);
+      sh = *reinterpret_cast<const f32x4*>(shift + cq * 4);
+    }
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const bool in = (inside >> it) & 1u;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float t = act_apply(__builtin_fmaf(v[it][e], sc[e], sh[e]), act, slope);
+        v[it][e] = in ? t : 0.f;
+      }
     }
   }
   // HP = floats per halo pixel in LDS (>= CIP).  The forward kernel pads a pixel to CIP + 4 floats: its 16-byte fragment
@@ -318,6 +342,10 @@ struct SmallWgradArgs {
   int n, h, w, ci, co;
   int up;            // 1: x is [n][h/2][w/2][ci] behind a nearest x2 up-sampling
   int tiles_x, tiles_y, ntiles;
+  const float* in_scale;   // x is an unwritten BatchNorm activation (HaloRegs::transform); null: x is used as it is
+  const float* in_shift;
+  int in_act;
+  float in_slope;
 };
 
 template <int G, int CO_T>
@@ -350,6 +378,7 @@ __global__ __launch_bounds__(256) void conv3x3_small_wgrad_kernel(const SmallWgr
   }
   for (; tile < a.ntiles; tile += gridDim.x) {
     __syncthreads();  // previous tile's readers are done
+    if (a.in_scale != nullptr) hx.transform(a.in_scale, a.in_shift, a.ci, a.in_act, a.in_slope);      // uniform
     hx.commit(halo);
     hd.commit(dyt);
     __syncthreads();
@@ -480,9 +509,10 @@ bool small_wgrad_applicable(int k, int stride, int pad, int ci, int co, int ntil
 }
 
 int launch_small_wgrad(const float* x, const float* dy, float* dw, int n, int h, int wd, int ci, int co, int accumulate,
-                       hipStream_t s, int up) {
+                       hipStream_t s, int up, const float* in_scale, const float* in_shift, int in_act, float in_slope) {
   SmallWgradArgs a = {};
   a.up = up;
+  a.in_scale = in_scale; a.in_shift = in_shift; a.in_act = in_act; a.in_slope = in_slope;
   const int dev = current_device();
   if (dev < 0 || g_workspace[dev] == nullptr) {
     set_error("small wgrad: no workspace bound to the current device");

@@ -1080,6 +1080,32 @@ extern "C" int udaseg_conv2d_wgrad(const udaseg_conv_desc* d, const float* x, co
   return conv2d_wgrad_impl(d, x, d->ci, 0, 0, dy, dw, accumulate, stream, 0);
 }
 
+// fp32, the gathered operand an unwritten BatchNorm activation (engine.LazyAct on fp32, round 4): the <= 32-channel full-resolution
+// layers only (conv3x3_small_wgrad_kernel applies the transform while it commits its halo tile)
+extern "C" int udaseg_conv2d_wgrad_bnin_ok(const udaseg_conv_desc* d) {
+  return d && d->kh == 3 && d->kw == 3 && d->n > 0 && d->hi > 0 && d->wi > 0 && d->ci % 4 == 0 && d->co % 4 == 0 &&
+                 small_wgrad_applicable(d->kh, d->stride, d->pad, d->ci, d->co, d->n * cdiv(d->hi, 16) * cdiv(d->wi, 16))
+             ? 1
+             : 0;
+}
+
+extern "C" int udaseg_conv2d_wgrad_bnin(const udaseg_conv_desc* d, const float* x, const float* in_scale, const float* in_shift,
+                                        int in_act, float in_slope, const float* dy, float* dw, int accumulate, void* stream) {
+  UDASEG_CHECK_ARG(d && x && in_scale && in_shift && dy && dw, "conv2d_wgrad_bnin: NULL pointer");
+  UDASEG_CHECK_ARG(in_act == UDASEG_ACT_NONE || in_act == UDASEG_ACT_LEAKY, "conv2d_wgrad_bnin: unknown activation %d", in_act);
+  UDASEG_CHECK_ARG(d->ho == d->hi && d->wo == d->wi, "conv2d_wgrad_bnin: stride-1 'same' convolutions only");
+  if (!udaseg_conv2d_wgrad_bnin_ok(d)) {
+    set_error("conv2d_wgrad_bnin: geometry not supported (3x3 / stride 1, <= 32 channels on either side, workspace bound; ask "
+              "udaseg_conv2d_wgrad_bnin_ok)");
+    return UDASEG_E_UNSUPPORTED;
+  }
+  hipStream_t st = as_stream(stream);
+  prof_begin(1, st);
+  const int rc = launch_small_wgrad(x, dy, dw, d->n, d->hi, d->wi, d->ci, d->co, accumulate, st, 0, in_scale, in_shift, in_act, in_slope);
+  prof_end(1, st, udaseg_conv_flops(d), 2, d);
+  return rc;
+}
+
 extern "C" int udaseg_conv2d_wgrad_bf16(const udaseg_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate,
                                         void* stream) {
   UDASEG_CHECK_ARG(d != nullptr, "conv2d_wgrad_bf16: NULL desc");

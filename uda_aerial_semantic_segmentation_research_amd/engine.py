@@ -52,6 +52,11 @@ FUSE_BN_APPLY = os.environ.get("UDASEG_FUSE_BN_APPLY", "0") != "0"
 # (measured, profiles/r03_bn_fusion_ab.txt: cfg 3 / cfg 5 images/s off 987.8 / 395.3, everywhere ("1") 990.7 / 397.9, 1x1
 # consumers only 993.5 / 399.3; wgrad 256 -> 256 at 48^2 92 -> 136 us with the transform in its gather).
 FUSE_BN_APPLY_1X1_ONLY = os.environ.get("UDASEG_FUSE_BN_APPLY", "0") == "2"
+# fp32 storage (round 4): the same for the <= 32-channel full-resolution decoder layers, whose stand-alone bn_apply pass moves
+# 268 MB per layer at 8 x 512^2: the consumer's forward (one-role split kernel) and weight gradient (small-channel direct kernel)
+# apply act(fma(y, scale, shift)) while they stage; the producer's BatchNorm backward re-evaluates its mask from y anyway.
+# UDASEG_FUSE_BN_APPLY_F32=0: always the stand-alone pass (A/B, cross-check; tests flip the module attribute)
+FUSE_BN_APPLY_F32 = os.environ.get("UDASEG_FUSE_BN_APPLY_F32", "1") != "0"
 
 
 # bf16 storage: weight gradients of the stride-1 3x3 layers with channel counts that are multiples of 64 on the halo-resident
@@ -426,7 +431,7 @@ class Plan:
         if training:
             self.stats = torch.zeros(max(nbn, 2) * self.R, dtype=torch.float64, device=dev)  # [R][sum | sumsq] per BN
             self.saved_stats = torch.empty(max(nbn, 2), dtype=torch.float32, device=dev)  # [mean | rstd] per BN
-            self.coefs = torch.empty(max(nbn, 2), dtype=torch.float32, device=dev) if self.bf16 else None  # [scale | shift] of lazy BNs
+            self.coefs = torch.empty(max(nbn, 2), dtype=torch.float32, device=dev)  # [scale | shift] of lazy BNs
         else:
             # inference: BatchNorm is folded into the conv weights (scratch refreshed per forward: one pass over the weights)
             self.fold_w = torch.empty_like(net._arena)
@@ -496,7 +501,11 @@ class Plan:
         d = K.conv_desc(n, h, w, ci, conv.cout_p, conv.k, conv.stride, conv.pad)
         y = torch.empty((n, d.ho, d.wo, conv.cout_p), device=x.device, dtype=out_dtype or self.adt)
         wf = self.wfrag(conv, d)
-        if wf is not None:
+        if isinstance(x, LazyAct):
+            assert wf is not None, "a LazyAct input needs the fragment kernels (decided by the producer)"
+            K.conv2d_fwd_frag(d, x.y, None, wf, self.b(conv) if conv.bias is not None else None, y, act, slope,
+                              in_scale=x.scale, in_shift=x.shift, in_act=x.act, in_slope=x.slope, st=self.st)
+        elif wf is not None:
             K.conv2d_fwd_frag(d, x, None, wf, self.b(conv) if conv.bias is not None else None, y, act, slope, st=self.st)
         else:
             K.conv2d_fwd(d, x, self.w(conv), self.b(conv) if conv.bias is not None else None, y, act, slope, False, self.st)
@@ -533,6 +542,15 @@ class Plan:
         """May BatchNorm + activation of this [n, ho, wo, c] output stay unwritten?  Only when its single consumer runs on the
         bf16-first kernels in BOTH directions (the forward applies the transform while staging; the data gradient's epilogue
         makes this layer's BatchNorm-backward sums, which then need no activation either)."""
+        if not self.bf16:
+            # fp32: a 3x3 / stride 1 consumer of <= 32 channels on either side that takes the split forward kernel and the
+            # small-channel weight gradient (kernels.conv_bnin_ok); nothing is asked of its data gradient
+            if not (FUSE_BN_APPLY_F32 and USE_F32_SPLIT and self.frag and consumer is not None and residual is None and act != ACT_NONE):
+                return False
+            if consumer.k != 3 or consumer.stride != 1 or consumer.pad != 1 or consumer.cin_p != c or c % 8 != 0:
+                return False
+            d2 = K.conv_desc(n, ho, wo, c, consumer.cout_p, 3, 1, 1)
+            return K.conv_bnin_ok(d2) and self.wfrag(consumer, d2) is not None
         if not (FUSE_BN_APPLY and FUSE_BN_REDUCE and self.frag and self.bf16 and consumer is not None and residual is None
                 and act != ACT_NONE):
             return False
@@ -688,7 +706,7 @@ class Plan:
             wfd = self.wfrag(conv, d, dgrad=True)
             fuse = (prev is not None and FUSE_BN_REDUCE and not dx_acc and not prev[9] and prev[7] != ACT_NONE
                     and prev[4].shape == dx.shape and (wfd is not None or K.conv2d_dgrad_bnreduce_ok(d, dy.dtype)))
-            if prev is not None and isinstance(prev[5], LazyAct) and not fuse:
+            if prev is not None and isinstance(prev[5], LazyAct) and not fuse and self.bf16:
                 raise RuntimeError("internal: the producer's activation was not written, its consumer's data gradient must make "
                                    "the BatchNorm-backward sums")
             if fuse:
@@ -713,6 +731,8 @@ class Plan:
         mean, rstd = ms
         gamma = self.pvec(bn, "weight")
         beta = None
+        if isinstance(z, LazyAct) and not self.bf16:
+            z, has_res = None, False         # fp32: the z-less kernels below re-evaluate the activation's argument from y
         if isinstance(z, LazyAct):
             bs = self._bnb.pop(id(y))        # made by the consumer's data gradient (conv_bwd refuses to run without them)
             K.bn_bwd_apply_recompute(dz, y, z.scale, z.shift, mean, rstd, gamma, bs, dz, self.gvec(bn, "weight"),
@@ -761,7 +781,7 @@ class GradSlots:
         k = id(t)
         if k in self._g:
             return self._g[k], True
-        b = torch.empty_like(t)
+        b = torch.empty_like(t.y if isinstance(t, LazyAct) else t)
         self._g[k] = b
         return b, False
 

@@ -187,8 +187,18 @@ def conv2d_wgrad_halo(d, x, skip, dy, dw, up=False, st=None):
              st), name)
 
 
+def conv_bnin_ok(d):
+    """fp32: can BOTH consumers of an unwritten BatchNorm activation in front of this convolution apply it while staging?
+    (forward on the one-role split kernel, weight gradient on the small-channel direct kernel)"""
+    return bool(ops.udaseg_conv2d_fwd_f32x3_bnin_ok(d)) and bool(ops.udaseg_conv2d_wgrad_bnin_ok(d))
+
+
 def conv2d_wgrad_bnin(d, y_prev, in_scale, in_shift, in_act, in_slope, dy, dw, accumulate=False, st=None):
-    """Weight gradient whose gathered operand is act(fma(y_prev, in_scale, in_shift)) (never written), bf16."""
+    """Weight gradient whose gathered operand is act(fma(y_prev, in_scale, in_shift)) (never written), bf16 or fp32."""
+    if y_prev.dtype == torch.float32:
+        check(ops.udaseg_conv2d_wgrad_bnin(d, y_prev, in_scale, in_shift, in_act, in_slope, dy, dw, int(accumulate),
+                                           st), "conv2d_wgrad_bnin")
+        return
     check(ops.udaseg_conv2d_wgrad_bnin_bf16(d, y_prev, in_scale, in_shift, in_act,
                                                      in_slope, dy, dw, int(accumulate),
                                                      st), "conv2d_wgrad_bnin_bf16")
@@ -228,8 +238,13 @@ def conv2d_fwd_frag(d, x, skip, wfrag, bias, y, act=ACT_NONE, slope=0.0, stats=N
                     in_slope=0.0, up=False, st=None):
     """Halo-resident forward convolution on the bf16 matrix pipe: bf16 tensors (csrc/conv_halo_bf16.hip) or fp32 tensors with
     the three-term split (csrc/conv_halo_f32x3.hip).  up: x is the half-resolution tensor of a fused decoder input."""
+    if x.dtype == torch.float32 and in_scale is not None:
+        assert y.dtype == torch.float32 and skip is None and not up
+        check(ops.udaseg_conv2d_fwd_f32x3_bnin(d, x, in_scale, in_shift, in_act, in_slope, wfrag, bias, y, act, slope, stats,
+                                               st), "conv2d_fwd_f32x3_bnin")
+        return
     if x.dtype == torch.float32:
-        assert in_scale is None and y.dtype == torch.float32
+        assert y.dtype == torch.float32
         check(ops.udaseg_conv2d_fwd_f32x3(d, x, skip, x.shape[-1] if up else 0, wfrag,
                                                    bias, y, act, slope, stats,
                                                    st), "conv2d_fwd_f32x3")

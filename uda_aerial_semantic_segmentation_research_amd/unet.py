@@ -143,7 +143,9 @@ class DecoderBlock(nn.Module):
         self.conv1 = nn.Sequential(ConvP(in_ch + skip_ch, out_ch, 3, 1, 1), BNP(out_ch))
         self.conv2 = nn.Sequential(ConvP(out_ch, out_ch, 3, 1, 1), BNP(out_ch))
 
-    def fwd(self, P, x, skip):
+    def fwd(self, P, x, skip, lazy_for=None):
+        """lazy_for: the convolution that is the ONLY consumer of this block's output (the segmentation head behind the last
+        block), or None: the output's BatchNorm + ReLU may then stay unwritten (engine.LazyAct)."""
         ca, cb = x.shape[-1], 0 if skip is None else skip.shape[-1]
         if self.upsample == "bilinear":      # north_star's alternate mode: a stand-alone HBM-bound pass (csrc/bilinear.hip)
             cat = K.upsample2x_bilinear_concat_fwd(x, skip, P.st)
@@ -152,7 +154,7 @@ class DecoderBlock(nn.Module):
         else:
             cat = K.upsample2x_concat_fwd(x, skip, P.st)
         a1, r1 = P.conv_bn_act(self.conv1[0], self.conv1[1], cat, *RELU, lazy_for=self.conv2[0])   # a1 feeds conv2 only
-        out, r2 = P.conv_bn_act(self.conv2[0], self.conv2[1], a1, *RELU)
+        out, r2 = P.conv_bn_act(self.conv2[0], self.conv2[1], a1, *RELU, lazy_for=lazy_for)
         return out, (x, skip, cat, a1, r1, r2)
 
     @staticmethod
@@ -319,21 +321,24 @@ class Unet(ArenaModule):
                 tape.append((blk, rec, h))
             feats.append(h)
         skips = feats[:-1][::-1]                  # f4, f3, f2, f1
+        head = self.segmentation_head[0]
+        nblk = len(self.decoder.blocks)
         for i, blk in enumerate(self.decoder.blocks):
             skip = skips[i] if i < len(skips) else None
-            h, rec = blk.fwd(P, h, skip)
+            # the last block's output feeds the head alone unless the caller asked for the decoder features as well
+            only_head = head if (i == nblk - 1 and "logits" in want and "decoder" not in want) else None
+            h, rec = blk.fwd(P, h, skip, lazy_for=only_head)
             tape.append((blk, rec, h))
-        head = self.segmentation_head[0]
         logits, d_head = None, None
         if "logits" in want:
             logits, d_head = P.conv(head, h, out_dtype=torch.float32)  # logits stay fp32 (loss accuracy) in every mode
         if self.training:
             self.tick_batchnorm_counters()
         top = feats[-1]
-        views = {"logits": None if logits is None else logits.permute(0, 3, 1, 2)[:, : self.classes],
-                 "decoder": h.permute(0, 3, 1, 2)[:, : DECODER_CHANNELS[-1]],
-                 "features": top.permute(0, 3, 1, 2)[:, : self.encoder.out_channels[-1]]}
-        outs = [views[w] for w in want]
+        views = {"logits": lambda: None if logits is None else logits.permute(0, 3, 1, 2)[:, : self.classes],
+                 "decoder": lambda: h.permute(0, 3, 1, 2)[:, : DECODER_CHANNELS[-1]],
+                 "features": lambda: top.permute(0, 3, 1, 2)[:, : self.encoder.out_channels[-1]]}
+        outs = [views[w]() for w in want]
         if not save:
             return outs, None
         tape_all = (P, tape, (r_stem, f1, pooled, pidx), (head, d_head, h), top)
