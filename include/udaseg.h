@@ -435,18 +435,19 @@ int udaseg_conv2d_fwd_f32x3(const udaseg_conv_desc* d, const float* x, const flo
 /* The same BatchNorm + activation that is never written, on fp32 tensors (round 4; the <= 32-channel full-resolution decoder layers,
  * where the stand-alone udaseg_bn_apply pass moves 268 MB per layer at 8 x 512^2): x is the producer's RAW convolution output, the
  * staging applies act(fma(x, in_scale[c], in_shift[c])) -- udaseg_bn_apply's own arithmetic, bit for bit -- before the split, zero
- * padding stays zero.  Forward: <= 32 produced channels (udaseg_conv2d_fwd_f32x3_bnin_ok), no fused decoder input.  Weight gradient
- * (fp32 pipe, the small-channel direct kernel): 3x3 / stride 1 with <= 32 channels on either side (udaseg_conv2d_wgrad_bnin_ok),
- * dW accumulated or overwritten.  The producer's own BatchNorm backward needs nothing new: on fp32 it re-evaluates the activation's
+ * padding stays zero.  up != 0: x is the half-resolution tensor [n][hi/2][wi/2][ci] behind a nearest x2 up-sampling (a decoder
+ * block without a skip input).  Forward: every geometry of udaseg_conv2d_fwd_f32x3 with a single source.  Weight gradient: the
+ * small-channel direct kernel (<= 32 channels, fp32 pipe; also up) or the halo-resident split kernel (plain source); dW accumulated
+ * or overwritten.  The producer's own BatchNorm backward needs nothing new: on fp32 it re-evaluates the activation's
  * argument from its conv output already (udaseg_bn_bwd_reduce / _apply with z = NULL).  nn.BatchNorm2d + nn.ReLU in front of a
  * 3x3 convolution inside smp.Unet's decoder blocks and head, reference src/models/train.py:341,343. */
-int udaseg_conv2d_fwd_f32x3_bnin_ok(const udaseg_conv_desc* d);
-int udaseg_conv2d_fwd_f32x3_bnin(const udaseg_conv_desc* d, const float* x, const float* in_scale, const float* in_shift, int in_act,
-                                 float in_slope, const void* wfrag3, const float* bias, float* y, int act, float slope, double* stats,
-                                 void* stream);
-int udaseg_conv2d_wgrad_bnin_ok(const udaseg_conv_desc* d);
-int udaseg_conv2d_wgrad_bnin(const udaseg_conv_desc* d, const float* x, const float* in_scale, const float* in_shift, int in_act,
-                             float in_slope, const float* dy, float* dw, int accumulate, void* stream);
+int udaseg_conv2d_fwd_f32x3_bnin_ok(const udaseg_conv_desc* d, int up);
+int udaseg_conv2d_fwd_f32x3_bnin(const udaseg_conv_desc* d, const float* x, int up, const float* in_scale, const float* in_shift,
+                                 int in_act, float in_slope, const void* wfrag3, const float* bias, float* y, int act, float slope,
+                                 double* stats, void* stream);
+int udaseg_conv2d_wgrad_bnin_ok(const udaseg_conv_desc* d, int up);
+int udaseg_conv2d_wgrad_bnin(const udaseg_conv_desc* d, const float* x, int up, const float* in_scale, const float* in_shift,
+                             int in_act, float in_slope, const float* dy, float* dw, int accumulate, void* stream);
 /* dx (+)= conv_transpose(dy, w); split / prev_y / accumulate as udaseg_conv2d_dgrad_frag_bf16, on fp32 tensors */
 int udaseg_conv2d_dgrad_f32x3(const udaseg_conv_desc* d, const float* dy, const void* wfrag3_t, float* dx, float* dx2, int split,
                               const float* prev_y, const float* save_mean, const float* save_rstd, const float* gamma,

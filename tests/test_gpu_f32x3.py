@@ -420,7 +420,11 @@ def test_shared_source_split_fp32_grade(K, case):
     grade(res[1][2], res[0][2], dw_ref, "weight gradient", cap=5e-6, k2=1.6)
 
 
-BNIN_CASES = [(2, 40, 72, 16, 16), (1, 33, 50, 16, 24), (2, 24, 64, 32, 16), (1, 20, 36, 16, 32), (8, 128, 128, 16, 16)]
+BNIN_CASES = [(2, 40, 72, 16, 16), (1, 33, 50, 16, 24), (2, 24, 64, 32, 16), (1, 20, 36, 16, 32), (8, 128, 128, 16, 16),
+              # the wave-specialised forward kernel / the halo-resident weight gradient (64 x 64, 32 x 64 and 32 x 32 channel blocks,
+              # 16-pixel-wide images)
+              (2, 24, 64, 64, 64), (1, 20, 36, 128, 64), (2, 16, 32, 64, 32), (1, 40, 40, 32, 32), (3, 16, 16, 64, 128),
+              (8, 32, 32, 256, 256)]
 
 
 @pytest.mark.parametrize("case", BNIN_CASES, ids=["n%d_%dx%d_ci%d_co%d" % c for c in BNIN_CASES])
@@ -470,6 +474,34 @@ def test_unwritten_batchnorm_activation_fp32(K, case, act, slope):
     assert err2((dw_a - base).cpu(), dw_l.cpu().double()) <= 1e-5
 
 
+@pytest.mark.parametrize("n,h,w,ci,co", [(2, 24, 40, 32, 16), (1, 16, 32, 16, 16), (8, 64, 64, 32, 16)])
+def test_unwritten_activation_behind_an_upsampling_fp32(K, n, h, w, ci, co):
+    """The same through a nearest x2 up-sampling (a decoder block without a skip input): forward bit for bit against the forward
+    on the written activation, weight gradient to the order of its fold's atomics."""
+    from uda_aerial_semantic_segmentation_research_amd.engine import LazyAct
+    g = torch.Generator().manual_seed(n + h + w + ci + co)
+    y_prev = (torch.randn(n, h, w, ci, generator=g) * 1.5 + 0.3).cuda()
+    sc, sh = (torch.rand(ci, generator=g) + 0.5).cuda(), (torch.randn(ci, generator=g) * 0.5).cuda()
+    z = LazyAct(y_prev, sc, sh, 1, 0.0).materialize()
+    wt = torch.randn(co, ci, 3, 3, generator=g) / math.sqrt(9 * ci)
+    wf, _, _, _ = pack3(K, wt)
+    d = K.conv_desc(n, 2 * h, 2 * w, ci, co, 3, 1, 1)
+    assert K.conv_bnin_ok(d, True)
+    R = K.bn_replicas()
+    ya, yb = (torch.full((n, 2 * h, 2 * w, co), float("nan"), device="cuda") for _ in range(2))
+    sa, sb = (torch.zeros(R * 2 * co, dtype=f64, device="cuda") for _ in range(2))
+    K.conv2d_fwd_frag(d, z, None, wf, None, ya, stats=sa, up=True)
+    K.conv2d_fwd_frag(d, y_prev, None, wf, None, yb, stats=sb, in_scale=sc, in_shift=sh, in_act=1, in_slope=0.0, up=True)
+    assert torch.equal(ya, yb) and torch.equal(sa.view(R, 2, co).sum(0), sb.view(R, 2, co).sum(0))
+    up = F.interpolate(nchw(z), scale_factor=2.0, mode="nearest")
+    assert err2(nchw(ya), F.conv2d(up.double(), wt.double(), padding=1)) <= 1e-6
+    dy = torch.randn(n, 2 * h, 2 * w, co, generator=g).cuda()
+    dw = torch.full((co, 3, 3, ci), float("nan"), device="cuda")
+    K.conv2d_wgrad_bnin(d, y_prev, sc, sh, 1, 0.0, dy, dw, False, up=True)
+    dw_ref = torch.nn.grad.conv2d_weight(up.double(), wt.shape, nchw(dy).double(), padding=1)
+    assert err2(dw.cpu().permute(0, 3, 1, 2), dw_ref) <= 2e-6
+
+
 def test_network_step_with_and_without_unwritten_activations_fp32(K, monkeypatch):
     """One r18-Unet training step with the last decoder block's BatchNorm activations unwritten (engine.FUSE_BN_APPLY_F32) against the
     same step with the stand-alone passes: logits bit for bit (the transform reproduces bn_apply's stores), gradients to atomics order."""
@@ -481,6 +513,7 @@ def test_network_step_with_and_without_unwritten_activations_fp32(K, monkeypatch
     x = torch.randn(2, 3, 64, 96, device="cuda")
     yl = torch.randint(0, 23, (2, 64, 96), device="cuda")
     outs = []
+    monkeypatch.setattr(engine, "FUSE_BN_APPLY_F32_UP", True)          # the off-by-default route through the up-sampling as well
     for lazy in (True, False):
         monkeypatch.setattr(engine, "FUSE_BN_APPLY_F32", lazy)
         torch.manual_seed(11)
@@ -489,7 +522,7 @@ def test_network_step_with_and_without_unwritten_activations_fp32(K, monkeypatch
         logits = net(x)
         lazies = sum(isinstance(t, engine.LazyAct) for blk, rec, out in net._last_tape[1] if hasattr(blk, "relu_outputs")
                      for t in (rec[3], out))
-        assert (lazies >= 2) == lazy, lazies
+        assert (lazies >= 4) == lazy, lazies
         loss = CrossEntropyLoss()(logits, yl)
         loss.backward()
         outs.append((logits.detach().clone(), {k: p.grad.detach().clone() for k, p in net.named_parameters()},

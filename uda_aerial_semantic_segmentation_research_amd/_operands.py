@@ -57,7 +57,7 @@ OPERANDS = {
     "udaseg_seg_partials": [], "udaseg_prof_reset": [], "udaseg_prof_kernel_count": [],
     "udaseg_set_option": [I("key"), I("value")],
     "udaseg_conv2d_dgrad_bnreduce_ok": [D], "udaseg_conv2d_dgrad_bnreduce_bf16_ok": [D], "udaseg_conv_flops": [D],
-    "udaseg_conv2d_fwd_f32x3_bnin_ok": [D], "udaseg_conv2d_wgrad_bnin_ok": [D],
+    "udaseg_conv2d_fwd_f32x3_bnin_ok": [D, I("up")], "udaseg_conv2d_wgrad_bnin_ok": [D, I("up")],
     "udaseg_workspace_bytes": [D],
     "udaseg_channel_sum_scratch_bytes": [I("c")], "udaseg_gap_splits": [I("hw")], "udaseg_frag_elems": [I("n_out"), I("k_in"), I("ks")],
     "udaseg_conv2d_wgrad_halo_bf16_ok": [D, I("up_ca")], "udaseg_conv2d_wgrad_halo_f32x3_ok": [D, I("up_ca")],
@@ -95,10 +95,12 @@ OPERANDS = {
     "udaseg_conv2d_fwd_f32x3": [D, T("x", f32, "(" + _HALF + "*up_ca if up_ca else X)"), T("skip", f32, "n*hi*wi*(ci-up_ca)", True),
                                 I("up_ca"), T("wfrag3", bf16, "3*frag(co,ci,kh)"), T("bias", f32, "co", True), T("y", f32, "Y"),
                                 I("act"), F("slope"), T("stats", f64, "2*co*R", True), S],
-    "udaseg_conv2d_fwd_f32x3_bnin": [D, T("x", f32, "X"), T("in_scale", f32, "ci"), T("in_shift", f32, "ci"), I("in_act"),
+    "udaseg_conv2d_fwd_f32x3_bnin": [D, T("x", f32, "(" + _HALF + "*ci if up else X)"), I("up"), T("in_scale", f32, "ci"),
+                                     T("in_shift", f32, "ci"), I("in_act"),
                                      F("in_slope"), T("wfrag3", bf16, "3*frag(co,ci,kh)"), T("bias", f32, "co", True), T("y", f32, "Y"),
                                      I("act"), F("slope"), T("stats", f64, "2*co*R", True), S],
-    "udaseg_conv2d_wgrad_bnin": [D, T("x", f32, "X"), T("in_scale", f32, "ci"), T("in_shift", f32, "ci"), I("in_act"),
+    "udaseg_conv2d_wgrad_bnin": [D, T("x", f32, "(" + _HALF + "*ci if up else X)"), I("up"), T("in_scale", f32, "ci"),
+                                 T("in_shift", f32, "ci"), I("in_act"),
                                  F("in_slope"), T("dy", f32, "Y"), T("dw", f32, "W"), I("accumulate"), S],
     "udaseg_conv2d_dgrad_f32x3": [D, T("dy", f32, "Y"), T("wfrag3_t", bf16, "3*frag(ci,co,kh)"),
                                   T("dx", f32, "n*hi*wi*(split if split else ci)"), T("dx2", f32, "n*hi*wi*(ci-split)", True),

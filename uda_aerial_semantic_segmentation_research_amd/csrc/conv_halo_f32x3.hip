@@ -63,7 +63,7 @@ struct F3Args {
   // x is the raw output of a conv + training-mode BatchNorm + activation layer whose activation was never written (round 4,
   // engine.LazyAct on fp32): the staging applies act(fma(x, in_scale[c], in_shift[c])) -- bn_apply's own fused multiply-add and
   // coefficients, so the value is bit for bit what the stand-alone pass would have stored -- before the split; padding stays zero.
-  // conv3x3_f32x3_kernel only (<= 32 produced channels), no fused decoder input.  null: x is used as it is.
+  // Both kernels; a single source (plain, or the half-resolution tensor of an up-sampled input: up_ca == ci).  null: x as it is.
   const float* in_scale;
   const float* in_shift;
   int in_act;
@@ -92,7 +92,7 @@ struct F3Cfg {
   static_assert(LDS_HALO >= 2 * NW * 32 * 4, "reduction scratch fits the halo region");
 };
 
-template <int WM, int WN, int RPW>
+template <int WM, int WN, int RPW, bool XF = false>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_f32x3_kernel(const F3Args a) {
   using C = F3Cfg<WM, WN, RPW>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -201,11 +201,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_f32x3_kernel(const F3
       }
     }
   };
-  const bool XF = a.in_scale != nullptr;                    // uniform: the gathered tensor is an unwritten BatchNorm activation
+  // XF: the gathered tensor is an unwritten BatchNorm activation (F3Args::in_scale) -- an instantiation of its own, the plain
+  // launches carry none of it
   const bool xf_relu = a.in_act == UDASEG_ACT_LEAKY && a.in_slope == 0.f;
   auto store_chunk = [&](int c) {
     f32x4 sc0 = {0.f, 0.f, 0.f, 0.f}, sc1 = sc0, sh0 = sc0, sh1 = sc0;
-    if (XF) {                                                // this thread's 8 channels of chunk c (its octet is fixed)
+    if constexpr (XF) {                                      // this thread's 8 channels of chunk c (its octet is fixed)
       const int ch = c * 16 + oct * 8;
       if (ch < a.ci) {
         sc0 = *reinterpret_cast<const f32x4*>(a.in_scale + ch);
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3x3_f32x3_kernel(const F3
     for (int i = 0; i < C::NI; ++i) {
       if (i < C::NI - 1 || tid + i * C::NT < C::NPIECE) {
         u32x4 lo = stage[i][0], hi = stage[i][1];
-        if (XF) {
+        if constexpr (XF) {
           const bool inside = voff[i] != 0x80000000u;        // zero padding is padding of the ACTIVATION: stays zero
           f32x4 l = __builtin_bit_cast(f32x4, lo), h = __builtin_bit_cast(f32x4, hi);
 #pragma unroll
@@ -353,7 +354,7 @@ struct F3WsCfg {
   static constexpr int LDS = 2 * LDS_HALO + 2 * LDS_WBUF;
 };
 
-template <int WM, int WN, int RPW, bool TL = false, int TW = 32>
+template <int WM, int WN, int RPW, bool TL = false, int TW = 32, bool XF = false>
 __global__ __launch_bounds__(512, 1) void conv3x3_f32x3_ws_kernel(const F3Args a) {
   using C = F3WsCfg<WM, WN, RPW, TW>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -455,11 +456,43 @@ __global__ __launch_bounds__(512, 1) void conv3x3_f32x3_ws_kernel(const F3Args a
         }
       }
     };
-    auto store_chunk = [&](int buf) {
+    const bool xf_relu = a.in_act == UDASEG_ACT_LEAKY && a.in_slope == 0.f;      // XF: see conv3x3_f32x3_kernel
+    auto store_chunk = [&](int buf, int c) {
       char* hb = smem + buf * C::LDS_HALO;
+      f32x4 sc0 = {0.f, 0.f, 0.f, 0.f}, sc1 = sc0, sh0 = sc0, sh1 = sc0;
+      if constexpr (XF) {                                    // this thread's 8 channels of chunk c (see conv3x3_f32x3_kernel)
+        const int ch = c * 16 + oct * 8;
+        if (ch < a.ci) {
+          sc0 = *reinterpret_cast<const f32x4*>(a.in_scale + ch);
+          sh0 = *reinterpret_cast<const f32x4*>(a.in_shift + ch);
+          if (ch + 4 < a.ci) {
+            sc1 = *reinterpret_cast<const f32x4*>(a.in_scale + ch + 4);
+            sh1 = *reinterpret_cast<const f32x4*>(a.in_shift + ch + 4);
+          }
+        }
+      }
 #pragma unroll
       for (int i = 0; i < C::NI; ++i) {
         if (i < C::NI - 1 || lt + i * C::NLD < C::NPIECE) {
+          if constexpr (XF) {
+            const bool inside = voff[i] != 0x80000000u;
+            f32x4 l = __builtin_bit_cast(f32x4, stage[i][0]), h = __builtin_bit_cast(f32x4, stage[i][1]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float t0 = __builtin_fmaf(l[e], sc0[e], sh0[e]), t1 = __builtin_fmaf(h[e], sc1[e], sh1[e]);
+              if (xf_relu) {
+                t0 = t0 > 0.f ? t0 : 0.f;
+                t1 = t1 > 0.f ? t1 : 0.f;
+              } else {
+                t0 = act_apply(t0, a.in_act, a.in_slope);
+                t1 = act_apply(t1, a.in_act, a.in_slope);
+              }
+              l[e] = inside ? t0 : 0.f;
+              h[e] = inside ? t1 : 0.f;
+            }
+            stage[i][0] = __builtin_bit_cast(u32x4, l);
+            stage[i][1] = __builtin_bit_cast(u32x4, h);
+          }
           u32x4 p0, p1, p2;
           split3(stage[i][0], stage[i][1], p0, p1, p2);
           *reinterpret_cast<u32x4*>(hb + soffl[i]) = p0;
@@ -485,7 +518,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_f32x3_ws_kernel(const F3Args a
 
     load_chunk(0);
     load_w(0);
-    store_chunk(0);
+    store_chunk(0, 0);
     store_w(0);
     if (nchunk > 1) load_chunk(1);
     if (NG > 1) load_w(1);
@@ -498,7 +531,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_f32x3_ws_kernel(const F3Args a
         if (G + 2 < NG) load_w(G + 2);
       }
       if (dx == 1 && c + 1 < nchunk) {
-        store_chunk((c + 1) & 1);                  // last read in chunk c - 1
+        store_chunk((c + 1) & 1, c + 1);           // last read in chunk c - 1
         if (c + 2 < nchunk) load_chunk(c + 2);
       }
       if constexpr (TL) {
@@ -680,7 +713,29 @@ static int launch_f3_ws_t(F3Args a, hipStream_t s, double flops) {
     kid = kprof_id(nm);
   }
   hipEvent_t ev = kprof_begin(s);
-  if (g_timeline != nullptr && blocks * 16 <= (long long)g_timeline_blocks * 6) {      // stamped twin (diagnosis only)
+  if (a.in_scale != nullptr) {          // the instantiation that transforms x while it stages (F3Args::in_scale)
+    auto kern_xf = conv3x3_f32x3_ws_kernel<WM, WN, RPW, false, TW, true>;
+    static bool xf_attr = false;
+    if (!xf_attr) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern_xf), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+      if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv3x3_f32x3_ws, in-staging transform)");
+      xf_attr = true;
+    }
+    static int kid_xf = -1;             // its own rocprofv3 symbol
+    if (kid_xf < 0) {
+      char nm[96];
+      snprintf(nm, sizeof(nm), "conv3x3_f32x3_ws_kernel<%d, %d, %d, false, %d, true>", WM, WN, RPW, TW);
+      kid_xf = kprof_id(nm);
+    }
+    hipLaunchKernelGGL(kern_xf, dim3((unsigned)blocks), dim3(C::NT), C::LDS, s, a);
+    kprof_end(kid_xf, ev, s, flops);
+    UDASEG_LAUNCH_CHECK("conv3x3_f32x3_ws (in-staging transform) launch");
+    if (a.sscr != nullptr) {
+      launch_halo_stats_fold(a.sscr, a.co, a.stats, s);
+      UDASEG_LAUNCH_CHECK("halo_stats_fold launch");
+    }
+    return UDASEG_OK;
+  } else if (g_timeline != nullptr && blocks * 16 <= (long long)g_timeline_blocks * 6) {      // stamped twin (diagnosis only)
     auto kern_tl = conv3x3_f32x3_ws_kernel<WM, WN, RPW, true, TW>;
     static bool tl_attr = false;
     if (!tl_attr) {
@@ -729,8 +784,26 @@ static int launch_f3_t(F3Args a, hipStream_t s, double flops) {
     kid = kprof_id(nm);
   }
   hipEvent_t ev = kprof_begin(s);
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::NT), C::LDS, s, a);
-  kprof_end(kid, ev, s, flops);
+  if (a.in_scale != nullptr) {
+    auto kern_xf = conv3x3_f32x3_kernel<WM, WN, RPW, true>;
+    static bool xf_attr = false;
+    if (!xf_attr && C::LDS > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern_xf), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+      if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv3x3_f32x3, in-staging transform)");
+      xf_attr = true;
+    }
+    static int kid_xf = -1;             // its own rocprofv3 symbol
+    if (kid_xf < 0) {
+      char nm[96];
+      snprintf(nm, sizeof(nm), "conv3x3_f32x3_kernel<%d, %d, %d, true>", WM, WN, RPW);
+      kid_xf = kprof_id(nm);
+    }
+    hipLaunchKernelGGL(kern_xf, dim3((unsigned)blocks), dim3(C::NT), C::LDS, s, a);
+    kprof_end(kid_xf, ev, s, flops);
+  } else {
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::NT), C::LDS, s, a);
+    kprof_end(kid, ev, s, flops);
+  }
   UDASEG_LAUNCH_CHECK("conv3x3_f32x3 launch");
   if (a.sscr != nullptr) {
     launch_halo_stats_fold(a.sscr, a.co, a.stats, s);
@@ -792,7 +865,6 @@ static int f3_choice(int h, int w, int n, int gathered, int produced) {
 static int launch_f3(F3Args a, hipStream_t s, double flops) {
   int choice = f3_choice(a.h, a.w, a.n, a.ci, a.co);
   if (choice == 0) choice = a.co <= 32 ? 1 : 6;
-  if (a.in_scale != nullptr) choice = 1;       // the in-staging transform lives in the one-role kernel (host-checked: <= 32 produced channels)
   if (choice == 1) return launch_f3_t<4, 1, 2>(a, s, flops);
   if (choice == 3) return launch_f3_t<2, 2, 2>(a, s, flops);      // 4 x 32 pixels x 64 channels
   if (choice == 4) return launch_f3_t<4, 2, 4>(a, s, flops);      // 16 x 32 pixels x 64 channels, 8 waves
@@ -871,28 +943,29 @@ extern "C" int udaseg_conv2d_fwd_f32x3(const udaseg_conv_desc* d, const float* x
   return rc;
 }
 
-extern "C" int udaseg_conv2d_fwd_f32x3_bnin_ok(const udaseg_conv_desc* d) {
-  return d && d->co <= 32 && f3_applicable(d, d->ci, d->co, 0) ? 1 : 0;
+extern "C" int udaseg_conv2d_fwd_f32x3_bnin_ok(const udaseg_conv_desc* d, int up) {
+  return d && f3_applicable(d, d->ci, d->co, up ? d->ci : 0) ? 1 : 0;
 }
 
-extern "C" int udaseg_conv2d_fwd_f32x3_bnin(const udaseg_conv_desc* d, const float* x, const float* in_scale, const float* in_shift,
-                                            int in_act, float in_slope, const void* wfrag3, const float* bias, float* y, int act,
-                                            float slope, double* stats, void* stream) {
+extern "C" int udaseg_conv2d_fwd_f32x3_bnin(const udaseg_conv_desc* d, const float* x, int up, const float* in_scale,
+                                            const float* in_shift, int in_act, float in_slope, const void* wfrag3, const float* bias,
+                                            float* y, int act, float slope, double* stats, void* stream) {
   F3Args a = {};
   int rc = f3_common(d, a, "conv2d_fwd_f32x3_bnin");
   if (rc) return rc;
   UDASEG_CHECK_ARG(x && in_scale && in_shift && wfrag3 && y, "conv2d_fwd_f32x3_bnin: NULL pointer");
   UDASEG_CHECK_ARG(in_act == UDASEG_ACT_NONE || in_act == UDASEG_ACT_LEAKY, "conv2d_fwd_f32x3_bnin: unknown activation %d", in_act);
-  if (!udaseg_conv2d_fwd_f32x3_bnin_ok(d)) {
-    set_error("conv2d_fwd_f32x3_bnin: geometry not supported (<= 32 produced channels; ask udaseg_conv2d_fwd_f32x3_bnin_ok)");
+  if (!udaseg_conv2d_fwd_f32x3_bnin_ok(d, up)) {
+    set_error("conv2d_fwd_f32x3_bnin: geometry not supported (ask udaseg_conv2d_fwd_f32x3_bnin_ok)");
     return UDASEG_E_UNSUPPORTED;
   }
   const long long px = (long long)d->n * d->hi * d->wi;
   a.x = x; a.wf = wfrag3; a.bias = bias; a.y = y;
   a.in_scale = in_scale; a.in_shift = in_shift; a.in_act = in_act; a.in_slope = in_slope;
   a.ci = d->ci; a.co = d->co;
+  a.up_ca = up ? d->ci : 0;            // up: x is the half-resolution tensor behind a nearest x2 up-sampling (no skip source)
   a.act = act; a.slope = slope; a.stats = stats;
-  a.x_bytes = (unsigned)(px * d->ci * 4);
+  a.x_bytes = (unsigned)(up ? (long long)d->n * (d->hi / 2) * (d->wi / 2) * d->ci * 4 : px * d->ci * 4);
   a.w_plane_bytes = (unsigned)(udaseg_frag_elems(d->co, d->ci, 3) * 2);
   a.y_bytes = (unsigned)(px * d->co * 4);
   hipStream_t st = as_stream(stream);

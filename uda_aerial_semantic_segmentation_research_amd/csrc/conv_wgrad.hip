@@ -1080,32 +1080,6 @@ extern "C" int udaseg_conv2d_wgrad(const udaseg_conv_desc* d, const float* x, co
   return conv2d_wgrad_impl(d, x, d->ci, 0, 0, dy, dw, accumulate, stream, 0);
 }
 
-// fp32, the gathered operand an unwritten BatchNorm activation (engine.LazyAct on fp32, round 4): the <= 32-channel full-resolution
-// layers only (conv3x3_small_wgrad_kernel applies the transform while it commits its halo tile)
-extern "C" int udaseg_conv2d_wgrad_bnin_ok(const udaseg_conv_desc* d) {
-  return d && d->kh == 3 && d->kw == 3 && d->n > 0 && d->hi > 0 && d->wi > 0 && d->ci % 4 == 0 && d->co % 4 == 0 &&
-                 small_wgrad_applicable(d->kh, d->stride, d->pad, d->ci, d->co, d->n * cdiv(d->hi, 16) * cdiv(d->wi, 16))
-             ? 1
-             : 0;
-}
-
-extern "C" int udaseg_conv2d_wgrad_bnin(const udaseg_conv_desc* d, const float* x, const float* in_scale, const float* in_shift,
-                                        int in_act, float in_slope, const float* dy, float* dw, int accumulate, void* stream) {
-  UDASEG_CHECK_ARG(d && x && in_scale && in_shift && dy && dw, "conv2d_wgrad_bnin: NULL pointer");
-  UDASEG_CHECK_ARG(in_act == UDASEG_ACT_NONE || in_act == UDASEG_ACT_LEAKY, "conv2d_wgrad_bnin: unknown activation %d", in_act);
-  UDASEG_CHECK_ARG(d->ho == d->hi && d->wo == d->wi, "conv2d_wgrad_bnin: stride-1 'same' convolutions only");
-  if (!udaseg_conv2d_wgrad_bnin_ok(d)) {
-    set_error("conv2d_wgrad_bnin: geometry not supported (3x3 / stride 1, <= 32 channels on either side, workspace bound; ask "
-              "udaseg_conv2d_wgrad_bnin_ok)");
-    return UDASEG_E_UNSUPPORTED;
-  }
-  hipStream_t st = as_stream(stream);
-  prof_begin(1, st);
-  const int rc = launch_small_wgrad(x, dy, dw, d->n, d->hi, d->wi, d->ci, d->co, accumulate, st, 0, in_scale, in_shift, in_act, in_slope);
-  prof_end(1, st, udaseg_conv_flops(d), 2, d);
-  return rc;
-}
-
 extern "C" int udaseg_conv2d_wgrad_bf16(const udaseg_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate,
                                         void* stream) {
   UDASEG_CHECK_ARG(d != nullptr, "conv2d_wgrad_bf16: NULL desc");
@@ -1121,7 +1095,8 @@ extern "C" int udaseg_conv2d_wgrad_bnin_bf16(const udaseg_conv_desc* d, const vo
 // halo-resident weight gradients (conv_wgrad_halo2.hip)
 namespace udaseg {
 bool wgrad_h2_applicable(const udaseg_conv_desc* d, int up_ca, bool f32);
-int launch_wgrad_h2(const udaseg_conv_desc* d, const void* x, const void* x2, int up_ca, const void* dy, float* dw, bool f32, hipStream_t s);
+int launch_wgrad_h2(const udaseg_conv_desc* d, const void* x, const void* x2, int up_ca, const void* dy, float* dw, bool f32, hipStream_t s,
+                    const float* in_scale = nullptr, const float* in_shift = nullptr, int in_act = 0, float in_slope = 0.f);
 static bool wgrad_halo_off(bool f32) {
   static int off = -1, off3 = -1;   // UDASEG_NO_WGRAD_HALO=1: the per-tap split-K kernels everywhere; UDASEG_F32_SPLIT=0: no fp32 split
   if (off < 0) {
@@ -1132,6 +1107,43 @@ static bool wgrad_halo_off(bool f32) {
   return f32 ? off3 != 0 : off != 0;
 }
 }  // namespace udaseg
+
+// fp32, the gathered operand an unwritten BatchNorm activation (engine.LazyAct on fp32, round 4): the small-channel direct kernel
+// (<= 32 channels, also behind a nearest x2 up-sampling: up) or the halo-resident split kernel (plain source) apply the transform
+// while they stage x
+extern "C" int udaseg_conv2d_wgrad_bnin_ok(const udaseg_conv_desc* d, int up) {
+  if (!d || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->n <= 0 || d->hi <= 0 || d->wi <= 0 || d->ci % 8 != 0 ||
+      d->co % 4 != 0)
+    return 0;
+  if (small_wgrad_applicable(d->kh, d->stride, d->pad, d->ci, d->co, d->n * cdiv(d->hi, 16) * cdiv(d->wi, 16))) return 1;
+  return !up && !wgrad_halo_off(true) && wgrad_h2_applicable(d, 0, true) ? 1 : 0;
+}
+
+extern "C" int udaseg_conv2d_wgrad_bnin(const udaseg_conv_desc* d, const float* x, int up, const float* in_scale, const float* in_shift,
+                                        int in_act, float in_slope, const float* dy, float* dw, int accumulate, void* stream) {
+  UDASEG_CHECK_ARG(d && x && in_scale && in_shift && dy && dw, "conv2d_wgrad_bnin: NULL pointer");
+  UDASEG_CHECK_ARG(in_act == UDASEG_ACT_NONE || in_act == UDASEG_ACT_LEAKY, "conv2d_wgrad_bnin: unknown activation %d", in_act);
+  UDASEG_CHECK_ARG(d->ho == d->hi && d->wo == d->wi, "conv2d_wgrad_bnin: stride-1 'same' convolutions only");
+  UDASEG_CHECK_ARG(!up || (d->hi % 2 == 0 && d->wi % 2 == 0), "conv2d_wgrad_bnin: an up-sampled source needs even extents");
+  if (!udaseg_conv2d_wgrad_bnin_ok(d, up)) {
+    set_error("conv2d_wgrad_bnin: geometry not supported (ask udaseg_conv2d_wgrad_bnin_ok)");
+    return UDASEG_E_UNSUPPORTED;
+  }
+  hipStream_t st = as_stream(stream);
+  prof_begin(1, st);
+  int rc;
+  if (small_wgrad_applicable(d->kh, d->stride, d->pad, d->ci, d->co, d->n * cdiv(d->hi, 16) * cdiv(d->wi, 16))) {
+    rc = launch_small_wgrad(x, dy, dw, d->n, d->hi, d->wi, d->ci, d->co, accumulate, st, up, in_scale, in_shift, in_act, in_slope);
+  } else {
+    if (!accumulate) {
+      hipError_t e = hipMemsetAsync(dw, 0, (size_t)d->co * 9 * d->ci * sizeof(float), st);
+      if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(dw)");
+    }
+    rc = launch_wgrad_h2(d, x, nullptr, 0, dy, dw, true, st, in_scale, in_shift, in_act, in_slope);
+  }
+  prof_end(1, st, udaseg_conv_flops(d), 2, d);
+  return rc;
+}
 
 extern "C" int udaseg_conv2d_wgrad_halo_bf16_ok(const udaseg_conv_desc* d, int up_ca) {
   return d != nullptr && !wgrad_halo_off(false) && wgrad_h2_applicable(d, up_ca, false) ? 1 : 0;

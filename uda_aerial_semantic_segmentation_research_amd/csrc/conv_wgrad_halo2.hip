@@ -43,6 +43,13 @@ struct WgradH2Args {
   int n, h, w, ci, co, up_ca;
   int ntx, nty, ntiles, ncib, pairs, P;
   unsigned x_bytes, x2_bytes, dy_bytes;
+  // fp32, single plain source: x is the raw output of a conv + BatchNorm + activation layer whose activation was never written
+  // (engine.LazyAct); the staging applies act(fma(x, in_scale[c], in_shift[c])) -- bn_apply's arithmetic -- to the pieces inside
+  // the image before the split.  null: x is used as it is.
+  const float* in_scale;
+  const float* in_shift;
+  int in_act;
+  float in_slope;
   unsigned long long* timeline;   // diagnosis (udaseg_debug_set_timeline, TL instantiation only): per (block, role) 8 x u64
 };
 extern unsigned long long* g_timeline;      // conv_igemm.hip
@@ -86,7 +93,7 @@ __device__ __forceinline__ bf16x8 h2_tr_fragment(const char* p) {
 }
 
 // One role of a block: the tile loop of the waves that own kernel columns DX0 .. DX0 + NDX - 1; STG: these waves also stage.
-template <typename C, int DX0, int NDX, bool STG, bool TL>
+template <typename C, int DX0, int NDX, bool STG, bool TL, bool XFT = false>
 __device__ __forceinline__ void wgrad_h2_role(const WgradH2Args& a, char* smem, int tid, int lane, int wave) {
   constexpr int PL = C::PL;
   char* const Xs = smem;
@@ -112,8 +119,22 @@ __device__ __forceinline__ void wgrad_h2_role(const WgradH2Args& a, char* smem, 
   __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dy), 0, (int)a.dy_bytes, 0x00020000);
   const int st = tid - (C::NT - C::NST);
   u32x4 sx[STG ? C::NX : 1][C::LPP], sd[STG ? C::ND : 1][C::LPP];
+  // in-staging transform of x (WgradH2Args::in_scale): a staging thread's 8-channel piece is the same for every piece it owns
+  // (NST is a multiple of the pieces per pixel), so its coefficients live in registers; x_in: bit i = piece i is inside the image
+  constexpr bool XF = XFT && PL == 3 && STG;          // its own instantiation: the plain launches carry none of this
+  static_assert(C::NST % C::XO == 0, "one channel octet per staging thread");
+  unsigned x_in = 0;
+  f32x4 xsc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, xsh[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  if constexpr (XF) {
+    const int ch = c0 + (st % C::XO) * 8;
+    xsc[0] = *reinterpret_cast<const f32x4*>(a.in_scale + ch);
+    xsc[1] = *reinterpret_cast<const f32x4*>(a.in_scale + ch + 4);
+    xsh[0] = *reinterpret_cast<const f32x4*>(a.in_shift + ch);
+    xsh[1] = *reinterpret_cast<const f32x4*>(a.in_shift + ch + 4);
+  }
   auto load_tile = [&](int tile) {
     if constexpr (STG) {
+      x_in = 0;
       const int tx = tile % a.ntx;
       const int t2 = tile / a.ntx;
       const int ty = t2 % a.nty, img = t2 / a.nty;
@@ -127,6 +148,7 @@ __device__ __forceinline__ void wgrad_h2_role(const WgradH2Args& a, char* smem, 
         const bool ok = pc < C::XPC && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
         const int p = half_res ? (img * (H >> 1) + (iy >> 1)) * (W >> 1) + (ix >> 1) : (img * H + iy) * W + ix;
         const unsigned off = ok ? (unsigned)((p * cx + c0 + oct * 8) * C::ES) : 0x80000000u;
+        if constexpr (XF) x_in |= (ok ? 1u : 0u) << i;
 #pragma unroll
         for (int l = 0; l < C::LPP; ++l) sx[i][l] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)off, 16 * l, 0);
       }
@@ -165,6 +187,21 @@ __device__ __forceinline__ void wgrad_h2_role(const WgradH2Args& a, char* smem, 
       for (int i = 0; i < C::NX; ++i) {
         const int pc = st + i * C::NST;
         const int pix = pc / C::XO, oct = pc % C::XO;
+        if constexpr (XF) {
+          {
+            const bool in = (x_in >> i) & 1u;
+#pragma unroll
+            for (int l = 0; l < 2; ++l) {
+              f32x4 v = __builtin_bit_cast(f32x4, sx[i][l]);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float t = act_apply(__builtin_fmaf(v[e], xsc[l][e], xsh[l][e]), a.in_act, a.in_slope);
+                v[e] = in ? t : 0.f;
+              }
+              sx[i][l] = __builtin_bit_cast(u32x4, v);
+            }
+          }
+        }
         if (i < C::NX - 1 || pc < C::XPC) store_piece(Xs + bo + (oct >> 2) * C::XSP + pix * 64 + (oct & 3) * 16, C::XPLANE, sx[i]);
       }
 #pragma unroll
@@ -303,14 +340,14 @@ __device__ __forceinline__ void wgrad_h2_role(const WgradH2Args& a, char* smem, 
       }
 }
 
-template <int PL, int COQ, int CIQ, int TR, int TWK, int NSTW, bool DB, bool TL = false>
+template <int PL, int COQ, int CIQ, int TR, int TWK, int NSTW, bool DB, bool TL = false, bool XF = false>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_h2_kernel(const WgradH2Args a) {
   using C = H2<PL, COQ, CIQ, TR, TWK, NSTW, DB>;
   extern __shared__ __attribute__((aligned(16))) char h2smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if (wave < 4) wgrad_h2_role<C, 0, 2, NSTW == 8, TL>(a, h2smem, tid, lane, wave);
-  else wgrad_h2_role<C, 2, 1, true, TL>(a, h2smem, tid, lane, wave);
+  if (wave < 4) wgrad_h2_role<C, 0, 2, NSTW == 8, TL, XF>(a, h2smem, tid, lane, wave);
+  else wgrad_h2_role<C, 2, 1, true, TL, XF>(a, h2smem, tid, lane, wave);
 }
 
 static int h2_env(const char* name, int dflt) {
@@ -345,12 +382,20 @@ static int h2_config(const udaseg_conv_desc* d, int up_ca, bool f32) {
 
 bool wgrad_h2_applicable(const udaseg_conv_desc* d, int up_ca, bool f32) { return d != nullptr && h2_config(d, up_ca, f32) != 0; }
 
+struct H2In {        // WgradH2Args::in_*
+  const float* scale = nullptr;
+  const float* shift = nullptr;
+  int act = 0;
+  float slope = 0.f;
+};
+
 template <int PL, int COQ, int CIQ, int TR, int TWK, int NSTW, bool DB = false>
 static int launch_h2_t(const udaseg_conv_desc* d, const void* x, const void* x2, int up_ca, const void* dy, float* dw, hipStream_t s,
-                       int target) {
+                       int target, const H2In& in = H2In()) {
   using C = H2<PL, COQ, CIQ, TR, TWK, NSTW, DB>;
   WgradH2Args a = {};
   a.x = x; a.x2 = x2; a.dy = dy; a.dw = dw;
+  a.in_scale = in.scale; a.in_shift = in.shift; a.in_act = in.act; a.in_slope = in.slope;
   a.n = d->n; a.h = d->hi; a.w = d->wi; a.ci = d->ci; a.co = d->co; a.up_ca = up_ca;
   a.ntx = cdiv(d->wi, C::TW); a.nty = cdiv(d->hi, C::TR); a.ntiles = d->n * a.ntx * a.nty;
   a.ncib = d->ci / C::CIB; a.pairs = a.ncib * (d->co / C::COB);
@@ -392,6 +437,27 @@ static int launch_h2_t(const udaseg_conv_desc* d, const void* x, const void* x2,
       return UDASEG_OK;
     }
   }
+  if constexpr (PL == 3) {
+    if (a.in_scale != nullptr) {          // the instantiation that transforms x while it stages (WgradH2Args::in_scale)
+      auto kern_xf = conv_wgrad_h2_kernel<PL, COQ, CIQ, TR, TWK, NSTW, DB, false, true>;
+      static bool xf_attr = false;
+      if (!xf_attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern_xf), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv_wgrad_h2, in-staging transform)");
+        xf_attr = true;
+      }
+      static int kid_xf = -1;
+      if (kid_xf < 0) {
+        char nm[112];
+        snprintf(nm, sizeof(nm), "conv_wgrad_h2_kernel<%d, %d, %d, %d, %d, %d, %s, false, true>", PL, COQ, CIQ, TR, TWK, NSTW, DB ? "true" : "false");
+        kid_xf = kprof_id(nm);
+      }
+      hipLaunchKernelGGL(kern_xf, dim3((unsigned)(a.pairs * P)), dim3(C::NT), C::LDS, s, a);
+      kprof_end(kid_xf, ev, s, 2.0 * (double)px * d->co * 9.0 * d->ci);
+      UDASEG_LAUNCH_CHECK("conv_wgrad_h2 (in-staging transform) launch");
+      return UDASEG_OK;
+    }
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.pairs * P)), dim3(C::NT), C::LDS, s, a);
   kprof_end(kid, ev, s, 2.0 * (double)px * d->co * 9.0 * d->ci);
   UDASEG_LAUNCH_CHECK("conv_wgrad_h2 launch");
@@ -399,7 +465,13 @@ static int launch_h2_t(const udaseg_conv_desc* d, const void* x, const void* x2,
 }
 
 int launch_wgrad_h2(const udaseg_conv_desc* d, const void* x, const void* x2, int up_ca, const void* dy, float* dw, bool f32,
-                    hipStream_t s) {
+                    hipStream_t s, const float* in_scale, const float* in_shift, int in_act, float in_slope) {
+  H2In in;
+  in.scale = in_scale; in.shift = in_shift; in.act = in_act; in.slope = in_slope;
+  if (in_scale != nullptr && (!f32 || up_ca != 0 || in_shift == nullptr)) {
+    set_error("conv2d_wgrad_halo: the in-staging transform needs fp32 operands and a single plain source");
+    return UDASEG_E_UNSUPPORTED;
+  }
   const int cfg = h2_config(d, up_ca, f32);
   if (cfg == 0) {
     set_error("conv2d_wgrad_halo: geometry not supported (ask the _ok query first)");
@@ -419,11 +491,11 @@ int launch_wgrad_h2(const udaseg_conv_desc* d, const void* x, const void* x2, in
   static int db = -1;      // UDASEG_WGRAD_DB=0: the single-buffer 4-row form of the 64 x 64 fp32 configuration (A/B)
   if (db < 0) db = h2_env("UDASEG_WGRAD_DB", 1);
   if (f32) {
-    if (cfg == 1 && db) return launch_h2_t<3, 2, 2, 2, 2, 4, true>(d, x, x2, up_ca, dy, dw, s, tf3);
-    if (cfg == 1) return launch_h2_t<3, 2, 2, 4, 2, 4>(d, x, x2, up_ca, dy, dw, s, tf3);
-    if (cfg == 2) return launch_h2_t<3, 2, 2, 8, 1, 4>(d, x, x2, up_ca, dy, dw, s, tdeep);
-    if (cfg == 3) return launch_h2_t<3, 1, 2, 4, 2, 4>(d, x, x2, up_ca, dy, dw, s, tf3);
-    return launch_h2_t<3, 1, 1, 4, 2, 4>(d, x, x2, up_ca, dy, dw, s, tf3);
+    if (cfg == 1 && db) return launch_h2_t<3, 2, 2, 2, 2, 4, true>(d, x, x2, up_ca, dy, dw, s, tf3, in);
+    if (cfg == 1) return launch_h2_t<3, 2, 2, 4, 2, 4>(d, x, x2, up_ca, dy, dw, s, tf3, in);
+    if (cfg == 2) return launch_h2_t<3, 2, 2, 8, 1, 4>(d, x, x2, up_ca, dy, dw, s, tdeep, in);
+    if (cfg == 3) return launch_h2_t<3, 1, 2, 4, 2, 4>(d, x, x2, up_ca, dy, dw, s, tf3, in);
+    return launch_h2_t<3, 1, 1, 4, 2, 4>(d, x, x2, up_ca, dy, dw, s, tf3, in);
   }
   if (cfg == 1) return launch_h2_t<1, 2, 2, 8, 2, 8>(d, x, x2, up_ca, dy, dw, s, tbf);
   if (cfg == 2) return launch_h2_t<1, 2, 2, 8, 1, 8>(d, x, x2, up_ca, dy, dw, s, tdeep);

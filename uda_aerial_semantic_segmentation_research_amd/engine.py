@@ -56,7 +56,14 @@ FUSE_BN_APPLY_1X1_ONLY = os.environ.get("UDASEG_FUSE_BN_APPLY", "0") == "2"
 # 268 MB per layer at 8 x 512^2: the consumer's forward (one-role split kernel) and weight gradient (small-channel direct kernel)
 # apply act(fma(y, scale, shift)) while they stage; the producer's BatchNorm backward re-evaluates its mask from y anyway.
 # UDASEG_FUSE_BN_APPLY_F32=0: always the stand-alone pass (A/B, cross-check; tests flip the module attribute)
+# Default: consumers of <= 32 channels on both sides only.  The kernels take every stride-1 3x3 geometry ("2": everywhere), but on
+# the >= 64-channel layers the transform in the weight gradient's staging costs more than the 8-33 MB passes it saves (same box,
+# images/s: off 957.8, <= 32 channels 976.0, everywhere 964.5; profiles/r04_bn_unwritten_fp32.txt).
 FUSE_BN_APPLY_F32 = os.environ.get("UDASEG_FUSE_BN_APPLY_F32", "1") != "0"
+FUSE_BN_APPLY_F32_SMALL_ONLY = os.environ.get("UDASEG_FUSE_BN_APPLY_F32", "1") != "2"
+# ... and through the next decoder block's up-sampling (block output -> conv1 of a block without a skip input): built and tested,
+# off by default -- the 67 MB pass it saves is paid back in the consumer's staging (964.4 with, 966.3 without, 952.9 all off)
+FUSE_BN_APPLY_F32_UP = os.environ.get("UDASEG_FUSE_BN_APPLY_F32_UP", "0") == "1"
 
 
 # bf16 storage: weight gradients of the stride-1 3x3 layers with channel counts that are multiples of 64 on the halo-resident
@@ -538,7 +545,7 @@ class Plan:
         """An empty tensor shaped like activation ``t`` (which may be a LazyAct)."""
         return torch.empty_like(t.y if isinstance(t, LazyAct) else t)
 
-    def _lazy_ok(self, c, n, ho, wo, consumer, act, residual):
+    def _lazy_ok(self, c, n, ho, wo, consumer, act, residual, up=False):
         """May BatchNorm + activation of this [n, ho, wo, c] output stay unwritten?  Only when its single consumer runs on the
         bf16-first kernels in BOTH directions (the forward applies the transform while staging; the data gradient's epilogue
         makes this layer's BatchNorm-backward sums, which then need no activation either)."""
@@ -549,8 +556,17 @@ class Plan:
                 return False
             if consumer.k != 3 or consumer.stride != 1 or consumer.pad != 1 or consumer.cin_p != c or c % 8 != 0:
                 return False
-            d2 = K.conv_desc(n, ho, wo, c, consumer.cout_p, 3, 1, 1)
-            return K.conv_bnin_ok(d2) and self.wfrag(consumer, d2) is not None
+            if FUSE_BN_APPLY_F32_SMALL_ONLY and (c > 32 or consumer.cout_p > 32):
+                return False
+            if up and not FUSE_BN_APPLY_F32_UP:
+                return False
+            # up: the consumer is the next decoder block's conv1 behind a nearest x2 up-sampling, no skip input
+            d2 = K.conv_desc(n, 2 * ho, 2 * wo, c, consumer.cout_p, 3, 1, 1) if up else K.conv_desc(n, ho, wo, c, consumer.cout_p, 3, 1, 1)
+            if up and not K.upcat_fusable(c, 0, consumer.cout_p, torch.float32):      # the consumer block would materialise up(h)
+                return False
+            return K.conv_bnin_ok(d2, up) and self.wfrag(consumer, d2, up_ca=c if up else 0) is not None
+        if up:
+            return False
         if not (FUSE_BN_APPLY and FUSE_BN_REDUCE and self.frag and self.bf16 and consumer is not None and residual is None
                 and act != ACT_NONE):
             return False
@@ -559,7 +575,7 @@ class Plan:
         d2 = K.conv_desc(n, ho, wo, c, consumer.cout_p, consumer.k, 1, consumer.pad)
         return self.wfrag(consumer, d2) is not None and self.wfrag(consumer, d2, dgrad=True) is not None
 
-    def conv_bn_act(self, conv, bn, x, act=ACT_LEAKY, slope=0.0, residual=None, lazy_for=None):
+    def conv_bn_act(self, conv, bn, x, act=ACT_LEAKY, slope=0.0, residual=None, lazy_for=None, lazy_up=False):
         """z = act(bn(conv(x)) (+ residual)); returns (z, record for backward).  In training the conv's epilogue also
         accumulates the BN statistics of its output (no separate pass over y).
 
@@ -583,6 +599,10 @@ class Plan:
                 assert wf is not None, "a LazyAct input needs the bf16-first kernels (decided by the producer)"
                 K.conv2d_fwd_frag(d, x.y, None, wf, bias, y, stats=sums[0], in_scale=x.scale, in_shift=x.shift, in_act=x.act,
                                   in_slope=x.slope, st=self.st)
+            elif wf is not None and up and isinstance(x.a, LazyAct):       # the up-sampled source is an unwritten activation (fp32)
+                assert x.skip is None
+                K.conv2d_fwd_frag(d, x.a.y, None, wf, bias, y, stats=sums[0], in_scale=x.a.scale, in_shift=x.a.shift, in_act=x.a.act,
+                                  in_slope=x.a.slope, up=True, st=self.st)
             elif wf is not None:
                 K.conv2d_fwd_frag(d, x.a if up else x, x.skip if up else None, wf, bias, y, stats=sums[0], up=up, st=self.st)
             elif up:
@@ -590,7 +610,7 @@ class Plan:
             else:
                 K.conv2d_fwd_bnstats(d, x, self.w(conv), bias, y, sums[0], self.st)
             c = ceil4(bn.c)
-            if y.shape[-1] == c and self._lazy_ok(c, n, d.ho, d.wo, lazy_for, act, residual):
+            if y.shape[-1] == c and self._lazy_ok(c, n, d.ho, d.wo, lazy_for, act, residual, lazy_up):
                 so, o = sums
                 mean, rstd = self.saved_stats[o:o + c], self.saved_stats[o + c:o + 2 * c]
                 scale, shift = self.coefs[o:o + c], self.coefs[o + c:o + 2 * c]
@@ -675,7 +695,10 @@ class Plan:
             wst = self.st
         if isinstance(x, UpCat):
             gw = self.gw(conv)
-            if self._wgrad_halo and x.skip is not None and K.conv2d_wgrad_halo_ok(d, x.a.shape[-1], f32=not self.bf16):
+            if isinstance(x.a, LazyAct):
+                assert x.skip is None
+                K.conv2d_wgrad_bnin(d, x.a.y, x.a.scale, x.a.shift, x.a.act, x.a.slope, dy, gw, True, wst, up=True)
+            elif self._wgrad_halo and x.skip is not None and K.conv2d_wgrad_halo_ok(d, x.a.shape[-1], f32=not self.bf16):
                 K.conv2d_wgrad_halo(d, x.a, x.skip, dy, gw, up=True, st=wst)      # both sources in one launch
             else:
                 K.conv2d_wgrad_part(d, x.a, 0, True, dy, gw, True, wst)

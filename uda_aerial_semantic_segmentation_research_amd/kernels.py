@@ -187,16 +187,17 @@ def conv2d_wgrad_halo(d, x, skip, dy, dw, up=False, st=None):
              st), name)
 
 
-def conv_bnin_ok(d):
+def conv_bnin_ok(d, up=False):
     """fp32: can BOTH consumers of an unwritten BatchNorm activation in front of this convolution apply it while staging?
-    (forward on the one-role split kernel, weight gradient on the small-channel direct kernel)"""
-    return bool(ops.udaseg_conv2d_fwd_f32x3_bnin_ok(d)) and bool(ops.udaseg_conv2d_wgrad_bnin_ok(d))
+    (forward on the split kernels, weight gradient on the small-channel direct kernel or the halo-resident split kernel)
+    up: the activation reaches the convolution through a nearest x2 up-sampling (d describes the up-sampled geometry)."""
+    return bool(ops.udaseg_conv2d_fwd_f32x3_bnin_ok(d, int(up))) and bool(ops.udaseg_conv2d_wgrad_bnin_ok(d, int(up)))
 
 
-def conv2d_wgrad_bnin(d, y_prev, in_scale, in_shift, in_act, in_slope, dy, dw, accumulate=False, st=None):
+def conv2d_wgrad_bnin(d, y_prev, in_scale, in_shift, in_act, in_slope, dy, dw, accumulate=False, st=None, up=False):
     """Weight gradient whose gathered operand is act(fma(y_prev, in_scale, in_shift)) (never written), bf16 or fp32."""
     if y_prev.dtype == torch.float32:
-        check(ops.udaseg_conv2d_wgrad_bnin(d, y_prev, in_scale, in_shift, in_act, in_slope, dy, dw, int(accumulate),
+        check(ops.udaseg_conv2d_wgrad_bnin(d, y_prev, int(up), in_scale, in_shift, in_act, in_slope, dy, dw, int(accumulate),
                                            st), "conv2d_wgrad_bnin")
         return
     check(ops.udaseg_conv2d_wgrad_bnin_bf16(d, y_prev, in_scale, in_shift, in_act,
@@ -239,8 +240,8 @@ def conv2d_fwd_frag(d, x, skip, wfrag, bias, y, act=ACT_NONE, slope=0.0, stats=N
     """Halo-resident forward convolution on the bf16 matrix pipe: bf16 tensors (csrc/conv_halo_bf16.hip) or fp32 tensors with
     the three-term split (csrc/conv_halo_f32x3.hip).  up: x is the half-resolution tensor of a fused decoder input."""
     if x.dtype == torch.float32 and in_scale is not None:
-        assert y.dtype == torch.float32 and skip is None and not up
-        check(ops.udaseg_conv2d_fwd_f32x3_bnin(d, x, in_scale, in_shift, in_act, in_slope, wfrag, bias, y, act, slope, stats,
+        assert y.dtype == torch.float32 and skip is None
+        check(ops.udaseg_conv2d_fwd_f32x3_bnin(d, x, int(up), in_scale, in_shift, in_act, in_slope, wfrag, bias, y, act, slope, stats,
                                                st), "conv2d_fwd_f32x3_bnin")
         return
     if x.dtype == torch.float32:

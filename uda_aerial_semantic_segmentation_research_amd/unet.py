@@ -143,9 +143,10 @@ class DecoderBlock(nn.Module):
         self.conv1 = nn.Sequential(ConvP(in_ch + skip_ch, out_ch, 3, 1, 1), BNP(out_ch))
         self.conv2 = nn.Sequential(ConvP(out_ch, out_ch, 3, 1, 1), BNP(out_ch))
 
-    def fwd(self, P, x, skip, lazy_for=None):
+    def fwd(self, P, x, skip, lazy_for=None, lazy_up=False):
         """lazy_for: the convolution that is the ONLY consumer of this block's output (the segmentation head behind the last
-        block), or None: the output's BatchNorm + ReLU may then stay unwritten (engine.LazyAct)."""
+        block; lazy_up: the next block's conv1 behind its up-sampling, when that block has no skip input), or None: the output's
+        BatchNorm + ReLU may then stay unwritten (engine.LazyAct)."""
         ca, cb = x.shape[-1], 0 if skip is None else skip.shape[-1]
         if self.upsample == "bilinear":      # north_star's alternate mode: a stand-alone HBM-bound pass (csrc/bilinear.hip)
             cat = K.upsample2x_bilinear_concat_fwd(x, skip, P.st)
@@ -154,7 +155,7 @@ class DecoderBlock(nn.Module):
         else:
             cat = K.upsample2x_concat_fwd(x, skip, P.st)
         a1, r1 = P.conv_bn_act(self.conv1[0], self.conv1[1], cat, *RELU, lazy_for=self.conv2[0])   # a1 feeds conv2 only
-        out, r2 = P.conv_bn_act(self.conv2[0], self.conv2[1], a1, *RELU, lazy_for=lazy_for)
+        out, r2 = P.conv_bn_act(self.conv2[0], self.conv2[1], a1, *RELU, lazy_for=lazy_for, lazy_up=lazy_up)
         return out, (x, skip, cat, a1, r1, r2)
 
     @staticmethod
@@ -326,8 +327,12 @@ class Unet(ArenaModule):
         for i, blk in enumerate(self.decoder.blocks):
             skip = skips[i] if i < len(skips) else None
             # the last block's output feeds the head alone unless the caller asked for the decoder features as well
-            only_head = head if (i == nblk - 1 and "logits" in want and "decoder" not in want) else None
-            h, rec = blk.fwd(P, h, skip, lazy_for=only_head)
+            only, only_up = None, False
+            if i == nblk - 1:
+                only = head if ("logits" in want and "decoder" not in want) else None
+            elif i + 1 >= len(skips) and self.decoder.blocks[i + 1].upsample != "bilinear" and FUSE_UPCAT:
+                only, only_up = self.decoder.blocks[i + 1].conv1[0], True      # the next block gathers up(h) alone
+            h, rec = blk.fwd(P, h, skip, lazy_for=only, lazy_up=only_up)
             tape.append((blk, rec, h))
         logits, d_head = None, None
         if "logits" in want:
