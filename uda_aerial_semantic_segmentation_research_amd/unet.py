@@ -329,8 +329,9 @@ class Unet(ArenaModule):
             # the last block's output feeds the head alone unless the caller asked for the decoder features as well
             only, only_up = None, False
             if i == nblk - 1:
-                only = head if ("logits" in want and "decoder" not in want) else None
-            elif i + 1 >= len(skips) and self.decoder.blocks[i + 1].upsample != "bilinear" and FUSE_UPCAT:
+                # (fp32 only: the bf16 form needs the consumer's data gradient to make this layer's BatchNorm-backward sums)
+                only = head if ("logits" in want and "decoder" not in want and not P.bf16) else None
+            elif i + 1 >= len(skips) and self.decoder.blocks[i + 1].upsample != "bilinear" and FUSE_UPCAT and not P.bf16:
                 only, only_up = self.decoder.blocks[i + 1].conv1[0], True      # the next block gathers up(h) alone
             h, rec = blk.fwd(P, h, skip, lazy_for=only, lazy_up=only_up)
             tape.append((blk, rec, h))
