@@ -708,8 +708,7 @@ static int launch_f3_ws_t(F3Args a, hipStream_t s, double flops) {
   static int kid = -1;
   if (kid < 0) {
     char nm[96];
-    if (TW == 32) snprintf(nm, sizeof(nm), "conv3x3_f32x3_ws_kernel<%d, %d, %d>", WM, WN, RPW);
-    else snprintf(nm, sizeof(nm), "conv3x3_f32x3_ws_kernel<%d, %d, %d, false, %d>", WM, WN, RPW, TW);
+    snprintf(nm, sizeof(nm), "conv3x3_f32x3_ws_kernel<%d, %d, %d, false, %d, false>", WM, WN, RPW, TW);      // the rocprofv3 symbol
     kid = kprof_id(nm);
   }
   hipEvent_t ev = kprof_begin(s);
@@ -780,7 +779,7 @@ static int launch_f3_t(F3Args a, hipStream_t s, double flops) {
   static int kid = -1;
   if (kid < 0) {
     char nm[96];
-    snprintf(nm, sizeof(nm), "conv3x3_f32x3_kernel<%d, %d, %d>", WM, WN, RPW);
+    snprintf(nm, sizeof(nm), "conv3x3_f32x3_kernel<%d, %d, %d, false>", WM, WN, RPW);
     kid = kprof_id(nm);
   }
   hipEvent_t ev = kprof_begin(s);

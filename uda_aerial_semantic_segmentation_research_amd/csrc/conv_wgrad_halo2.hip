@@ -417,7 +417,7 @@ static int launch_h2_t(const udaseg_conv_desc* d, const void* x, const void* x2,
   static int kid = -1;
   if (kid < 0) {
     char nm[96];
-    snprintf(nm, sizeof(nm), "conv_wgrad_h2_kernel<%d, %d, %d, %d, %d, %d, %s>", PL, COQ, CIQ, TR, TWK, NSTW, DB ? "true" : "false");
+    snprintf(nm, sizeof(nm), "conv_wgrad_h2_kernel<%d, %d, %d, %d, %d, %d, %s, false, false>", PL, COQ, CIQ, TR, TWK, NSTW, DB ? "true" : "false");
     kid = kprof_id(nm);
   }
   hipEvent_t ev = kprof_begin(s);
