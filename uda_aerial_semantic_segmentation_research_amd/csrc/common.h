@@ -1,5 +1,6 @@
 // Shared host/device helpers for libudaseg_hip.so (gfx950 only).
 #pragma once
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -176,7 +177,8 @@ struct StreamShape {
 };
 
 // Choose block/grid so grid*bs is a multiple of c4 (see header comment).
-static inline StreamShape stream_shape(int64_t n4, int c4, int max_blocks = 2048) {
+// per_thread: vectors a thread streams (4: measured best for every kernel that uses this shape)
+static inline StreamShape stream_shape(int64_t n4, int c4, int max_blocks = 2048, int per_thread = 4) {
   StreamShape s;
   s.c4 = c4;
   int unit;  // grid must be a multiple of `unit`
@@ -188,7 +190,7 @@ static inline StreamShape stream_shape(int64_t n4, int c4, int max_blocks = 2048
     unit = (c4 + 255) / 256;
     while ((unit * 256) % c4 != 0) ++unit;  // c4 = 512 -> 2
   }
-  int64_t want = (n4 + (int64_t)s.bs * 4 - 1) / ((int64_t)s.bs * 4);  // ~4 float4 per thread
+  int64_t want = (n4 + (int64_t)s.bs * per_thread - 1) / ((int64_t)s.bs * per_thread);
   if (want > max_blocks) want = max_blocks;
   if (want < 1) want = 1;
   s.grid = (int)(((want + unit - 1) / unit) * unit);
@@ -197,6 +199,21 @@ static inline StreamShape stream_shape(int64_t n4, int c4, int max_blocks = 2048
   return s;
 }
 
+
+// vectors per thread of the BatchNorm apply kernels (UDASEG_BN_APPLY_PT: tuning aid).  Every block of these kernels opens with a pass
+// over the 16 replicated f64 accumulator sets (256 bytes per channel, ~33 MB per launch over all blocks), which suggested fewer, longer
+// blocks for the <= 17 MB layers: measured and NOT so -- 4 / 8 / 16 / 32 / 64 vectors per thread leave the small layers at the same
+// ~6-7 us device time (tools/bn_bandwidth.py's 14 us floor is the host's launch rate) and the step is best at 4 (977 against 972
+// images/s at 16, same box).
+static inline int apply_per_thread() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("UDASEG_BN_APPLY_PT");
+    v = e ? atoi(e) : 4;
+    if (v < 1 || v > 256) v = 4;
+  }
+  return v;
+}
 
 // small-channel direct 3x3 kernels (conv_small.hip)
 bool small_conv_applicable(int k, int stride, int pad, int ci_gather, int co_out);

@@ -564,7 +564,7 @@ extern "C" int udaseg_bn_apply_bf16(const void* y, const double* sums, const flo
   if (rc) return rc;
   UDASEG_CHECK_ARG(y && sums && gamma && beta && z, "bn_apply_bf16: NULL pointer");
   const int64_t n8 = pixels * (c / 8);
-  const StreamShape s = stream_shape(n8, c / 8);
+  const StreamShape s = stream_shape(n8, c / 8, 2048, apply_per_thread());
   static int kid_bn_apply_bf16_kernel = -1;
   KTimer kt_bn_apply_bf16_kernel(&kid_bn_apply_bf16_kernel, "bn_apply_bf16_kernel", as_stream(stream), (double)pixels * c * 2.0 * (residual ? 3.0 : 2.0));
   hipLaunchKernelGGL(bn_apply_bf16_kernel, dim3(s.grid), dim3(s.bs), (size_t)2 * c * sizeof(float), as_stream(stream),
@@ -613,7 +613,7 @@ extern "C" int udaseg_bn_bwd_apply_bf16(const void* dz, const void* z, const voi
                    "bn_bwd_apply_bf16: NULL pointer");
   UDASEG_CHECK_ARG((size_t)5 * c * sizeof(float) <= 65536, "bn_bwd_apply_bf16: too many channels");
   const int64_t n8 = pixels * (c / 8);
-  const StreamShape s = stream_shape(n8, c / 8);
+  const StreamShape s = stream_shape(n8, c / 8, 2048, apply_per_thread());
   static int kid_bwa = -1;
   KTimer kt_bwa(&kid_bwa, "bn_bwd_apply_bf16_kernel", as_stream(stream), (double)pixels * c * 2.0 * ((act != UDASEG_ACT_NONE ? 4.0 : 3.0) + (dres ? 1.0 : 0.0)));
   hipLaunchKernelGGL(bn_bwd_apply_bf16_kernel, dim3(s.grid), dim3(s.bs), (size_t)5 * c * sizeof(float), as_stream(stream),
@@ -634,7 +634,7 @@ extern "C" int udaseg_bn_bwd_apply_recompute_bf16(const void* dz, const void* y,
                    "bn_bwd_apply_recompute_bf16: NULL pointer");
   UDASEG_CHECK_ARG((size_t)7 * c * sizeof(float) <= 65536, "bn_bwd_apply_recompute_bf16: too many channels");
   const int64_t n8 = pixels * (c / 8);
-  const StreamShape s = stream_shape(n8, c / 8);
+  const StreamShape s = stream_shape(n8, c / 8, 2048, apply_per_thread());
   static int kid_bwr = -1;
   KTimer kt_bwr(&kid_bwr, "bn_bwd_apply_bf16_kernel", as_stream(stream), (double)pixels * c * 2.0 * 3.0);
   hipLaunchKernelGGL(bn_bwd_apply_bf16_kernel, dim3(s.grid), dim3(s.bs), (size_t)7 * c * sizeof(float), as_stream(stream),
