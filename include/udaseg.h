@@ -50,6 +50,11 @@ int udaseg_set_option(int key, int value);
 const char* udaseg_last_error(void);
 /* number of HIP devices visible to the library (0 on a CPU-only box; never initialises a context) */
 int udaseg_device_count(void);
+/* Host-side helpers of the launch plan (no reference counterpart: what `torch.zeros` / `stream.wait_stream` do for the reference's
+ * eager ops, at a tenth of their host cost -- BASELINE cfg 3 is bound by the host's launch rate).  udaseg_memset_async: byte fill of
+ * a device buffer in stream order; udaseg_stream_wait: `waiter` waits for everything enqueued on `signal` so far. */
+int udaseg_memset_async(void* ptr, int value, size_t bytes, void* stream);
+int udaseg_stream_wait(void* waiter_stream, void* signal_stream);
 
 /* Geometry of one 2-D convolution, NHWC. hi/wi/ci: input; ho/wo/co: output; square stride, symmetric pad.
  * ci and co are the PHYSICAL channel counts (multiples of 4). */

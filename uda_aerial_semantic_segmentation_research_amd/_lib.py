@@ -29,6 +29,8 @@ SIGNATURES = {
     "udaseg_version": (_I, []),
     "udaseg_last_error": (C.c_char_p, []),
     "udaseg_device_count": (_I, []),
+    "udaseg_memset_async": (_I, [_P, _I, C.c_size_t, _P]),
+    "udaseg_stream_wait": (_I, [_P, _P]),
     "udaseg_conv2d_fwd": (_I, [_D, _P, _P, _P, _P, _I, _F, _I, _P]),
     "udaseg_conv2d_fwd_bnstats": (_I, [_D, _P, _P, _P, _P, _P, _P]),
     "udaseg_conv2d_fwd_fused": (_I, [_D, _P, _P, _P, _P, _P, _I, _F, _P]),

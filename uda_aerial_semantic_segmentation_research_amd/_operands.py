@@ -70,6 +70,8 @@ OPERANDS = {
     "udaseg_prof_records": [I("family"), I("max_records"), H("ms"), H("flops"), H("kind"), H("desc11")],
     # caller-owned scratch bound to the current device
     "udaseg_set_workspace": [T("ptr", u8, "bytes", opt=True), I("bytes")],
+    "udaseg_memset_async": [T("ptr", "raw32", "(bytes+3)//4"), I("value"), I("bytes"), S],
+    "udaseg_stream_wait": [H("waiter"), H("signal")],      # two hipStream_t handles, passed through
     "udaseg_set_stats_scratch": [T("ptr", u8, "bytes", opt=True), I("bytes")],
     "udaseg_debug_set_timeline": [T("buffer", i64, "6*blocks", opt=True), I("blocks")],
     # ---- convolutions, fp32 storage

@@ -142,6 +142,42 @@ extern "C" int udaseg_device_count(void) {
   return n;
 }
 
+// ---- host-side helpers for the Python plan (round 4: BASELINE cfg 3 is bound by the HOST's launch rate, profiles/r04_host_bound.txt;
+// a torch fill costs ~30 us of host time, a torch.cuda.Event pair ~8 us, these 3 us each)
+extern "C" int udaseg_memset_async(void* ptr, int value, size_t bytes, void* stream) {
+  UDASEG_CHECK_ARG(ptr != nullptr || bytes == 0, "memset_async: NULL pointer");
+  if (bytes == 0) return UDASEG_OK;
+  hipError_t e = hipMemsetAsync(ptr, value, bytes, as_stream(stream));
+  if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync");
+  return UDASEG_OK;
+}
+
+// `waiter` does not run past this point before everything enqueued on `signal` so far has finished (an event from a per-device ring:
+// hipStreamWaitEvent captures the record it waits for at call time, so a slot may be recorded again while older waits are pending)
+extern "C" int udaseg_stream_wait(void* waiter, void* signal) {
+  constexpr int RING = 256;
+  static hipEvent_t ring[16][RING];
+  static bool made[16] = {};
+  static unsigned next[16] = {};
+  static std::mutex mu;
+  int dev = 0;
+  UDASEG_CHECK_ARG(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16, "stream_wait: no current HIP device");
+  std::lock_guard<std::mutex> lk(mu);
+  if (!made[dev]) {
+    for (int i = 0; i < RING; ++i) {
+      hipError_t e = hipEventCreateWithFlags(&ring[dev][i], hipEventDisableTiming);
+      if (e != hipSuccess) return hip_fail(e, "hipEventCreateWithFlags(stream_wait ring)");
+    }
+    made[dev] = true;
+  }
+  hipEvent_t ev = ring[dev][next[dev]++ % RING];
+  hipError_t e = hipEventRecord(ev, as_stream(signal));
+  if (e != hipSuccess) return hip_fail(e, "hipEventRecord(stream_wait)");
+  e = hipStreamWaitEvent(as_stream(waiter), ev, 0);
+  if (e != hipSuccess) return hip_fail(e, "hipStreamWaitEvent(stream_wait)");
+  return UDASEG_OK;
+}
+
 extern "C" int udaseg_prof_enable(int on) {
   g_prof_on = on != 0;
   return UDASEG_OK;

@@ -436,7 +436,7 @@ class Plan:
         nbn = net._nbn
         self.dev = dev
         if training:
-            self.stats = torch.zeros(max(nbn, 2) * self.R, dtype=torch.float64, device=dev)  # [R][sum | sumsq] per BN
+            self.stats = K.zeros((max(nbn, 2) * self.R,), torch.float64, dev, self.st)  # [R][sum | sumsq] per BN
             self.saved_stats = torch.empty(max(nbn, 2), dtype=torch.float32, device=dev)  # [mean | rstd] per BN
             self.coefs = torch.empty(max(nbn, 2), dtype=torch.float32, device=dev)  # [scale | shift] of lazy BNs
         else:
@@ -650,9 +650,11 @@ class Plan:
         # weight gradients are off the backward critical path (only Adam / the all-reduce consume them): they run on a
         # side HIP stream and fill the matrix cores while the main chain sits in HBM-bound BatchNorm-backward kernels
         self.side_stream = net._side_stream() if SIDE_STREAM_WGRAD else None
-        self.garena = torch.zeros_like(net._arena)
+        self.garena = K.zeros_like(net._arena, self.st)
         nbn = net._nbn
-        self.bstats = torch.zeros(max(nbn, 2) * self.R, dtype=torch.float64, device=self.dev)
+        self.bstats = K.zeros((max(nbn, 2) * self.R,), torch.float64, self.dev, self.st)
+        self._side_h = self.side_stream.cuda_stream if self.side_stream is not None else None
+        self._main_h = self.main_stream.cuda_stream
         self._bstat_off = 0
         # dgrad needs the weights as [ci][taps][co]: one batched repack of the whole arena per step, normally issued
         # on the side stream at the start of the forward (_prepack_dgrad_weights)
@@ -686,10 +688,8 @@ class Plan:
         backward (``bn_bwd`` finds them in ``self._bnb`` and skips its reduce pass)."""
         side = self.side_stream
         if side is not None:
-            ev = torch.cuda.Event()
-            ev.record(self.main_stream)                         # dy is final here
-            side.wait_event(ev)
-            wst = side.cuda_stream
+            wst = self._side_h
+            K.stream_wait(wst, self._main_h)                    # dy is final here (a pooled event inside the library)
             dy.record_stream(side)                              # the caching allocator must not recycle dy under the side stream
         else:
             wst = self.st

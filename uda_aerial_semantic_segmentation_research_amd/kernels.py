@@ -17,6 +17,24 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def zeros(shape, dtype, device, st=None):
+    """torch.zeros at a sixth of its host cost: torch.empty + one hipMemsetAsync on the plan's stream (a torch fill costs ~30 us of
+    host time on this stack, and BASELINE cfg 3 is bound by the host's launch rate: profiles/r04_host_bound.txt)."""
+    t = torch.empty(shape, dtype=dtype, device=device)
+    check(ops.udaseg_memset_async(t, 0, t.numel() * t.element_size(), st), "memset_async")
+    return t
+
+
+def zeros_like(x, st=None):
+    return zeros(x.shape, x.dtype, x.device, st)
+
+
+def stream_wait(waiter, signal):
+    """Stream ``waiter`` (a hipStream_t handle) waits for everything enqueued on ``signal`` so far -- torch's
+    ``Event().record(signal); waiter.wait_event(ev)`` at a third of its host cost (a pooled event inside the library)."""
+    check(ops.udaseg_stream_wait(waiter, signal), "stream_wait")
+
+
 _WORKSPACE = {}
 
 
