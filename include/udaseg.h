@@ -477,6 +477,9 @@ int udaseg_debug_set_timeline(void* buffer, int blocks);
 /* ---- small utilities ---- */
 int udaseg_fill_f32(float* p, int64_t count, float value, void* stream);
 int udaseg_axpy_f32(float* y, const float* x, int64_t count, float alpha, void* stream); /* y += alpha*x */
+/* p[i] += value, int64: num_batches_tracked of every nn.BatchNorm2d of a network (views of one arena) in one launch; reference
+ * src/models/train.py:341 (training-mode forward) */
+int udaseg_add_i64(int64_t* p, int64_t count, int64_t value, void* stream);
 int udaseg_scale_f32(const float* x, float* y, int64_t count, float alpha, void* stream); /* y = alpha*x: gradient reversal,
                                                                                          * src/models/uda.py:99-111 */
 

@@ -140,6 +140,7 @@ SIGNATURES = {
     "udaseg_debug_set_timeline": (_I, [_P, _I]),
     "udaseg_fill_f32": (_I, [_P, _L, _F, _P]),
     "udaseg_axpy_f32": (_I, [_P, _P, _L, _F, _P]),
+    "udaseg_add_i64": (_I, [_P, _L, _L, _P]),
     "udaseg_prof_enable": (_I, [_I]),
     "udaseg_prof_reset": (_I, []),
     "udaseg_prof_read": (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

@@ -276,6 +276,7 @@ OPERANDS = {
                          F("beta1"), F("beta2"), F("eps"), F("bc1"), F("bc2"), S],
     "udaseg_fill_f32": [T("p", f32, "count"), I("count"), F("value"), S],
     "udaseg_axpy_f32": [T("y", f32, "count"), T("x", f32, "count"), I("count"), F("alpha"), S],
+    "udaseg_add_i64": [T("p", i64, "count"), I("count"), I("value"), S],
     "udaseg_scale_f32": [T("x", f32, "count"), T("y", f32, "count"), I("count"), F("alpha"), S],
 }
 

@@ -174,6 +174,11 @@ __global__ void scale_kernel(const float* __restrict__ x, float* __restrict__ y,
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += T) y[i] = alpha * x[i];
 }
 
+__global__ void add_i64_kernel(long long* __restrict__ p, int64_t n, long long v) {
+  const int64_t T = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += T) p[i] += v;
+}
+
 static inline int grid_for(int64_t items, int per_thread = 2) {
   int64_t g = (items + 256LL * per_thread - 1) / (256LL * per_thread);
   if (g > 4096) g = 4096;
@@ -264,6 +269,17 @@ extern "C" int udaseg_axpy_f32(float* y, const float* x, int64_t count, float al
   if (count == 0) return UDASEG_OK;
   hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(count, 4)), dim3(256), 0, as_stream(stream), y, x, count, alpha);
   UDASEG_LAUNCH_CHECK("axpy launch");
+  return UDASEG_OK;
+}
+
+/* p[i] += value on int64 (nn.BatchNorm2d's num_batches_tracked += 1 for every BatchNorm of a network in ONE launch: the buffers are
+ * views of one arena; a torch add_ costs ~38 us of host time, this 4; reference src/models/train.py:341 in training mode) */
+extern "C" int udaseg_add_i64(int64_t* p, int64_t count, int64_t value, void* stream) {
+  UDASEG_CHECK_ARG(p && count >= 0, "add_i64: bad arguments");
+  if (count == 0) return UDASEG_OK;
+  hipLaunchKernelGGL(add_i64_kernel, dim3(grid_for(count, 4)), dim3(256), 0, as_stream(stream), reinterpret_cast<long long*>(p), count,
+                     (long long)value);
+  UDASEG_LAUNCH_CHECK("add_i64 launch");
   return UDASEG_OK;
 }
 

@@ -191,6 +191,7 @@ class ArenaModule(nn.Module):
         self._arena = None          # flat fp32 parameters
         self._buf_arena = None      # flat fp32 BN running stats
         self._entries = []          # (param, offset, numel_physical, physical_shape, logical_view_fn)
+        self._pvec_cache = {}       # (id(module), name) -> view of the arena (Plan.pvec)
         self._param_list = []
         self._wt_arena = None       # dgrad-packed weights (scratch, refreshed every backward)
         self._wt_off = {}
@@ -354,7 +355,10 @@ class ArenaModule(nn.Module):
         return st
 
     def tick_batchnorm_counters(self):
-        self._nbt.add_(1)
+        if self._nbt.is_cuda:
+            K.check(K.ops.udaseg_add_i64(self._nbt, self._nbt.numel(), 1, None), "add_i64")      # one 4-us call instead of a torch add_
+        else:
+            self._nbt.add_(1)
 
     def _apply(self, fn, *a, **kw):
         out = super()._apply(fn, *a, **kw)
@@ -407,11 +411,18 @@ class ArenaModule(nn.Module):
                     p.grad.add_(g)
 
     def grad_views(self, garena):
-        """Logical-shape gradient views (one per parameter, in ``self._param_list`` order) over a grad arena."""
-        outs = []
-        for p, o, n, shp, mod, name in self._entries:
-            outs.append(self._logical_view(garena[o:o + n], mod, name, tuple(p.shape)))
-        return outs
+        """Logical-shape gradient views (one per parameter, in ``self._param_list`` order) over a grad arena: ONE as_strided per
+        parameter from a cached (size, stride, offset) recipe -- the slice / view / slice / permute chain they replace cost 0.35 ms
+        of host time per backward pass (92 parameters), and BASELINE cfg 3 is close to host-bound (profiles/r04_host_bound.txt)."""
+        rec = getattr(self, "_view_recipes", None)
+        if rec is None or rec[0] is not self._entries:
+            rs = []
+            for p, o, n, shp, mod, name in self._entries:
+                v = self._logical_view(garena[o:o + n], mod, name, tuple(p.shape))
+                rs.append((tuple(v.shape), tuple(v.stride()), v.storage_offset() - garena.storage_offset()))
+            rec = self._view_recipes = (self._entries, rs)
+        base = garena.storage_offset()
+        return [garena.as_strided(sz, st, base + off) for sz, st, off in rec[1]]
 
 
 class Plan:
@@ -476,16 +487,23 @@ class Plan:
         return self.net._arena[o:o + n]
 
     def pvec(self, mod, name):
-        o, n, shp = self.idx[(id(mod), name)]
-        return self.net._arena[o:o + n]
+        # parameter vectors are views of the network's arena, which lives as long as the network does: cached there (a slice costs
+        # ~1.3 us of host time, a step asks for ~140 of them)
+        cache = self.net.__dict__.setdefault("_pvec_cache", {})
+        key = (id(mod), name)
+        v = cache.get(key)
+        if v is None or v._base is not self.net._arena:
+            o, n, shp = self.idx[key]
+            v = cache[key] = self.net._arena[o:o + n]
+        return v
 
     def gvec(self, mod, name):
         o, n, shp = self.idx[(id(mod), name)]
-        return self.garena[o:o + n]
+        return self.garena.as_strided((n,), (1,), o)
 
     def gw(self, conv):
         o, n, shp = self.idx[(id(conv), "weight")]
-        return self.garena[o:o + n].view(shp)
+        return self.garena.as_strided(shp, (shp[1] * shp[2] * shp[3], shp[2] * shp[3], shp[3], 1), o)
 
     def offset_of(self, mod, name="weight"):
         return self.idx[(id(mod), name)][0]
