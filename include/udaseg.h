@@ -447,9 +447,13 @@ int udaseg_conv2d_fwd_f32x3(const udaseg_conv_desc* d, const float* x, const flo
  * argument from its conv output already (udaseg_bn_bwd_reduce / _apply with z = NULL).  nn.BatchNorm2d + nn.ReLU in front of a
  * 3x3 convolution inside smp.Unet's decoder blocks and head, reference src/models/train.py:341,343. */
 int udaseg_conv2d_fwd_f32x3_bnin_ok(const udaseg_conv_desc* d, int up);
+/* z_out != NULL (plain source, launches for which udaseg_conv2d_fwd_f32x3_bnin_writes says 1: the wave-specialised kernel): the
+ * loader waves also WRITE the transformed activation ([n][hi][wi][ci], bit for bit udaseg_bn_apply's output) -- the convolution's
+ * weight gradient then reads it like any activation; saved: bn_apply's launch and its read of x */
+int udaseg_conv2d_fwd_f32x3_bnin_writes(const udaseg_conv_desc* d);
 int udaseg_conv2d_fwd_f32x3_bnin(const udaseg_conv_desc* d, const float* x, int up, const float* in_scale, const float* in_shift,
-                                 int in_act, float in_slope, const void* wfrag3, const float* bias, float* y, int act, float slope,
-                                 double* stats, void* stream);
+                                 int in_act, float in_slope, float* z_out, const void* wfrag3, const float* bias, float* y, int act,
+                                 float slope, double* stats, void* stream);
 int udaseg_conv2d_wgrad_bnin_ok(const udaseg_conv_desc* d, int up);
 int udaseg_conv2d_wgrad_bnin(const udaseg_conv_desc* d, const float* x, int up, const float* in_scale, const float* in_shift,
                              int in_act, float in_slope, const float* dy, float* dw, int accumulate, void* stream);

@@ -131,7 +131,8 @@ SIGNATURES = {
     "udaseg_conv_f32x3_preferred": (_I, [_D, _I, _I]),
     "udaseg_conv2d_fwd_f32x3": (_I, [_D, _P, _P, _I, _P, _P, _P, _I, _F, _P, _P]),
     "udaseg_conv2d_fwd_f32x3_bnin_ok": (_I, [_D, _I]),
-    "udaseg_conv2d_fwd_f32x3_bnin": (_I, [_D, _P, _I, _P, _P, _I, _F, _P, _P, _P, _I, _F, _P, _P]),
+    "udaseg_conv2d_fwd_f32x3_bnin_writes": (_I, [_D]),
+    "udaseg_conv2d_fwd_f32x3_bnin": (_I, [_D, _P, _I, _P, _P, _I, _F, _P, _P, _P, _P, _I, _F, _P, _P]),
     "udaseg_conv2d_wgrad_bnin_ok": (_I, [_D, _I]),
     "udaseg_conv2d_wgrad_bnin": (_I, [_D, _P, _I, _P, _P, _I, _F, _P, _P, _I, _P]),
     "udaseg_conv2d_dgrad_f32x3": (_I, [_D, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _F, _P, _I, _P]),

@@ -58,6 +58,7 @@ OPERANDS = {
     "udaseg_set_option": [I("key"), I("value")],
     "udaseg_conv2d_dgrad_bnreduce_ok": [D], "udaseg_conv2d_dgrad_bnreduce_bf16_ok": [D], "udaseg_conv_flops": [D],
     "udaseg_conv2d_fwd_f32x3_bnin_ok": [D, I("up")], "udaseg_conv2d_wgrad_bnin_ok": [D, I("up")],
+    "udaseg_conv2d_fwd_f32x3_bnin_writes": [D],
     "udaseg_workspace_bytes": [D],
     "udaseg_channel_sum_scratch_bytes": [I("c")], "udaseg_gap_splits": [I("hw")], "udaseg_frag_elems": [I("n_out"), I("k_in"), I("ks")],
     "udaseg_conv2d_wgrad_halo_bf16_ok": [D, I("up_ca")], "udaseg_conv2d_wgrad_halo_f32x3_ok": [D, I("up_ca")],
@@ -99,7 +100,8 @@ OPERANDS = {
                                 I("act"), F("slope"), T("stats", f64, "2*co*R", True), S],
     "udaseg_conv2d_fwd_f32x3_bnin": [D, T("x", f32, "(" + _HALF + "*ci if up else X)"), I("up"), T("in_scale", f32, "ci"),
                                      T("in_shift", f32, "ci"), I("in_act"),
-                                     F("in_slope"), T("wfrag3", bf16, "3*frag(co,ci,kh)"), T("bias", f32, "co", True), T("y", f32, "Y"),
+                                     F("in_slope"), T("z_out", f32, "X", True), T("wfrag3", bf16, "3*frag(co,ci,kh)"),
+                                     T("bias", f32, "co", True), T("y", f32, "Y"),
                                      I("act"), F("slope"), T("stats", f64, "2*co*R", True), S],
     "udaseg_conv2d_wgrad_bnin": [D, T("x", f32, "(" + _HALF + "*ci if up else X)"), I("up"), T("in_scale", f32, "ci"),
                                  T("in_shift", f32, "ci"), I("in_act"),

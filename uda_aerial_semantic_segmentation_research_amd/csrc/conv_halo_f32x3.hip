@@ -68,6 +68,12 @@ struct F3Args {
   const float* in_shift;
   int in_act;
   float in_slope;
+  // ... and WRITE it out on the way (wave-specialised kernel only): the loader waves of the blocks of channel block 0 store the
+  // transformed pixels of their tile's interior to z_out ([n][h][w][ci], the layout of x) -- bit for bit what udaseg_bn_apply would
+  // have stored.  The consumer's weight gradient then reads z_out like any activation; what is saved is bn_apply's launch and its
+  // read of x.  null: nothing is written.
+  float* z_out;
+  unsigned z_bytes;
   unsigned x_bytes, x2_bytes, w_plane_bytes, y_bytes, y2_bytes, bnb_bytes;
   unsigned long long* timeline;   // diagnosis (udaseg_debug_set_timeline; stamped twin of the wave-specialised kernel only)
 };
@@ -402,6 +408,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_f32x3_ws_kernel(const F3Args a
     const int lt = tid - 256;
     const int oct = lt & 1;
     unsigned voff[C::NI], voff2[C::NI], soffl[C::NI];
+    unsigned zmask = 0;
     const bool UPC = a.up_ca > 0;
     const int cx = UPC ? a.up_ca : a.ci, cx2 = a.ci - a.up_ca;
 #pragma unroll
@@ -419,11 +426,17 @@ __global__ __launch_bounds__(512, 1) void conv3x3_f32x3_ws_kernel(const F3Args a
         voff2[i] = 0x80000000u;
       }
       soffl[i] = (unsigned)(pix * 32 + ((oct ^ ((hx >> 3) & 1)) * 16));
+      if constexpr (XF) {
+        if (ok && hy >= 1 && hy <= C::TH && hx >= 1 && hx <= C::TW) zmask |= 1u << i;       // the tile's own pixels (F3Args::z_out)
+      }
     }
     __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t rs_x2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(UPC && a.x2 ? a.x2 : a.x), 0,
                                                                      (int)(UPC && a.x2 ? a.x2_bytes : 0u), 0x00020000);
     __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wf), 0, (int)(3u * a.w_plane_bytes), 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc(XF && a.z_out ? a.z_out : const_cast<float*>(a.x), 0,
+                                                                    (int)(XF && a.z_out ? a.z_bytes : 0u), 0x00020000);
+    const bool zwrite = XF && a.z_out != nullptr && cb == 0 && !UPC;
     const int frag_per_nb = 3 * a.nk16 * 3;
     int wbase[C::NWI];
     const unsigned wlane16 = (unsigned)lane * 16u;
@@ -492,6 +505,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_f32x3_ws_kernel(const F3Args a
             }
             stage[i][0] = __builtin_bit_cast(u32x4, l);
             stage[i][1] = __builtin_bit_cast(u32x4, h);
+            if (zwrite && ((zmask >> i) & 1u) && c * 16 + oct * 8 < a.ci) {       // write-through of the activation
+              __builtin_amdgcn_raw_buffer_store_b128(stage[i][0], rs_z, (int)voff[i], c * 64, 0);
+              __builtin_amdgcn_raw_buffer_store_b128(stage[i][1], rs_z, (int)voff[i], c * 64 + 16, 0);
+            }
           }
           u32x4 p0, p1, p2;
           split3(stage[i][0], stage[i][1], p0, p1, p2);
@@ -946,9 +963,16 @@ extern "C" int udaseg_conv2d_fwd_f32x3_bnin_ok(const udaseg_conv_desc* d, int up
   return d && f3_applicable(d, d->ci, d->co, up ? d->ci : 0) ? 1 : 0;
 }
 
+// 1: this launch would take the wave-specialised kernel, whose loader waves can write the transformed activation out (z_out)
+extern "C" int udaseg_conv2d_fwd_f32x3_bnin_writes(const udaseg_conv_desc* d) {
+  if (!d || !f3_applicable(d, d->ci, d->co, 0)) return 0;
+  const int ch = f3_choice(d->hi, d->wi, d->n, d->ci, d->co);
+  return (ch == 5 || ch == 6 || (ch >= 7 && ch <= 12)) ? 1 : 0;
+}
+
 extern "C" int udaseg_conv2d_fwd_f32x3_bnin(const udaseg_conv_desc* d, const float* x, int up, const float* in_scale,
-                                            const float* in_shift, int in_act, float in_slope, const void* wfrag3, const float* bias,
-                                            float* y, int act, float slope, double* stats, void* stream) {
+                                            const float* in_shift, int in_act, float in_slope, float* z_out, const void* wfrag3,
+                                            const float* bias, float* y, int act, float slope, double* stats, void* stream) {
   F3Args a = {};
   int rc = f3_common(d, a, "conv2d_fwd_f32x3_bnin");
   if (rc) return rc;
@@ -963,6 +987,13 @@ extern "C" int udaseg_conv2d_fwd_f32x3_bnin(const udaseg_conv_desc* d, const flo
   a.in_scale = in_scale; a.in_shift = in_shift; a.in_act = in_act; a.in_slope = in_slope;
   a.ci = d->ci; a.co = d->co;
   a.up_ca = up ? d->ci : 0;            // up: x is the half-resolution tensor behind a nearest x2 up-sampling (no skip source)
+  if (z_out != nullptr) {
+    UDASEG_CHECK_ARG(!up && udaseg_conv2d_fwd_f32x3_bnin_writes(d),
+                     "conv2d_fwd_f32x3_bnin: z_out needs a plain source and a launch on the wave-specialised kernel (ask "
+                     "udaseg_conv2d_fwd_f32x3_bnin_writes)");
+    a.z_out = z_out;
+    a.z_bytes = (unsigned)(px * d->ci * 4);
+  }
   a.act = act; a.slope = slope; a.stats = stats;
   a.x_bytes = (unsigned)(up ? (long long)d->n * (d->hi / 2) * (d->wi / 2) * d->ci * 4 : px * d->ci * 4);
   a.w_plane_bytes = (unsigned)(udaseg_frag_elems(d->co, d->ci, 3) * 2);

@@ -64,6 +64,11 @@ FUSE_BN_APPLY_F32_SMALL_ONLY = os.environ.get("UDASEG_FUSE_BN_APPLY_F32", "1") !
 # ... and through the next decoder block's up-sampling (block output -> conv1 of a block without a skip input): built and tested,
 # off by default -- the 67 MB pass it saves is paid back in the consumer's staging (964.4 with, 966.3 without, 952.9 all off)
 FUSE_BN_APPLY_F32_UP = os.environ.get("UDASEG_FUSE_BN_APPLY_F32_UP", "0") == "1"
+# >= 64-channel layers: the consumer's forward (wave-specialised kernel) can write the activation out while it stages it, so that
+# its weight gradient reads a plain tensor (UDASEG_FUSE_BN_APPLY_F32_WRITE=1).  Built, bit-exact (tests), and OFF: 950.8 against 958.0
+# images/s without it (same box, three alternations) -- the transform + stores in the loader waves cost more than the eleven
+# launch-floor-bound bn_apply passes they replace.
+FUSE_BN_APPLY_F32_WRITE = os.environ.get("UDASEG_FUSE_BN_APPLY_F32_WRITE", "0") == "1"
 
 
 # bf16 storage: weight gradients of the stride-1 3x3 layers with channel counts that are multiples of 64 on the halo-resident
@@ -126,10 +131,13 @@ class LazyAct:
     """act(batchnorm(y)) that is never written: ``y`` is the producer's raw convolution output, ``scale`` / ``shift`` the finalised
     per-channel coefficients (udaseg_bn_finalize).  Its single consumer applies act(fma(y, scale, shift)) rounded to bf16 while
     staging (forward convolution, weight gradient); the producer's BatchNorm backward re-evaluates the mask the same way."""
-    __slots__ = ("y", "scale", "shift", "act", "slope")
+    __slots__ = ("y", "scale", "shift", "act", "slope", "z", "z_valid")
 
-    def __init__(self, y, scale, shift, act, slope):
+    def __init__(self, y, scale, shift, act, slope, z=None):
         self.y, self.scale, self.shift, self.act, self.slope = y, scale, shift, act, slope
+        # fp32 write-through (round 4): a buffer the consumer's FORWARD fills with the activation while it stages y (z_valid then);
+        # the consumer's weight gradient reads it like any tensor
+        self.z, self.z_valid = z, False
 
     shape = property(lambda self: self.y.shape)
     dtype = property(lambda self: self.y.dtype)
@@ -138,6 +146,8 @@ class LazyAct:
     def materialize(self):
         """The activation as a tensor (tests / debugging only): one rounding of y * scale + shift like the kernels' fused
         multiply-add (evaluated in f64, rounded once to fp32), activation, round to the storage type."""
+        if self.z_valid:
+            return self.z
         t = torch.addcmul(self.shift.double(), self.y.double(), self.scale.double()).float()
         if self.act != ACT_NONE:
             t = torch.where(t > 0, t, self.slope * t)
@@ -574,8 +584,18 @@ class Plan:
                 return False
             if consumer.k != 3 or consumer.stride != 1 or consumer.pad != 1 or consumer.cin_p != c or c % 8 != 0:
                 return False
-            if FUSE_BN_APPLY_F32_SMALL_ONLY and (c > 32 or consumer.cout_p > 32):
-                return False
+            if c > 32 or consumer.cout_p > 32:
+                # wide layers: the consumer's forward writes the activation out as it stages it (its loader waves have the slack) and
+                # its weight gradient reads that buffer -- the transform inside the weight gradient's staging costs more than the
+                # pass saves ("2": that form everywhere, for A/B)
+                if up:
+                    return False
+                d2 = K.conv_desc(n, ho, wo, c, consumer.cout_p, 3, 1, 1)
+                if self.wfrag(consumer, d2) is None:
+                    return False
+                if FUSE_BN_APPLY_F32_WRITE and K.conv_bnin_writes(d2):
+                    return "write"
+                return (not FUSE_BN_APPLY_F32_SMALL_ONLY) and K.conv_bnin_ok(d2)
             if up and not FUSE_BN_APPLY_F32_UP:
                 return False
             # up: the consumer is the next decoder block's conv1 behind a nearest x2 up-sampling, no skip input
@@ -616,7 +636,8 @@ class Plan:
             if lazy_in:
                 assert wf is not None, "a LazyAct input needs the bf16-first kernels (decided by the producer)"
                 K.conv2d_fwd_frag(d, x.y, None, wf, bias, y, stats=sums[0], in_scale=x.scale, in_shift=x.shift, in_act=x.act,
-                                  in_slope=x.slope, st=self.st)
+                                  in_slope=x.slope, st=self.st, z_out=x.z)
+                x.z_valid = x.z is not None
             elif wf is not None and up and isinstance(x.a, LazyAct):       # the up-sampled source is an unwritten activation (fp32)
                 assert x.skip is None
                 K.conv2d_fwd_frag(d, x.a.y, None, wf, bias, y, stats=sums[0], in_scale=x.a.scale, in_shift=x.a.shift, in_act=x.a.act,
@@ -628,13 +649,14 @@ class Plan:
             else:
                 K.conv2d_fwd_bnstats(d, x, self.w(conv), bias, y, sums[0], self.st)
             c = ceil4(bn.c)
-            if y.shape[-1] == c and self._lazy_ok(c, n, d.ho, d.wo, lazy_for, act, residual, lazy_up):
+            lazy = y.shape[-1] == c and self._lazy_ok(c, n, d.ho, d.wo, lazy_for, act, residual, lazy_up)
+            if lazy:
                 so, o = sums
                 mean, rstd = self.saved_stats[o:o + c], self.saved_stats[o + c:o + 2 * c]
                 scale, shift = self.coefs[o:o + c], self.coefs[o + c:o + 2 * c]
                 K.bn_finalize(so, self.pvec(bn, "weight"), self.pvec(bn, "bias"), n * d.ho * d.wo, bn.eps, bn.momentum,
                               bn.running_mean, bn.running_var, mean, rstd, scale, shift, self.st)
-                z, ms = LazyAct(y, scale, shift, act, slope), (mean, rstd)
+                z, ms = LazyAct(y, scale, shift, act, slope, torch.empty_like(y) if lazy == "write" else None), (mean, rstd)
             else:
                 z, ms = self.bn(bn, y, act, slope, residual, sums)
         else:
@@ -732,6 +754,8 @@ class Plan:
             else:
                 K.conv2d_dgrad_split(d, dy, self.packed_wt(conv), d_up, d_skip, self.st)
             return
+        if isinstance(x, LazyAct) and x.z_valid:
+            x = x.z                                            # written out by this convolution's own forward
         if isinstance(x, LazyAct):
             K.conv2d_wgrad_bnin(d, x.y, x.scale, x.shift, x.act, x.slope, dy, self.gw(conv), True, wst)
         elif self._wgrad_halo and K.conv2d_wgrad_halo_ok(d, f32=not self.bf16):

@@ -212,6 +212,11 @@ def conv_bnin_ok(d, up=False):
     return bool(ops.udaseg_conv2d_fwd_f32x3_bnin_ok(d, int(up))) and bool(ops.udaseg_conv2d_wgrad_bnin_ok(d, int(up)))
 
 
+def conv_bnin_writes(d):
+    """fp32: the forward of this convolution can write the transformed activation out while it stages it (wave-specialised kernel)"""
+    return bool(ops.udaseg_conv2d_fwd_f32x3_bnin_writes(d)) and bool(ops.udaseg_conv2d_fwd_f32x3_bnin_ok(d, 0))
+
+
 def conv2d_wgrad_bnin(d, y_prev, in_scale, in_shift, in_act, in_slope, dy, dw, accumulate=False, st=None, up=False):
     """Weight gradient whose gathered operand is act(fma(y_prev, in_scale, in_shift)) (never written), bf16 or fp32."""
     if y_prev.dtype == torch.float32:
@@ -254,14 +259,15 @@ def conv_frag_preferred(d, dgrad=False, up_ca=0, f32=False):
 
 
 def conv2d_fwd_frag(d, x, skip, wfrag, bias, y, act=ACT_NONE, slope=0.0, stats=None, in_scale=None, in_shift=None, in_act=ACT_NONE,
-                    in_slope=0.0, up=False, st=None):
+                    in_slope=0.0, up=False, st=None, z_out=None):
     """Halo-resident forward convolution on the bf16 matrix pipe: bf16 tensors (csrc/conv_halo_bf16.hip) or fp32 tensors with
     the three-term split (csrc/conv_halo_f32x3.hip).  up: x is the half-resolution tensor of a fused decoder input."""
     if x.dtype == torch.float32 and in_scale is not None:
         assert y.dtype == torch.float32 and skip is None
-        check(ops.udaseg_conv2d_fwd_f32x3_bnin(d, x, int(up), in_scale, in_shift, in_act, in_slope, wfrag, bias, y, act, slope, stats,
-                                               st), "conv2d_fwd_f32x3_bnin")
+        check(ops.udaseg_conv2d_fwd_f32x3_bnin(d, x, int(up), in_scale, in_shift, in_act, in_slope, z_out, wfrag, bias, y, act, slope,
+                                               stats, st), "conv2d_fwd_f32x3_bnin")
         return
+    assert z_out is None
     if x.dtype == torch.float32:
         assert y.dtype == torch.float32
         check(ops.udaseg_conv2d_fwd_f32x3(d, x, skip, x.shape[-1] if up else 0, wfrag,
