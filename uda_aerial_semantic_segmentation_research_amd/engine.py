@@ -509,11 +509,11 @@ class Plan:
 
     def gvec(self, mod, name):
         o, n, shp = self.idx[(id(mod), name)]
-        return self.garena.as_strided((n,), (1,), o)
+        return self.garena.as_strided((n,), (1,), self.garena.storage_offset() + o)
 
     def gw(self, conv):
         o, n, shp = self.idx[(id(conv), "weight")]
-        return self.garena.as_strided(shp, (shp[1] * shp[2] * shp[3], shp[2] * shp[3], shp[3], 1), o)
+        return self.garena.as_strided(shp, (shp[1] * shp[2] * shp[3], shp[2] * shp[3], shp[3], 1), self.garena.storage_offset() + o)
 
     def offset_of(self, mod, name="weight"):
         return self.idx[(id(mod), name)][0]
