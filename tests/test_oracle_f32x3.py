@@ -42,3 +42,27 @@ def test_six_products_miss_the_product_by_at_most_one_fp32_ulp():
     e_split = np.abs(six_products(x, w).sum(1) - ref)
     e_fp32 = np.abs(np.cumsum((x * w).astype(np.float32), axis=1, dtype=np.float32)[:, -1].astype(np.float64) - ref)
     assert e_split.max() <= 0.05 * e_fp32.max() + 1e-9
+
+
+def test_sign_pattern_of_the_k_loop():
+    """oracle/f32x3_ref.py::negated_groups restates csrc/halo_common.h::f3_negated_groups: the (chunk, dx) groups [q1, q3) of a 3x3
+    layer's K loop that run on negated weights and a negated accumulator (+ - - +).  The middle block is never empty, never the
+    whole loop, and centred -- what makes the truncation bias of the two halves cancel."""
+    from oracle.f32x3_ref import negated_groups
+    for nk16 in range(1, 65):
+        g = negated_groups(nk16)
+        ng = 3 * nk16
+        assert 0 < g.start < g.stop < ng
+        assert g.start == ng - g.stop                       # as many positive groups in front as behind
+        assert abs(len(g) - ng / 2) <= 1.0                  # about half of the loop
+    assert list(negated_groups(1)) == [1] and list(negated_groups(2)) == [2, 3] and list(negated_groups(4)) == [3, 4, 5, 6, 7, 8]
+    # and in exact arithmetic the pattern changes nothing: sum of +g over the outer groups minus (-g) over the middle ones
+    rng = np.random.default_rng(0)
+    terms = rng.standard_normal(3 * 8)
+    mid = negated_groups(8)
+    acc = 0.0
+    for G, t in enumerate(terms):
+        if G == mid.start or G == mid.stop:
+            acc = -acc
+        acc += -t if G in mid else t
+    assert abs(acc - terms.sum()) < 1e-12
