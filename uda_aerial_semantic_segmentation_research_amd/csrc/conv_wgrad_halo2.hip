@@ -479,21 +479,24 @@ int launch_wgrad_h2(const udaseg_conv_desc* d, const void* x, const void* x2, in
   }
   // blocks per launch: few and long-lived (one set of atomics per wave; the kernel runs beside the main stream's chain).
   // UDASEG_WGRAD_F3_BLOCKS / UDASEG_WGRAD_HALO_BLOCKS: tuning aids
-  static int tf3 = -1, tbf = -1, tdeep = -1;
+  static int tf3 = -1, tbf = -1, tdeep = -1, tdeep3 = -1;
   if (tf3 < 0) {
     tf3 = h2_env("UDASEG_WGRAD_F3_BLOCKS", 120);
     tbf = h2_env("UDASEG_WGRAD_HALO_BLOCKS", 96);
-    tdeep = h2_env("UDASEG_WGRAD_DEEP_BLOCKS", 256);
+    tdeep = h2_env("UDASEG_WGRAD_DEEP_BLOCKS", 256);       // 16-pixel-wide images, bf16
+    tdeep3 = h2_env("UDASEG_WGRAD_DEEP_BLOCKS", 128);      // ... fp32 split: 64 / 96 / 128 / 160 / 256 / 384 blocks -> 979.3 / 980.6 / 987.3 /
+                                                           // 985.5 / 983.5 images/s on one box, 942.1 (128) / 942.3 (192) / 937.1 / 936.9 on another
     if (tf3 < 1) tf3 = 120;
     if (tbf < 1) tbf = 96;
     if (tdeep < 1) tdeep = 256;
+    if (tdeep3 < 1) tdeep3 = 128;
   }
   static int db = -1;      // UDASEG_WGRAD_DB=0: the single-buffer 4-row form of the 64 x 64 fp32 configuration (A/B)
   if (db < 0) db = h2_env("UDASEG_WGRAD_DB", 1);
   if (f32) {
     if (cfg == 1 && db) return launch_h2_t<3, 2, 2, 2, 2, 4, true>(d, x, x2, up_ca, dy, dw, s, tf3, in);
     if (cfg == 1) return launch_h2_t<3, 2, 2, 4, 2, 4>(d, x, x2, up_ca, dy, dw, s, tf3, in);
-    if (cfg == 2) return launch_h2_t<3, 2, 2, 8, 1, 4>(d, x, x2, up_ca, dy, dw, s, tdeep, in);
+    if (cfg == 2) return launch_h2_t<3, 2, 2, 8, 1, 4>(d, x, x2, up_ca, dy, dw, s, tdeep3, in);
     if (cfg == 3) return launch_h2_t<3, 1, 2, 4, 2, 4>(d, x, x2, up_ca, dy, dw, s, tf3, in);
     return launch_h2_t<3, 1, 1, 4, 2, 4>(d, x, x2, up_ca, dy, dw, s, tf3, in);
   }
