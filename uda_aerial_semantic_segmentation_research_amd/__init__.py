@@ -13,3 +13,7 @@ import os as _os
 # serialise (measured: the side-stream overlap vanished as soon as a NCCL process group existed, -7 % step time; 8 queues
 # restore it).  Read by the HIP runtime at its first call, so it must be set before any GPU work.
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# Kernel arguments written straight to device memory instead of through a host-coherent staging buffer: shortens every launch on
+# the host side.  BASELINE cfg 3 (~370 launches per iteration) runs close to the host's launch rate on the slower hosts of the pool:
+# 7.89 -> 7.20 ms of host time per iteration there (tools/host_probe.py), cfg 2 unchanged (969.9 against 971.9 images/s).
+_os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
