@@ -523,11 +523,23 @@ class Plan:
         if not self.frag:
             return None
         ent = self.net._frag_off.get(id(conv))
-        ok = K.conv_frag_ok if FRAG_POLICY == "always" else K.conv_frag_preferred
-        if ent is None or (dgrad and ent[2] is None) or not ok(d, dgrad, up_ca, f32=not self.bf16):
+        if ent is None or (dgrad and ent[2] is None):
             return None
-        o, n = (ent[2], ent[3]) if dgrad else (ent[0], ent[1])
-        return self.net._frag_arena[o:o + n]
+        # the library's answer is a function of the geometry alone: asked once per (convolution, geometry, policy), the fragment
+        # view cached with it (two ctypes calls and a slice per convolution and direction otherwise: host time, and cfg 3 runs close
+        # to the host's launch rate)
+        cache = self.net.__dict__.setdefault("_wfrag_cache", {})
+        key = (id(conv), d.n, d.hi, d.wi, d.ci, d.co, bool(dgrad), up_ca, FRAG_POLICY, self.bf16)
+        hit = cache.get(key)
+        if hit is not None and hit[0] is self.net._frag_arena:
+            return hit[1]
+        ok = K.conv_frag_ok if FRAG_POLICY == "always" else K.conv_frag_preferred
+        view = None
+        if ok(d, dgrad, up_ca, f32=not self.bf16):
+            o, n = (ent[2], ent[3]) if dgrad else (ent[0], ent[1])
+            view = self.net._frag_arena[o:o + n]
+        cache[key] = (self.net._frag_arena, view)
+        return view
 
     # -- forward pieces
     def conv(self, conv, x, act=ACT_NONE, slope=0.0, out_dtype=None):
@@ -574,6 +586,19 @@ class Plan:
         return torch.empty_like(t.y if isinstance(t, LazyAct) else t)
 
     def _lazy_ok(self, c, n, ho, wo, consumer, act, residual, up=False):
+        """Cached per (consumer, geometry, switches): see _lazy_ok_uncached."""
+        if consumer is None:
+            return False
+        cache = self.net.__dict__.setdefault("_lazy_cache", {})
+        key = (id(consumer), c, n, ho, wo, act, residual is None, up, self.bf16, FUSE_BN_APPLY, FUSE_BN_APPLY_1X1_ONLY, FUSE_BN_REDUCE,
+               FUSE_BN_APPLY_F32, FUSE_BN_APPLY_F32_SMALL_ONLY, FUSE_BN_APPLY_F32_UP, FUSE_BN_APPLY_F32_WRITE, USE_F32_SPLIT, FRAG_POLICY,
+               self.frag)
+        v = cache.get(key)
+        if v is None:
+            v = cache[key] = self._lazy_ok_uncached(c, n, ho, wo, consumer, act, residual, up)
+        return v
+
+    def _lazy_ok_uncached(self, c, n, ho, wo, consumer, act, residual, up=False):
         """May BatchNorm + activation of this [n, ho, wo, c] output stay unwritten?  Only when its single consumer runs on the
         bf16-first kernels in BOTH directions (the forward applies the transform while staging; the data gradient's epilogue
         makes this layer's BatchNorm-backward sums, which then need no activation either)."""
