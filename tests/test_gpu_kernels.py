@@ -740,3 +740,28 @@ def test_dgrad_with_bn_backward_reductions(K, n, h, w, c1, c2):
     # ... and operands that do not fit the descriptor never reach it (the binding's operand table, _operands.py)
     with pytest.raises(ValueError, match="too short"):
         K.conv2d_dgrad_bnreduce(dk, dy, wt, dx, prev_y, mean, rstd, gamma, beta, 1, 0.0, bs)
+
+
+def test_host_side_helpers(K):
+    """udaseg_memset_async / udaseg_add_i64 / udaseg_stream_wait: what torch.zeros, `num_batches_tracked += 1` and
+    `stream.wait_event(Event().record(...))` do for the reference's eager step."""
+    z = K.zeros((3, 1000, 7), torch.float64, torch.device("cuda", 0))
+    assert z.dtype == torch.float64 and z.shape == (3, 1000, 7) and not z.any()
+    base = torch.full((257,), float("nan"), device="cuda")
+    zl = K.zeros_like(base)
+    assert zl.shape == base.shape and not zl.any() and torch.isnan(base).all()
+    cnt = torch.arange(37, device="cuda", dtype=torch.int64) * 1000003
+    K.check(K.ops.udaseg_add_i64(cnt, cnt.numel(), 5, None), "add_i64")
+    assert torch.equal(cnt.cpu(), torch.arange(37, dtype=torch.int64) * 1000003 + 5)
+    # ordering: a side stream waits for a long fill on the main stream before it reads the buffer
+    main, side = torch.cuda.current_stream(), torch.cuda.Stream()
+    big = torch.empty(64 << 20, device="cuda")
+    out = torch.empty(1, device="cuda")
+    for v in (1.0, 2.0, 3.0):
+        big.fill_(v)                                             # main stream
+        K.stream_wait(side.cuda_stream, main.cuda_stream)
+        with torch.cuda.stream(side):
+            out.copy_(big[-1:])
+        K.stream_wait(main.cuda_stream, side.cuda_stream)        # the next fill must not overtake the read
+        torch.cuda.synchronize()
+        assert out.item() == v
