@@ -473,6 +473,34 @@ int udaseg_conv2d_wgrad_halo_f32x3_ok(const udaseg_conv_desc* d, int up_ca);
 int udaseg_conv2d_wgrad_halo_f32x3(const udaseg_conv_desc* d, const float* x, const float* skip, int up_ca, const float* dy,
                                    float* dw, void* stream);
 
+/* ---- the decoder's up-sampled input convolved as what it is (round 5, csrc/conv_up_f32x3.hip).  smp's DecoderBlock runs
+ *      conv3x3(cat([nearest_x2(a), skip])) (reference: model created src/test_system.py:90-95, called src/models/train.py:341,
+ *      differentiated :343; trace fixture tests/golden/unet_r50_trace.json: aten::upsample_nearest2d + aten::cat in front of every
+ *      decoder conv1).  On the up-sampled channels the nine taps of an output pixel of parity phase (oy & 1, ox & 1) read FOUR
+ *      distinct pixels of `a`: a 2 x 2 convolution of `a` per phase with weights pre-summed over the taps that coincide --
+ *      4/9 of the multiplications, forward and data gradient, and the data gradient comes out at a's own resolution (no 2 x 2
+ *      sum-pool pass).  fp32 tensors, the three-term split of udaseg_conv2d_fwd_f32x3; the pre-sums are fp32 additions in the
+ *      packer.  The skip half of the concatenation is a plain 3x3 convolution of `skip` (udaseg_conv2d_fwd_f32x3 /
+ *      udaseg_conv2d_dgrad_f32x3 on weight slices packed by modes 0 / 1 below), run FIRST; the up half accumulates on top.
+ *      d: the whole convolution at the OUTPUT resolution (hi x wi = 2h x 2w, ci = up_ca + skip channels, co).
+ *      udaseg_pack_up_batched_f32x3: table rows of 8 int32 {mode, src element offset, dst element offset (plane 0), N, K, ldk, 0, 0}
+ *        mode 0: 3x3 forward packing of channels [offset, offset + K) of OHWI rows of ldk channels (w32), N = co;
+ *        mode 1: 3x3 data-gradient packing from wt32 [N][9][K] (ldk = K; rows [up_ca, ci) of the dgrad packing);
+ *        mode 2: phase packing for udaseg_conv2d_fwd_up_f32x3 from w32 OHWI [N = co][3][3][ldk], channels [0, K = up_ca);
+ *        mode 3: phase packing for udaseg_conv2d_dgrad_up_f32x3 from wt32 [ci][9][K = co], rows [0, N = up_ca);
+ *        plane stride udaseg_frag_elems(N, K, 3) (modes 0, 1) / udaseg_frag_elems(N, K, 4) (modes 2, 3) bf16 elements. ---- */
+int udaseg_conv_up_f32x3_ok(const udaseg_conv_desc* d, int up_ca);
+int udaseg_pack_up_batched_f32x3(const float* w32, const float* wt32, void* packed, const int* table, int entries, void* stream);
+/* y[n][hi][wi][co] (+)= conv3x3(nearest_x2(a)) over a's up_ca channels (accumulate != 0: on top of the skip half's result);
+ * stats != NULL: BatchNorm statistics of y AFTER the accumulation ([R][2][co] f64, accumulated) */
+int udaseg_conv2d_fwd_up_f32x3(const udaseg_conv_desc* d, const float* a, int up_ca, const void* wfrag_up, float* y, int accumulate,
+                               double* stats, void* stream);
+/* da[n][hi/2][wi/2][up_ca] (+)= gradient of `a` through conv3x3(nearest_x2(a)) given dy[n][hi][wi][co] (co a multiple of 8) */
+int udaseg_conv2d_dgrad_up_f32x3(const udaseg_conv_desc* d, const float* dy, int up_ca, const void* wfrag_up_t, float* da,
+                                 int accumulate, void* stream);
+/* tests / tuning: one tile configuration (1..8, csrc/conv_up_f32x3.hip up_choice) for every launch; 0 = the heuristic again */
+int udaseg_up_f32x3_force_config(int cfg);
+
 /* ---- diagnosis: while a device buffer of 6 * blocks u64 is registered, every implicit-GEMM launch of at most `blocks` blocks
  *      writes per block {entry, first tile load, end of K loop, exit} (100 MHz wall-clock ticks), HW_ID and XCC_ID into it
  *      (tools/igemm_timeline.py).  NULL switches it off.  Not for timed runs. ---- */

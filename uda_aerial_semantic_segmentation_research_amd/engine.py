@@ -40,6 +40,11 @@ FRAG_POLICY = "always" if os.environ.get("UDASEG_FRAG") == "2" else "auto"
 # terms (csrc/conv_halo_f32x3.hip: six products per operand pair, fp32 accumulation, one unit in the last place of a PRODUCT
 # left out).  UDASEG_F32_SPLIT=0 keeps them on the fp32-MFMA kernels (A/B; tests flip the module attribute to cross-check).
 USE_F32_SPLIT = os.environ.get("UDASEG_F32_SPLIT", "1") != "0"
+# fp32 storage (round 5): the up-sampled half of a decoder conv1's fused input runs as four 2x2 phase convolutions of the
+# half-resolution tensor with pre-summed weights (csrc/conv_up_f32x3.hip: 4 taps instead of 9, forward and data gradient; the skip
+# half is a plain 3x3 convolution of its own).  UDASEG_UP_PHASE=0: the nine-tap gather over the virtual concatenation (A/B; tests
+# flip the module attribute to cross-check)
+USE_UP_PHASE = os.environ.get("UDASEG_UP_PHASE", "1") != "0"
 
 
 # bf16 storage: BatchNorm + activation of a layer whose ONLY consumer is a convolution on the bf16-first kernels is not written at
@@ -127,6 +132,15 @@ class UpCat:
         self.a, self.skip = a, skip
 
 
+class UpGrad:
+    """Destination of a fused decoder input's data gradient in the phase form: ``da`` the gradient of the HALF-resolution source
+    itself (accumulated when ``acc``), ``d_skip`` the skip source's (or None)."""
+    __slots__ = ("da", "acc", "d_skip")
+
+    def __init__(self, da, acc, d_skip):
+        self.da, self.acc, self.d_skip = da, acc, d_skip
+
+
 class LazyAct:
     """act(batchnorm(y)) that is never written: ``y`` is the producer's raw convolution output, ``scale`` / ``shift`` the finalised
     per-channel coefficients (udaseg_bn_finalize).  Its single consumer applies act(fma(y, scale, shift)) rounded to bf16 while
@@ -163,6 +177,7 @@ class ConvP(nn.Module):
         self.weight = nn.Parameter(torch.empty(cout, cin, k, k))
         self.bias = nn.Parameter(torch.empty(cout)) if bias else None
         self.needs_dgrad = True
+        self.up_ca = 0          # > 0: a decoder conv1 whose first up_ca input channels are a nearest x2 up-sampled tensor
         self.align = 4          # physical channel granule: 4 (fp32 storage) or 8 (bf16 storage), set by the owning network
 
     @property
@@ -332,6 +347,28 @@ class ArenaModule(nn.Module):
                         ent[2], ent[3] = foff, 4 * fe
                         foff += 4 * fe
                     self._frag_off[id(m)] = tuple(ent)
+            # fp32: phase packings of the decoder conv1 layers (csrc/conv_up_f32x3.hip; table rows of 8: mode, src, dst, N, K, ldk)
+            self._up_off, urows_f, urows_b = {}, [], []
+            if f32 and USE_UP_PHASE:
+                for m in self.modules():
+                    cs = m.cin_p - m.up_ca if isinstance(m, ConvP) else 0
+                    if not (isinstance(m, ConvP) and m.up_ca > 0 and m.k == 3 and m.stride == 1 and m.pad == 1 and m.needs_dgrad
+                            and m.bias is None and m.up_ca % 16 == 0 and cs % 8 == 0 and m.cout_p % 8 == 0):
+                        continue
+                    wo, wto, ent = self._idx[(id(m), "weight")][0], self._wt_off[id(m)], {}
+                    for key, mode, src, nn_, kk, ldk in (("up_fwd", 2, wo, m.cout_p, m.up_ca, m.cin_p),
+                                                        ("up_bwd", 3, wto, m.up_ca, m.cout_p, m.cout_p),
+                                                        ("skip_fwd", 0, wo + m.up_ca, m.cout_p, cs, m.cin_p),
+                                                        ("skip_bwd", 1, wto + m.up_ca * 9 * m.cout_p, cs, m.cout_p, m.cout_p)):
+                        if key.startswith("skip") and cs == 0:
+                            continue
+                        ne = 3 * K.frag_elems(nn_, kk, 4 if key.startswith("up") else 3)
+                        (urows_f if key.endswith("fwd") else urows_b).append([mode, src, foff, nn_, kk, ldk, 0, 0])
+                        ent[key] = (foff, ne)
+                        foff += ne
+                    self._up_off[id(m)] = ent
+            self._up_fwd_table = torch.tensor(urows_f, dtype=torch.int32, device=device) if urows_f else None
+            self._up_bwd_table = torch.tensor(urows_b, dtype=torch.int32, device=device) if urows_b else None
             if frows:
                 self._frag_arena = torch.empty(foff, device=device, dtype=torch.bfloat16)
                 self._frag_fwd_table = torch.tensor(frows, dtype=torch.int32, device=device)
@@ -454,6 +491,8 @@ class Plan:
         self.frag = training and getattr(net, "_frag_arena", None) is not None      # bf16 kernels / fp32 three-term split
         if self.frag:
             K.pack_frag_batched(self.w16 if self.bf16 else net._arena, None, net._frag_arena, net._frag_fwd_table, self.st)
+            if getattr(net, "_up_fwd_table", None) is not None:
+                K.pack_up_batched(net._arena, None, net._frag_arena, net._up_fwd_table, self.st)
         nbn = net._nbn
         self.dev = dev
         if training:
@@ -540,6 +579,25 @@ class Plan:
             view = self.net._frag_arena[o:o + n]
         cache[key] = (self.net._frag_arena, view)
         return view
+
+    def up_frag(self, conv, d, up_ca):
+        """The phase packings of a decoder conv1 ({"up_fwd", "up_bwd"[, "skip_fwd", "skip_bwd"]} -> views of the fragment arena) when
+        this launch can run its up-sampled half as four 2x2 phase convolutions (csrc/conv_up_f32x3.hip), else None."""
+        if not (self.frag and USE_UP_PHASE and not self.bf16):
+            return None
+        ent = getattr(self.net, "_up_off", {}).get(id(conv))
+        if ent is None or up_ca != conv.up_ca:
+            return None
+        cache = self.net.__dict__.setdefault("_upfrag_cache", {})
+        key = (id(conv), d.n, d.hi, d.wi, d.ci, d.co)
+        hit = cache.get(key)
+        if hit is not None and hit[0] is self.net._frag_arena:
+            return hit[1]
+        views = None
+        if K.conv_up_ok(d, up_ca):
+            views = {k: self.net._frag_arena[o:o + n] for k, (o, n) in ent.items()}
+        cache[key] = (self.net._frag_arena, views)
+        return views
 
     # -- forward pieces
     def conv(self, conv, x, act=ACT_NONE, slope=0.0, out_dtype=None):
@@ -658,7 +716,16 @@ class Plan:
             y = torch.empty((n, d.ho, d.wo, conv.cout_p), device=dev, dtype=self.adt)
             sums = self._next_stats(ceil4(bn.c))
             wf = self.wfrag(conv, d, up_ca=x.a.shape[3] if up else 0)
-            if lazy_in:
+            upw = self.up_frag(conv, d, x.a.shape[3]) if (up and not isinstance(x.a, LazyAct)) else None
+            if upw is not None:
+                # phase form: the skip half as a plain 3x3 convolution of its own, the up-sampled half (4 taps per phase) on top,
+                # BatchNorm statistics of the sum in the second launch's epilogue
+                assert bias is None
+                if x.skip is not None:
+                    ds = K.conv_desc(n, h, w, x.skip.shape[3], conv.cout_p, 3, 1, 1)
+                    K.conv2d_fwd_frag(ds, x.skip, None, upw["skip_fwd"], None, y, st=self.st)
+                K.conv2d_fwd_up(d, x.a, upw["up_fwd"], y, accumulate=x.skip is not None, stats=sums[0], st=self.st)
+            elif lazy_in:
                 assert wf is not None, "a LazyAct input needs the bf16-first kernels (decided by the producer)"
                 K.conv2d_fwd_frag(d, x.y, None, wf, bias, y, stats=sums[0], in_scale=x.scale, in_shift=x.shift, in_act=x.act,
                                   in_slope=x.slope, st=self.st, z_out=x.z)
@@ -729,6 +796,8 @@ class Plan:
             K.pack_dgrad_batched(net._arena, net._wt_arena, net._wt_table, self.st)
         if self.frag and net._frag_bwd_table is not None:
             K.pack_frag_batched(None, net._wt_arena, net._frag_arena, net._frag_bwd_table, self.st)
+        if self.frag and getattr(net, "_up_bwd_table", None) is not None:
+            K.pack_up_batched(None, net._wt_arena, net._frag_arena, net._up_bwd_table, self.st)
         if self.side_stream is not None:
             self.side_stream.wait_stream(self.main_stream)      # zeroed gradient arena is visible to the side stream
 
@@ -769,8 +838,15 @@ class Plan:
                 K.conv2d_wgrad_part(d, x.a, 0, True, dy, gw, True, wst)
                 if x.skip is not None:
                     K.conv2d_wgrad_part(d, x.skip, x.a.shape[-1], False, dy, gw, True, wst)
-            d_up, d_skip = dx
             assert not dx_acc and conv.bias is None
+            if isinstance(dx, UpGrad):          # phase form: the gradient of the half-resolution source at its own resolution
+                upw = self.up_frag(conv, d, x.a.shape[-1])
+                K.conv2d_dgrad_up(d, dy, x.a.shape[-1], upw["up_bwd"], dx.da, accumulate=dx.acc, st=self.st)
+                if x.skip is not None:
+                    ds = K.conv_desc(d.n, d.hi, d.wi, x.skip.shape[-1], d.co, 3, 1, 1)
+                    K.conv2d_dgrad_frag(ds, dy, upw["skip_bwd"], dx.d_skip, st=self.st)
+                return
+            d_up, d_skip = dx
             wfd = self.wfrag(conv, d, dgrad=True)
             if wfd is not None and (x.skip is None or x.a.shape[-1] % 32 == 0):
                 K.conv2d_dgrad_frag(d, dy, wfd, d_up, d_skip if x.skip is not None else None, st=self.st)

@@ -245,6 +245,26 @@ def pack_frag_batched(w, wt, packed, table, st=None):
                                                      st), "pack_frag_batched_bf16")
 
 
+def pack_up_batched(w, wt, packed, table, st=None):
+    """Fragment packings of the decoder conv1 layers whose up-sampled half runs as four 2x2 phase convolutions
+    (csrc/conv_up_f32x3.hip): table rows of 8 int32 {mode, src offset, dst offset, N, K, ldk, 0, 0}."""
+    check(ops.udaseg_pack_up_batched_f32x3(w, wt, packed, table, table.shape[0], st), "pack_up_batched_f32x3")
+
+
+def conv_up_ok(d, up_ca):
+    return bool(ops.udaseg_conv_up_f32x3_ok(d, up_ca))
+
+
+def conv2d_fwd_up(d, a, wfrag_up, y, accumulate=False, stats=None, st=None):
+    """y (+)= conv3x3(nearest_x2(a)) as four 2x2 phase convolutions of a (fp32, three-term split); d: the whole decoder conv1."""
+    check(ops.udaseg_conv2d_fwd_up_f32x3(d, a, a.shape[-1], wfrag_up, y, int(accumulate), stats, st), "conv2d_fwd_up_f32x3")
+
+
+def conv2d_dgrad_up(d, dy, up_ca, wfrag_up_t, da, accumulate=False, st=None):
+    """da (+)= gradient of a through conv3x3(nearest_x2(a)), at a's resolution."""
+    check(ops.udaseg_conv2d_dgrad_up_f32x3(d, dy, up_ca, wfrag_up_t, da, int(accumulate), st), "conv2d_dgrad_up_f32x3")
+
+
 def conv_frag_ok(d, dgrad=False, up_ca=0, f32=False):
     if f32:
         return bool(ops.udaseg_conv_f32x3_ok(d, int(dgrad), up_ca))

@@ -20,7 +20,7 @@ import torch.nn as nn
 
 from . import kernels as K
 from ._lib import ACT_LEAKY, ACT_NONE, require_gpu
-from .engine import ArenaModule, BNP, ConvP, GradSlots, Plan, UpCat, ceil4, is_padded_input
+from .engine import LazyAct, ArenaModule, BNP, ConvP, GradSlots, Plan, UpCat, UpGrad, ceil4, is_padded_input
 
 ENCODERS = {
     "resnet18": ("basic", (2, 2, 2, 2), (64, 64, 128, 256, 512)),
@@ -142,6 +142,8 @@ class DecoderBlock(nn.Module):
         self.in_ch, self.skip_ch, self.out_ch, self.upsample = in_ch, skip_ch, out_ch, upsample
         self.conv1 = nn.Sequential(ConvP(in_ch + skip_ch, out_ch, 3, 1, 1), BNP(out_ch))
         self.conv2 = nn.Sequential(ConvP(out_ch, out_ch, 3, 1, 1), BNP(out_ch))
+        if upsample == "nearest":
+            self.conv1[0].up_ca = in_ch       # the first in_ch input channels are nearest_x2(x): engine.Plan.up_frag
 
     def fwd(self, P, x, skip, lazy_for=None, lazy_up=False):
         """lazy_for: the convolution that is the ONLY consumer of this block's output (the segmentation head behind the last
@@ -173,6 +175,14 @@ class DecoderBlock(nn.Module):
             ds, ds_acc = G.slot(skip)
         else:
             ds, ds_acc = None, False
+        if isinstance(cat, UpCat) and not isinstance(x, LazyAct) and P.up_frag(self.conv1[0], r1[2], x.shape[-1]) is not None:
+            # phase form (csrc/conv_up_f32x3.hip): conv1's data gradient lands in dx at x's own resolution -- no gradient of the
+            # up-sampled tensor, no 2x2 sum-pool pass
+            d_skip = (torch.empty_like(skip) if ds_acc else ds) if skip is not None else None
+            P.conv_bn_act_bwd(r1, d_a1, dx=UpGrad(dx, dx_acc, d_skip))
+            if ds_acc:
+                ds.add_(d_skip)
+            return
         if isinstance(cat, UpCat):
             n, h, w, ca = x.shape
             d_up = torch.empty((n, 2 * h, 2 * w, ca), device=x.device, dtype=x.dtype)   # gradient of the up-sampled x
