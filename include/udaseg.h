@@ -500,6 +500,18 @@ int udaseg_conv2d_dgrad_up_f32x3(const udaseg_conv_desc* d, const float* dy, int
                                  int accumulate, void* stream);
 /* tests / tuning: one tile configuration (1..8, csrc/conv_up_f32x3.hip up_choice) for every launch; 0 = the heuristic again */
 int udaseg_up_f32x3_force_config(int cfg);
+/* The weight gradient in the same form (csrc/conv_wgrad_halo2.hip, conv_wgrad_up_kernel): the 16 phase-tap correlations
+ * T_{py,px}[u][v] = sum_{q,r} dy[2q+py, 2r+px] (x) a[q+py-1+u, r+px-1+v] at a's resolution, each added into the 1, 2 or 4 taps of
+ * dW[co][9][ci] it stands for -- 16 tap evaluations per pixel of `a` instead of 36.  dW rows are d->ci channels long, the launch
+ * fills channels [0, up_ca) (accumulated onto, like every weight gradient here).  up_ca a multiple of 64, co of 32, a at least 16
+ * pixels wide.  The skip half: udaseg_conv2d_wgrad_halo_slice_f32x3 = udaseg_conv2d_wgrad_halo_f32x3 on a channel slice
+ * [c_off, c_off + d->ci) of rows of ldw channels (d: the slice as a convolution of its own).  loss.backward(), src/models/train.py:343. */
+int udaseg_conv2d_wgrad_up_f32x3_ok(const udaseg_conv_desc* d, int up_ca);
+int udaseg_conv2d_wgrad_up_f32x3(const udaseg_conv_desc* d, const float* a, int up_ca, const float* dy, float* dw, void* stream);
+int udaseg_conv2d_wgrad_halo_slice_f32x3(const udaseg_conv_desc* d, const float* x, const float* dy, float* dw, int ldw, int c_off,
+                                         void* stream);
+/* tests / tuning: blocks per launch of the phase-form weight gradient (0 = the default, 128) */
+int udaseg_wgrad_up_set_blocks(int blocks);
 
 /* ---- diagnosis: while a device buffer of 6 * blocks u64 is registered, every implicit-GEMM launch of at most `blocks` blocks
  *      writes per block {entry, first tile load, end of K loop, exit} (100 MHz wall-clock ticks), HW_ID and XCC_ID into it

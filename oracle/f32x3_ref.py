@@ -116,6 +116,6 @@ def up_dgrad_phases(dy, w, dtype=np.float64):
 
 def up_negated_groups(ng):
     """Groups [q1, q3) of the phase kernels' K loop that run on negated weights (csrc/conv_up_f32x3.hip::up_negated_groups);
-    ng = 4 * chunks (forward) / 8 * chunks (data gradient)."""
+    ng = 4 * chunks: four (px, ex) groups per chunk (forward), four phases = virtual chunks per chunk (data gradient)."""
     q1 = (ng + 2) // 4
     return range(q1, ng - q1)

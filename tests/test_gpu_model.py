@@ -204,12 +204,20 @@ def test_decoder_block_plan(pkg, cin, cskip, cout):
         check(g, gr[k[len("block."):]].grad, f"decoder grad {k}", 1e-3)
 
 
-@pytest.mark.parametrize("name,dtype", [("resnet18", torch.float32), ("resnet50", torch.float32), ("resnet18", torch.bfloat16)])
-def test_fused_decoder_input_equals_materialised(pkg, name, dtype):
-    """The decoder's cat([nearest_x2(x), skip]) gathered inside conv1 (default) against the same network with the
-    concatenation written by the stand-alone kernel: logits bit for bit (train and eval mode), gradients to atomics noise."""
+@pytest.mark.parametrize("name,dtype,phase", [("resnet18", torch.float32, False), ("resnet50", torch.float32, False),
+                                              ("resnet18", torch.bfloat16, False), ("resnet18", torch.float32, True),
+                                              ("resnet50", torch.float32, True)])
+def test_fused_decoder_input_equals_materialised(pkg, name, dtype, phase, monkeypatch):
+    """The decoder's cat([nearest_x2(x), skip]) gathered inside conv1 against the same network with the concatenation written by
+    the stand-alone kernel.  phase=False (the nine-tap gather over the virtual concatenation): logits bit for bit (train and eval
+    mode), gradients to atomics noise.  phase=True (round 5, the default on fp32: the up-sampled half as four 2x2 phase convolutions
+    with pre-summed weights, csrc/conv_up_f32x3.hip): bit equality is NOT expected -- the pre-sums round once more and the sums run
+    in another order -- train-mode logits agree to 1e-5, the head's gradients to 1e-5, the whole gradient by direction (a ReLU
+    pre-activation within rounding distance of zero may change sign between two fp32 evaluations); eval mode does not use the
+    phase kernels and stays bit-equal."""
     from oracle.adversarial_ref import synthetic_batch
-    from uda_aerial_semantic_segmentation_research_amd import unet as U
+    from uda_aerial_semantic_segmentation_research_amd import engine as E, unet as U
+    monkeypatch.setattr(E, "USE_UP_PHASE", phase)
     from uda_aerial_semantic_segmentation_research_amd.losses import CrossEntropyLoss
     _, net = _pair(name, compute_dtype=dtype)
     x, y, _ = synthetic_batch(2, 64, 64, seed=4)
@@ -236,10 +244,20 @@ def test_fused_decoder_input_equals_materialised(pkg, name, dtype):
         U.FUSE_UPCAT = True
     assert out[False][3] == ["Tensor"] * 5
     assert out[True][3].count("UpCat") >= (4 if dtype == torch.bfloat16 else 5), out[True][3]
-    assert torch.equal(out[True][0], out[False][0]), "train-mode logits differ"
     assert torch.equal(out[True][2], out[False][2]), "eval-mode logits differ"
-    e = ((out[True][1] - out[False][1]).abs().max() / out[False][1].abs().max()).item()
-    assert e <= 1e-5, f"gradient arenas differ by {e:.3e}"
+    if not phase:
+        assert torch.equal(out[True][0], out[False][0]), "train-mode logits differ"
+        e = ((out[True][1] - out[False][1]).abs().max() / out[False][1].abs().max()).item()
+        assert e <= 1e-5, f"gradient arenas differ by {e:.3e}"
+        return
+    assert getattr(net, "_up_off", None), "the phase packings were not built"
+    el = ((out[True][0] - out[False][0]).abs().max() / out[False][0].abs().max()).item()
+    ga, gb = out[True][1].double(), out[False][1].double()
+    cos = (ga @ gb / (ga.norm() * gb.norm())).item()
+    o, nel, _ = net.entry_index()[(id(net.segmentation_head[0]), "weight")]
+    eh = ((ga[o:o + nel] - gb[o:o + nel]).norm() / gb[o:o + nel].norm()).item()
+    print(f"phase form vs materialised: logits {el:.3e} head gradient {eh:.3e} 1 - cos(all gradients) {1 - cos:.3e}")
+    assert el <= 1e-5 and eh <= 1e-5 and cos >= 0.9995
 
 
 def test_unet_bilinear_decoder_vs_oracle(pkg):

@@ -99,16 +99,16 @@ def test_phase_packings_match_the_oracle_bit_for_bit(K):
                 if G in neg:
                     want = -want
                 assert np.array_equal(tot[b, G, j], want), ("fwd", b, G, j)
-    # data gradient: plane[nb][G = 2 (4 chunk + phase) + e][jy][lane][8]; n = a channel, k = dy channel
+    # data gradient: plane[nb][G = 4 chunk + phase][j = 2 e + jy][lane][8]; n = a channel, k = dy channel
     nb, nk = (ca + 31) // 32, (co + 15) // 16
-    tot = P["up_bwd"].view(3, -1).float().cpu().double().sum(0).view(nb, 8 * nk, 2, 64, 8).numpy()
-    neg = up_negated_groups(8 * nk)
+    tot = P["up_bwd"].view(3, -1).float().cpu().double().sum(0).view(nb, 4 * nk, 4, 64, 8).numpy()
+    neg = up_negated_groups(4 * nk)
     for b in range(nb):
-        for G in range(8 * nk):
-            vc, e = G >> 1, G & 1
-            kk, py, px = vc >> 2, (vc >> 1) & 1, vc & 1
-            ex = e if px else 1 + e
-            for jy in range(2):
+        for G in range(4 * nk):
+            kk, py, px = G >> 2, (G >> 1) & 1, G & 1
+            for j in range(4):
+                e, jy = j >> 1, j & 1
+                ex = e if px else 1 + e
                 ey = (0 if py else 1) + jy
                 u, v = 2 - py - ey, 2 - px - ex
                 want = np.zeros((64, 8))
@@ -119,7 +119,7 @@ def test_phase_packings_match_the_oracle_bit_for_bit(K):
                         want[l, :hi - k0] = pw[py, px, k0:hi, n_, u, v]
                 if G in neg:
                     want = -want
-                assert np.array_equal(tot[b, G, jy], want), ("bwd", b, G, jy)
+                assert np.array_equal(tot[b, G, j], want), ("bwd", b, G, j)
 
 
 # (n, h, w of the OUTPUT, up-sampled channels, skip channels, produced channels)
@@ -202,3 +202,52 @@ def test_up_only_write_mode_leaves_nothing_unwritten(K):
     K.conv2d_fwd_up(K.conv_desc(n, h, w, ca, co, 3, 1, 1), nhwc(a), P["up_fwd"], y)
     ref = F.conv2d(F.interpolate(a.double(), scale_factor=2, mode="nearest"), wt.double(), padding=1)
     assert err(nchw(y), ref) <= 1e-5
+
+
+WG_CASES = [(2, 16, 64, 64, 64, 64), (2, 32, 32, 128, 64, 64), (1, 20, 72, 64, 32, 32), (8, 64, 64, 256, 128, 128),
+            (1, 8, 64, 512, 256, 256), (2, 24, 40, 64, 0, 64), (3, 34, 70, 64, 64, 96), (2, 34, 38, 64, 64, 64), (8, 128, 128, 128, 64, 64)]
+
+
+@pytest.mark.parametrize("case", WG_CASES, ids=[("n%d_%dx%d_ca%d_cs%d_co%d" % c) for c in WG_CASES])
+@pytest.mark.parametrize("blocks", [0, 16, 600], ids=["default_blocks", "16_blocks", "600_blocks"])
+def test_up_phase_wgrad_fp32_grade(K, case, blocks):
+    """dW of conv3x3(cat([nearest_x2(a), skip])): the up-sampled half as 16 phase-tap correlations at a's resolution
+    (conv_wgrad_up_kernel), the skip half as a channel slice of the halo-resident kernel -- against the float64 autograd of the
+    reference's op sequence, next to the nine-tap halo kernel over the same virtual input; accumulation onto an existing gradient;
+    any split of the tile sequence over blocks (atomics) gives the same sums."""
+    from uda_aerial_semantic_segmentation_research_amd import _lib
+    n, h, w, ca, cs, co = case
+    g = torch.Generator().manual_seed(sum(case))
+    a = torch.randn(n, ca, h // 2, w // 2, generator=g)
+    skip = torch.randn(n, cs, h, w, generator=g) if cs else None
+    dy = torch.randn(n, co, h, w, generator=g)
+    up = F.interpolate(a, scale_factor=2, mode="nearest")
+    xin = (torch.cat([up, skip], 1) if cs else up).double()
+    wt = torch.zeros(co, ca + cs, 3, 3, dtype=f64, requires_grad=True)
+    F.conv2d(xin, wt, padding=1).backward(dy.double())
+    ref = wt.grad.permute(0, 2, 3, 1).contiguous()              # OHWI
+    d = K.conv_desc(n, h, w, ca + cs, co, 3, 1, 1)
+    assert K.conv2d_wgrad_up_ok(d, ca)
+    base = torch.randn(co, 3, 3, ca + cs, generator=g)
+    dw = base.clone().cuda()
+    lib = _lib.load()
+    lib.udaseg_wgrad_up_set_blocks(blocks)
+    try:
+        K.conv2d_wgrad_up(d, nhwc(a), nhwc(dy), dw)
+    finally:
+        lib.udaseg_wgrad_up_set_blocks(0)
+    if cs:
+        K.conv2d_wgrad_halo_slice(K.conv_desc(n, h, w, cs, co, 3, 1, 1), nhwc(skip), nhwc(dy), dw, ca)
+    got = dw.cpu() - base
+    e2, em = err2(got, ref), err(got, ref)
+    e9 = 5e-7
+    if cs and K.conv2d_wgrad_halo_ok(d, ca, f32=True):
+        dw9 = torch.zeros(co, 3, 3, ca + cs, device="cuda")
+        K.conv2d_wgrad_halo(d, nhwc(a), nhwc(skip), nhwc(dy), dw9, up=True)
+        e9 = err2(dw9.cpu(), ref)
+    print(f"weight gradient: l2 phase {e2:.3e} nine-tap {e9:.3e} | worst element {em:.3e}")
+    assert e2 <= 1.6 * e9 + 2.0 ** -23 and em <= 1e-5
+    # the up-sampled half alone, tap by tap: every one of the nine taps got its four phase taps
+    for ky in range(3):
+        for kx in range(3):
+            assert err2(got[:, ky, kx, :ca], ref[:, ky, kx, :ca]) <= 2e-6, (ky, kx)

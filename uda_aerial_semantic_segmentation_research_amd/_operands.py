@@ -65,7 +65,8 @@ OPERANDS = {
     "udaseg_conv_frag_ok": [D, I("dgrad"), I("up_ca")], "udaseg_conv_frag_preferred": [D, I("dgrad"), I("up_ca")],
     "udaseg_conv_f32x3_ok": [D, I("dgrad"), I("up_ca")], "udaseg_conv_f32x3_preferred": [D, I("dgrad"), I("up_ca")],
     "udaseg_f32x3_force_config": [I("cfg")], "udaseg_up_f32x3_force_config": [I("cfg")],
-    "udaseg_conv_up_f32x3_ok": [D, I("up_ca")],
+    "udaseg_conv_up_f32x3_ok": [D, I("up_ca")], "udaseg_conv2d_wgrad_up_f32x3_ok": [D, I("up_ca")],
+    "udaseg_wgrad_up_set_blocks": [I("blocks")],
     "udaseg_prof_enable": [I("on")], "udaseg_prof_kernel_name": [I("kid")],
     "udaseg_prof_read": [I("family"), H("total_ms"), H("total_flops"), H("launches")],
     "udaseg_prof_kernel_read": [I("kid"), H("total_ms"), H("total_flops"), H("launches")],
@@ -120,6 +121,9 @@ OPERANDS = {
                                    T("y", f32, "Y"), I("accumulate"), T("stats", f64, "2*co*R", True), S],
     "udaseg_conv2d_dgrad_up_f32x3": [D, T("dy", f32, "Y"), I("up_c"), T("wfrag_up_t", bf16, "3*frag(up_c,co,4)"),
                                      T("da", f32, _HALF + "*up_c"), I("accumulate"), S],
+    "udaseg_conv2d_wgrad_up_f32x3": [D, T("a", f32, _HALF + "*up_c"), I("up_c"), T("dy", f32, "Y"), T("dw", f32, "W"), S],
+    "udaseg_conv2d_wgrad_halo_slice_f32x3": [D, T("x", f32, "X"), T("dy", f32, "Y"), T("dw", f32, "co*kh*kw*ldw_"), I("ldw_"),
+                                             I("c_off"), S],
     "udaseg_pack_frag_batched_f32x3": [T("w32", f32, 1, True), T("wt32", f32, 1, True), T("packed", bf16, 1),
                                        T("table", i32, "6*entries"), I("entries"), S],
     # ---- convolutions, bf16 storage

@@ -154,27 +154,31 @@ extern "C" int udaseg_memset_async(void* ptr, int value, size_t bytes, void* str
 
 // `waiter` does not run past this point before everything enqueued on `signal` so far has finished (an event from a per-device ring:
 // hipStreamWaitEvent captures the record it waits for at call time, so a slot may be recorded again while older waits are pending)
+// Both streams must belong to the CURRENT device (the ring is per device; the engine's main and side streams are): an event
+// recorded on another device's stream fails with hipErrorInvalidHandle, reported, not hidden.  Events are created one slot at a
+// time on first use (a failed creation leaves the slot empty and is retried by the next call: nothing is leaked or overwritten).
 extern "C" int udaseg_stream_wait(void* waiter, void* signal) {
   constexpr int RING = 256;
-  static hipEvent_t ring[16][RING];
-  static bool made[16] = {};
+  static hipEvent_t ring[16][RING] = {};
   static unsigned next[16] = {};
   static std::mutex mu;
   int dev = 0;
   UDASEG_CHECK_ARG(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16, "stream_wait: no current HIP device");
   std::lock_guard<std::mutex> lk(mu);
-  if (!made[dev]) {
-    for (int i = 0; i < RING; ++i) {
-      hipError_t e = hipEventCreateWithFlags(&ring[dev][i], hipEventDisableTiming);
-      if (e != hipSuccess) return hip_fail(e, "hipEventCreateWithFlags(stream_wait ring)");
+  const unsigned slot = next[dev] % RING;
+  if (ring[dev][slot] == nullptr) {
+    hipError_t e = hipEventCreateWithFlags(&ring[dev][slot], hipEventDisableTiming);
+    if (e != hipSuccess) {
+      ring[dev][slot] = nullptr;
+      return hip_fail(e, "hipEventCreateWithFlags(stream_wait ring)");
     }
-    made[dev] = true;
   }
-  hipEvent_t ev = ring[dev][next[dev]++ % RING];
+  hipEvent_t ev = ring[dev][slot];
   hipError_t e = hipEventRecord(ev, as_stream(signal));
-  if (e != hipSuccess) return hip_fail(e, "hipEventRecord(stream_wait)");
+  if (e != hipSuccess) return hip_fail(e, "hipEventRecord(stream_wait: is `signal` a stream of the current device?)");
   e = hipStreamWaitEvent(as_stream(waiter), ev, 0);
   if (e != hipSuccess) return hip_fail(e, "hipStreamWaitEvent(stream_wait)");
+  ++next[dev];
   return UDASEG_OK;
 }
 

@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <atomic>
 
 #include "../../include/udaseg.h"
 
@@ -227,7 +228,9 @@ int launch_small_wgrad(const float* x, const float* dy, float* dw, int n, int h,
                        hipStream_t s, int up = 0, const float* in_scale = nullptr, const float* in_shift = nullptr,
                        int in_act = 0, float in_slope = 0.f);
 
-// live launch timing (bench.py roofline leg): per API call (prof_*) and per kernel launch (kprof_*)
+// live launch timing (bench.py roofline leg): per API call (prof_*) and per kernel launch (kprof_*).  The launchers keep their
+// kernel id / "attribute set" flags in function-local std::atomic statics: launches come from two host threads' streams, a racing
+// first call registers the same name twice (kprof_id is serialised and returns the same id) and sets the same attribute twice.
 constexpr int PROF_NKERNELS = 24;
 int kprof_id(const char* rocprof_symbol);   // id of a kernel symbol outside the fixed table (registered on first use)
 hipEvent_t kprof_begin(hipStream_t s);
@@ -235,11 +238,11 @@ void kprof_end(int kid, hipEvent_t a, hipStream_t s, double flops);
 // RAII form for the bandwidth-bound kernels: `work` carries their ALGORITHMIC BYTES (bench.py reports TB/s for symbols that do
 // not start with "conv").  Costs one static-int test per call when profiling is off.
 struct KTimer {
-  int* kid;
+  std::atomic<int>* kid;
   hipStream_t s;
   hipEvent_t ev;
   double work;
-  KTimer(int* k, const char* rocprof_symbol, hipStream_t st, double w) : kid(k), s(st), work(w) {
+  KTimer(std::atomic<int>* k, const char* rocprof_symbol, hipStream_t st, double w) : kid(k), s(st), work(w) {
     if (*kid < 0) *kid = kprof_id(rocprof_symbol);
     ev = kprof_begin(s);
   }

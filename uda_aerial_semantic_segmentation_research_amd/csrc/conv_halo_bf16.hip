@@ -1154,7 +1154,7 @@ template <int KS, int CK, int WM, int WN, int RPW, int TW>
 static int launch_halo_t(HaloArgs a, hipStream_t s, double flops) {
   using C = HaloCfg<KS, CK, WM, WN, RPW, TW>;
   auto kern = conv_halo_bf16_kernel<KS, CK, WM, WN, RPW, TW>;
-  static bool attr_done = false;
+  static std::atomic<bool> attr_done{false};
   if (!attr_done && C::LDS > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv_halo_bf16)");
@@ -1169,7 +1169,7 @@ static int launch_halo_t(HaloArgs a, hipStream_t s, double flops) {
   a.timeline = (g_timeline && blocks <= g_timeline_blocks) ? g_timeline : nullptr;
   a.sscr = nullptr;
   if (a.stats != nullptr && blocks > 1024) a.sscr = halo_stats_scratch(a.co);
-  static int kid = -1;
+  static std::atomic<int> kid{-1};
   if (kid < 0) {
     char nm[96];
     snprintf(nm, sizeof(nm), "conv_halo_bf16_kernel<%d, %d, %d, %d, %d, %d>", KS, CK, WM, WN, RPW, TW);
@@ -1190,7 +1190,7 @@ template <int CK, int WM, int WN>
 static int launch_stream_t(HaloArgs a, hipStream_t s, double flops) {
   using C = StreamCfg<CK, WM, WN>;
   auto kern = conv1x1_stream_bf16_kernel<CK, WM, WN>;
-  static bool attr_done = false;
+  static std::atomic<bool> attr_done{false};
   if (!attr_done && C::LDS > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv1x1_stream_bf16)");
@@ -1210,7 +1210,7 @@ static int launch_stream_t(HaloArgs a, hipStream_t s, double flops) {
   long long P = cus / a.ncb;                 // one 8-wave block per CU
   if (P < 1) P = 1;
   if (P > tiles) P = tiles;
-  static int kid = -1;
+  static std::atomic<int> kid{-1};
   if (kid < 0) {
     char nm[96];
     snprintf(nm, sizeof(nm), "conv1x1_stream_bf16_kernel<%d, %d, %d>", CK, WM, WN);
@@ -1227,7 +1227,7 @@ template <int PBW>
 static int launch_gemm_t(HaloArgs a, hipStream_t s, double flops) {
   using C = GemmCfg<PBW>;
   auto kern = conv1x1_gemm_bf16_kernel<PBW>;
-  static bool attr_done = false;
+  static std::atomic<bool> attr_done{false};
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv1x1_gemm_bf16)");
@@ -1250,7 +1250,7 @@ static int launch_gemm_t(HaloArgs a, hipStream_t s, double flops) {
   const long long per = cdiv64(tiles, grid);
   grid = cdiv64(tiles, per);
   a.sscr = nullptr;
-  static int kid = -1;
+  static std::atomic<int> kid{-1};
   if (kid < 0) {
     char nm[64];
     snprintf(nm, sizeof(nm), "conv1x1_gemm_bf16_kernel<%d>", PBW);

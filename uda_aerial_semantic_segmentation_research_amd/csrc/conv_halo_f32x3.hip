@@ -706,7 +706,7 @@ template <int WM, int WN, int RPW, int TW = 32>
 static int launch_f3_ws_t(F3Args a, hipStream_t s, double flops) {
   using C = F3WsCfg<WM, WN, RPW, TW>;
   auto kern = conv3x3_f32x3_ws_kernel<WM, WN, RPW, false, TW>;
-  static bool attr_done = false;
+  static std::atomic<bool> attr_done{false};
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv3x3_f32x3_ws)");
@@ -722,7 +722,7 @@ static int launch_f3_ws_t(F3Args a, hipStream_t s, double flops) {
   if (blocks <= 0) return UDASEG_OK;
   a.sscr = nullptr;
   if (a.stats != nullptr && blocks > 1024) a.sscr = halo_stats_scratch(a.co);
-  static int kid = -1;
+  static std::atomic<int> kid{-1};
   if (kid < 0) {
     char nm[96];
     snprintf(nm, sizeof(nm), "conv3x3_f32x3_ws_kernel<%d, %d, %d, false, %d, false>", WM, WN, RPW, TW);      // the rocprofv3 symbol
@@ -731,13 +731,13 @@ static int launch_f3_ws_t(F3Args a, hipStream_t s, double flops) {
   hipEvent_t ev = kprof_begin(s);
   if (a.in_scale != nullptr) {          // the instantiation that transforms x while it stages (F3Args::in_scale)
     auto kern_xf = conv3x3_f32x3_ws_kernel<WM, WN, RPW, false, TW, true>;
-    static bool xf_attr = false;
+    static std::atomic<bool> xf_attr{false};
     if (!xf_attr) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern_xf), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
       if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv3x3_f32x3_ws, in-staging transform)");
       xf_attr = true;
     }
-    static int kid_xf = -1;             // its own rocprofv3 symbol
+    static std::atomic<int> kid_xf{-1};             // its own rocprofv3 symbol
     if (kid_xf < 0) {
       char nm[96];
       snprintf(nm, sizeof(nm), "conv3x3_f32x3_ws_kernel<%d, %d, %d, false, %d, true>", WM, WN, RPW, TW);
@@ -753,7 +753,7 @@ static int launch_f3_ws_t(F3Args a, hipStream_t s, double flops) {
     return UDASEG_OK;
   } else if (g_timeline != nullptr && blocks * 16 <= (long long)g_timeline_blocks * 6) {      // stamped twin (diagnosis only)
     auto kern_tl = conv3x3_f32x3_ws_kernel<WM, WN, RPW, true, TW>;
-    static bool tl_attr = false;
+    static std::atomic<bool> tl_attr{false};
     if (!tl_attr) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern_tl), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
       if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv3x3_f32x3_ws timeline twin)");
@@ -777,7 +777,7 @@ template <int WM, int WN, int RPW>
 static int launch_f3_t(F3Args a, hipStream_t s, double flops) {
   using C = F3Cfg<WM, WN, RPW>;
   auto kern = conv3x3_f32x3_kernel<WM, WN, RPW>;
-  static bool attr_done = false;
+  static std::atomic<bool> attr_done{false};
   if (!attr_done && C::LDS > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv3x3_f32x3)");
@@ -793,7 +793,7 @@ static int launch_f3_t(F3Args a, hipStream_t s, double flops) {
   if (blocks <= 0) return UDASEG_OK;
   a.sscr = nullptr;
   if (a.stats != nullptr && blocks > 1024) a.sscr = halo_stats_scratch(a.co);
-  static int kid = -1;
+  static std::atomic<int> kid{-1};
   if (kid < 0) {
     char nm[96];
     snprintf(nm, sizeof(nm), "conv3x3_f32x3_kernel<%d, %d, %d, false>", WM, WN, RPW);
@@ -802,13 +802,13 @@ static int launch_f3_t(F3Args a, hipStream_t s, double flops) {
   hipEvent_t ev = kprof_begin(s);
   if (a.in_scale != nullptr) {
     auto kern_xf = conv3x3_f32x3_kernel<WM, WN, RPW, true>;
-    static bool xf_attr = false;
+    static std::atomic<bool> xf_attr{false};
     if (!xf_attr && C::LDS > 48 * 1024) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern_xf), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
       if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv3x3_f32x3, in-staging transform)");
       xf_attr = true;
     }
-    static int kid_xf = -1;             // its own rocprofv3 symbol
+    static std::atomic<int> kid_xf{-1};             // its own rocprofv3 symbol
     if (kid_xf < 0) {
       char nm[96];
       snprintf(nm, sizeof(nm), "conv3x3_f32x3_kernel<%d, %d, %d, true>", WM, WN, RPW);

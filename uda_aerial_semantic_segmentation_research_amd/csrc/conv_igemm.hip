@@ -824,7 +824,7 @@ int g_timeline_blocks = 0;
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool BF, bool UNI, bool UP, bool X3 = false>
 static int launch_cfg_t(const IgemmArgs& a, hipStream_t s) {
-  static bool attr_done = false;
+  static std::atomic<bool> attr_done{false};
   constexpr int lds = igemm_lds_bytes<BM, BN, X3>();
   auto kern = conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, BF, UNI, UP, X3>;
   if (!attr_done) {

@@ -27,8 +27,9 @@
 //   * conv_up_dgrad_f32x3_kernel: gathers dy through a space-to-depth view (phase (py, px) of dy is an image of a's size whose
 //     pixels are 2 pixels apart in memory: the same 64-byte pieces per (pixel, chunk) as any other gather), one "virtual chunk"
 //     per (16 channels of dy, phase) with the 2 x 2 taps that phase has in a's 3 x 3 neighbourhood, produces da directly.
-// Weight fragments: udaseg_pack_up_batched_f32x3 (modes 2 / 3), layout plane[p][nb][G][J][lane][8] -- G the kernel's group index,
-// J = 4 (forward) / 2 (data gradient) fragments per group and 32-channel block.  Sign pattern + - - + over the groups as in
+// Weight fragments: udaseg_pack_up_batched_f32x3 (modes 2 / 3), layout plane[p][nb][G][4][lane][8] -- G the kernel's group index
+// (forward: 4 chunk + (px, ex) group; data gradient: 4 chunk + phase, one group per virtual chunk), four fragments per group and
+// 32-channel block.  Sign pattern + - - + over the groups as in
 // halo_common.h (the bf16 MFMA adder truncates).
 #include <stdlib.h>
 
@@ -78,7 +79,7 @@ struct UpCfg {
 };
 
 // ---- the loader role, shared by both kernels.  S2D: the gathered tensor is dy seen through the space-to-depth view.
-// GPH: groups per staged halo (forward: 4 per chunk; data gradient: 2 per virtual chunk).
+// GPH: groups per staged halo (forward: 4 per chunk; data gradient: 1 per virtual chunk).
 template <class C, bool S2D, int GPH>
 __device__ __forceinline__ void up_loader_role(const UpArgs& a, char* smem, char* wlds, int lt, int lane, int mw, int cb, int img,
                                                int y0, int x0, int nhalo, int NG) {
@@ -355,7 +356,7 @@ __global__ __launch_bounds__(512, 1) void conv_up_fwd_f32x3_kernel(const UpArgs 
 // ------------------------------------------------------------------------------------------------------ data gradient
 template <int WM, int WN, int RPW, int TW>
 __global__ __launch_bounds__(512, 1) void conv_up_dgrad_f32x3_kernel(const UpArgs a) {
-  using C = UpCfg<WM, WN, RPW, TW, 2>;
+  using C = UpCfg<WM, WN, RPW, TW, 4>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const wlds = smem + 2 * C::LDS_HALO;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -379,10 +380,10 @@ __global__ __launch_bounds__(512, 1) void conv_up_dgrad_f32x3_kernel(const UpArg
   const int y0 = ty * C::TH, x0 = tx * C::TW;
   const int H = a.h, W = a.w;
   const int nblocks32 = (a.co + 31) >> 5;
-  const int nvc = 4 * ((a.ci + 15) >> 4), NG = 2 * nvc;
+  const int nvc = 4 * ((a.ci + 15) >> 4);          // one group per virtual chunk
 
   if (loader) {
-    up_loader_role<C, true, 2>(a, smem, wlds, tid - 256, lane, mw, cb, img, y0, x0, nvc, NG);
+    up_loader_role<C, true, 1>(a, smem, wlds, tid - 256, lane, mw, cb, img, y0, x0, nvc, nvc);
     return;
   }
 
@@ -401,25 +402,24 @@ __global__ __launch_bounds__(512, 1) void conv_up_dgrad_f32x3_kernel(const UpArg
     const int hx = lp % C::TW + ex;
     poff[ex] = ((wm * RPW * C::RL + lp / C::TW) * C::HWD + hx) * 32 + ((lh ^ ((hx >> 3) & 1)) * 16);
   }
-  const int wrd = (wn * 2 * 3) * 1024 + lane * 16;
+  const int wrd = (wn * 4 * 3) * 1024 + lane * 16;
   __syncthreads();                                 // group 0 is staged
   for (int vc = 0; vc < nvc; ++vc) {
     const char* hb = smem + (vc & 1) * C::LDS_HALO;
     const int py = (vc >> 1) & 1, px = vc & 1;     // phase of this virtual chunk (scalar)
+    const char* wb = wlds + (vc & 1) * C::LDS_WBUF + wrd;
+    if (vc == a.q1 || vc == a.q3) {
+#pragma unroll
+      for (int r = 0; r < RPW; ++r) acc[r] = -acc[r];
+    }
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-      const int G = 2 * vc + e;
       const int ex = px ? e : 1 + e;               // px = 0: halo column offsets {1, 2}; px = 1: {0, 1}
-      const char* wb = wlds + (G & 1) * C::LDS_WBUF + wrd;
-      if (G == a.q1 || G == a.q3) {
-#pragma unroll
-        for (int r = 0; r < RPW; ++r) acc[r] = -acc[r];
-      }
       u32x4 bf[2][3];                              // halo row offsets ey = ey0 + {0, 1}, ey0 = 1 (py = 0) / 0 (py = 1)
 #pragma unroll
       for (int jy = 0; jy < 2; ++jy)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) bf[jy][pl] = *reinterpret_cast<const u32x4*>(wb + (jy * 3 + pl) * 1024);
+        for (int pl = 0; pl < 3; ++pl) bf[jy][pl] = *reinterpret_cast<const u32x4*>(wb + ((e * 2 + jy) * 3 + pl) * 1024);
       const int po = ex == 0 ? poff[0] : (ex == 1 ? poff[1] : poff[2]);
       const int ey0 = py ? 0 : 1;
       const char* hrow = hb + po + ey0 * C::HWD * 32;        // the rows this phase reads start at halo row ey0
@@ -446,8 +446,8 @@ __global__ __launch_bounds__(512, 1) void conv_up_dgrad_f32x3_kernel(const UpArg
                                                                         __builtin_bit_cast(bf16x8, pf[s & 1][ij - i]), acc[d / C::RL], 0, 0, 0);
             }
       }
-      __syncthreads();
     }
+    __syncthreads();                               // virtual chunk vc + 1 is staged; this one's buffers may be rewritten
   }
 
   const int cbase = nb * 32;
@@ -533,8 +533,8 @@ __global__ void pack_up_batched_f32x3_kernel(const float* __restrict__ w32, cons
     }
     return;
   }
-  const int J = mode == 2 ? 4 : 2;
-  const int NG = mode == 2 ? 4 * nk16 : 8 * nk16;
+  const int J = 4;
+  const int NG = 4 * nk16;
   const long long total = (long long)nb * NG * J * 64;
   const long long plane = total * 8;
   int q1 = 0, q3 = 0;
@@ -554,12 +554,12 @@ __global__ void pack_up_batched_f32x3_kernel(const float* __restrict__ w32, cons
       v = ((g + 1) >> 1) - px;
       py = j >> 1;
       u = j & 1;
-    } else {                                       // G = 2 (4 chunk + phase) + e; j = jy
-      const int vc = G >> 1, ee = G & 1;
-      kk = vc >> 2;
-      py = (vc >> 1) & 1;
-      px = vc & 1;
-      const int ex = px ? ee : 1 + ee, ey = (py ? 0 : 1) + j;
+    } else {                                       // G = 4 chunk + phase; j = 2 e + jy
+      const int ee = j >> 1, jy = j & 1;
+      kk = G >> 2;
+      py = (G >> 1) & 1;
+      px = G & 1;
+      const int ex = px ? ee : 1 + ee, ey = (py ? 0 : 1) + jy;
       u = 2 - py - ey;
       v = 2 - px - ex;
     }
@@ -594,8 +594,8 @@ static int g_up_force = 0;      // udaseg_set_option(UDASEG_OPT_UP_CONFIG): 0 = 
 
 template <int WM, int WN, int RPW, int TW, bool DGRAD>
 static int launch_up_t(UpArgs a, hipStream_t s, double flops) {
-  using C = UpCfg<WM, WN, RPW, TW, DGRAD ? 2 : 4>;
-  static bool attr_done = false;
+  using C = UpCfg<WM, WN, RPW, TW, 4>;
+  static std::atomic<bool> attr_done{false};
   if (!attr_done) {
     hipError_t e;
     if constexpr (DGRAD)
@@ -612,12 +612,12 @@ static int launch_up_t(UpArgs a, hipStream_t s, double flops) {
   a.ncb = cdiv(a.co, 32 * C::WN);
   a.nk16 = (a.ci + 15) / 16;
   a.q1 = a.q3 = -1;
-  if (f3_signs_on()) up_negated_groups((DGRAD ? 8 : 4) * a.nk16, a.q1, a.q3);
+  if (f3_signs_on()) up_negated_groups(4 * a.nk16, a.q1, a.q3);
   const long long blocks = (long long)a.n * a.nty * a.ntx * a.ncb;
   if (blocks <= 0) return UDASEG_OK;
   a.sscr = nullptr;
   if (a.stats != nullptr && blocks > 1024) a.sscr = halo_stats_scratch(a.co);
-  static int kid = -1;
+  static std::atomic<int> kid{-1};
   if (kid < 0) {
     char nm[96];
     snprintf(nm, sizeof(nm), "conv_up_%s_f32x3_kernel<%d, %d, %d, %d>", DGRAD ? "dgrad" : "fwd", WM, WN, RPW, TW);
@@ -638,25 +638,19 @@ static int launch_up_t(UpArgs a, hipStream_t s, double flops) {
 }
 
 // configuration of a launch: (a's extents, produced channels).  1: 2 x 32 a-pixels x 64 channels; 2: 4 x 32 x 64; 3: 4 x 32 x 32;
-// 4: 8 x 32 x 32; 5: 4 x 16 x 64 (16-pixel-wide a); 6: 8 x 16 x 64; 7: 8 x 16 x 32; 8: 8 x 32 x 64 (data gradient only)
+// 4: 8 x 32 x 32; 5: 4 x 16 x 64 (16-pixel-wide a); 6: 8 x 16 x 64; 7: 8 x 16 x 32; 8: 8 x 32 x 64 (data gradient only).
+// Measured per decoder block of BASELINE cfg 2 (tools/up_probe.py, profiles/r05_up_probe.txt; us forward / data gradient):
+// the FORWARD is fastest on 32-channel blocks everywhere (cfg 3 / 7: 83 / 53 / 51 / 61 / 96 us for blocks 0..4 against 109 / 94 /
+// 104 / 113 / 211 for the nine-tap gather of the same half) -- four phases x 12 weight fragments per group are this kernel's LDS
+// traffic, and two channel blocks per workgroup double it per staged halo; the DATA GRADIENT wants the 8 x 32 x 64 tile wherever
+// that still gives a block per CU (43 / 53 us on blocks 2 / 3), 4 x 32 x 64 below that, 32-channel blocks for <= 32 produced.
 static int up_choice(int n, int h, int w, int produced, bool dgrad) {
   if (g_up_force > 0) return g_up_force;
-  if (w <= 16) {
-    if (produced <= 32) return 7;
-    const long long b6 = (long long)n * cdiv(h, 8) * cdiv(produced, 64);
-    return (dgrad && b6 >= 256) ? 6 : 5;
-  }
-  if (produced <= 32) {
-    const long long b4 = (long long)n * cdiv(h, 8) * cdiv(w, 32);
-    return (dgrad && b4 >= 512) ? 4 : 3;
-  }
+  if (w <= 16) return 7;
+  if (!dgrad || produced <= 32) return 3;
   const long long ncb = cdiv(produced, 64);
-  if (dgrad) {
-    if ((long long)n * cdiv(h, 8) * cdiv(w, 32) * ncb >= 256) return 8;
-    if ((long long)n * cdiv(h, 4) * cdiv(w, 32) * ncb >= 256) return 2;
-    return 1;
-  }
-  return (long long)n * cdiv(h, 4) * cdiv(w, 32) * ncb >= 512 ? 2 : 1;
+  if ((long long)n * cdiv(h, 8) * cdiv(w, 32) * ncb >= 256) return 8;
+  return 2;
 }
 
 template <bool DGRAD>

@@ -869,8 +869,8 @@ static int launch_wgrad_x3(WgradArgs a, int accumulate, hipStream_t s) {
     hipLaunchKernelGGL((conv_wgrad_x3_kernel<BMW, BNW, WAVES_M, WAVES_N, true>), grid, block, 0, s, a);
   else
     hipLaunchKernelGGL((conv_wgrad_x3_kernel<BMW, BNW, WAVES_M, WAVES_N, false>), grid, block, 0, s, a);
-  static int kidx[2] = {-1, -1};
-  int& kid = kidx[a.row_uniform ? 1 : 0];
+  static std::atomic<int> kidx[2] = {{-1}, {-1}};
+  std::atomic<int>& kid = kidx[a.row_uniform ? 1 : 0];
   if (kid < 0) {
     char nm[96];
     snprintf(nm, sizeof(nm), "conv_wgrad_x3_kernel<%d, %d, %d, %d, %s>", BMW, BNW, WAVES_M, WAVES_N, a.row_uniform ? "true" : "false");
@@ -951,8 +951,8 @@ static int launch_wgrad(WgradArgs a, int accumulate, hipStream_t s, bool bf16 = 
       hipLaunchKernelGGL((conv_wgrad_bf16_kernel<BMW, BNW, WAVES_M, WAVES_N, true>), grid, block, 0, s, a);
     else
       hipLaunchKernelGGL((conv_wgrad_bf16_kernel<BMW, BNW, WAVES_M, WAVES_N, false>), grid, block, 0, s, a);
-    static int kid16[2] = {-1, -1};     // one id per rocprofv3 symbol (round 2 lumped the bf16 instantiations into one)
-    int& kid = kid16[a.row_uniform ? 1 : 0];
+    static std::atomic<int> kid16[2] = {{-1}, {-1}};     // one id per rocprofv3 symbol (round 2 lumped the bf16 instantiations into one)
+    std::atomic<int>& kid = kid16[a.row_uniform ? 1 : 0];
     if (kid < 0) {
       char nm[96];
       snprintf(nm, sizeof(nm), "conv_wgrad_bf16_kernel<%d, %d, %d, %d, %s>", BMW, BNW, WAVES_M, WAVES_N, a.row_uniform ? "true" : "false");
@@ -977,8 +977,8 @@ static int launch_wgrad(WgradArgs a, int accumulate, hipStream_t s, bool bf16 = 
       hipLaunchKernelGGL((conv_wgrad_kernel<BMW, BNW, WAVES_M, WAVES_N, false>), grid, block, 0, s, a);
     int kid32 = (a.row_uniform ? 18 : 7) + (BMW == 64 ? 0 : 1);      // the fixed table knows the 64 x 64 and 32 x 128 symbols
     if (BMW == 128) {
-      static int kid128[2] = {-1, -1};
-      int& k = kid128[a.row_uniform ? 1 : 0];
+      static std::atomic<int> kid128[2] = {{-1}, {-1}};
+      std::atomic<int>& k = kid128[a.row_uniform ? 1 : 0];
       if (k < 0) {
         char nm[96];
         snprintf(nm, sizeof(nm), "conv_wgrad_kernel<%d, %d, %d, %d, %s>", BMW, BNW, WAVES_M, WAVES_N, a.row_uniform ? "true" : "false");
@@ -1096,7 +1096,8 @@ extern "C" int udaseg_conv2d_wgrad_bnin_bf16(const udaseg_conv_desc* d, const vo
 namespace udaseg {
 bool wgrad_h2_applicable(const udaseg_conv_desc* d, int up_ca, bool f32);
 int launch_wgrad_h2(const udaseg_conv_desc* d, const void* x, const void* x2, int up_ca, const void* dy, float* dw, bool f32, hipStream_t s,
-                    const float* in_scale = nullptr, const float* in_shift = nullptr, int in_act = 0, float in_slope = 0.f);
+                    const float* in_scale = nullptr, const float* in_shift = nullptr, int in_act = 0, float in_slope = 0.f,
+                    int ldw = 0, int dw_coff = 0);
 static bool wgrad_halo_off(bool f32) {
   static int off = -1, off3 = -1;   // UDASEG_NO_WGRAD_HALO=1: the per-tap split-K kernels everywhere; UDASEG_F32_SPLIT=0: no fp32 split
   if (off < 0) {
@@ -1130,15 +1131,16 @@ extern "C" int udaseg_conv2d_wgrad_bnin(const udaseg_conv_desc* d, const float* 
     return UDASEG_E_UNSUPPORTED;
   }
   hipStream_t st = as_stream(stream);
+  const bool small = small_wgrad_applicable(d->kh, d->stride, d->pad, d->ci, d->co, d->n * cdiv(d->hi, 16) * cdiv(d->wi, 16));
+  if (!small && !accumulate) {          // before prof_begin: an early return must not leave the family's timing record open
+    hipError_t e = hipMemsetAsync(dw, 0, (size_t)d->co * 9 * d->ci * sizeof(float), st);
+    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(dw)");
+  }
   prof_begin(1, st);
   int rc;
-  if (small_wgrad_applicable(d->kh, d->stride, d->pad, d->ci, d->co, d->n * cdiv(d->hi, 16) * cdiv(d->wi, 16))) {
+  if (small) {
     rc = launch_small_wgrad(x, dy, dw, d->n, d->hi, d->wi, d->ci, d->co, accumulate, st, up, in_scale, in_shift, in_act, in_slope);
   } else {
-    if (!accumulate) {
-      hipError_t e = hipMemsetAsync(dw, 0, (size_t)d->co * 9 * d->ci * sizeof(float), st);
-      if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(dw)");
-    }
     rc = launch_wgrad_h2(d, x, nullptr, 0, dy, dw, true, st, in_scale, in_shift, in_act, in_slope);
   }
   prof_end(1, st, udaseg_conv_flops(d), 2, d);
@@ -1181,6 +1183,26 @@ extern "C" int udaseg_conv2d_wgrad_halo_f32x3(const udaseg_conv_desc* d, const f
   hipStream_t st = as_stream(stream);
   prof_begin(1, st);
   const int rc = launch_wgrad_h2(d, x, skip, up_ca, dy, dw, true, st);
+  prof_end(1, st, udaseg_conv_flops(d), 2, d);
+  return rc;
+}
+
+// The same kernel filling a channel SLICE of a wider layer's gradient: d describes the slice (ci = the slice's channels = x's
+// channels), dW rows are ldw channels long and the slice starts at c_off.  The skip half of a decoder conv1 whose up-sampled half
+// runs in the phase form (udaseg_conv2d_wgrad_up_f32x3).
+extern "C" int udaseg_conv2d_wgrad_halo_slice_f32x3(const udaseg_conv_desc* d, const float* x, const float* dy, float* dw, int ldw,
+                                                    int c_off, void* stream) {
+  UDASEG_CHECK_ARG(d && x && dy && dw, "conv2d_wgrad_halo_slice_f32x3: NULL pointer");
+  UDASEG_CHECK_ARG(d->n > 0 && d->hi > 0 && d->wi > 0 && d->ho == d->hi && d->wo == d->wi, "conv2d_wgrad_halo_slice_f32x3: bad extents");
+  UDASEG_CHECK_ARG(ldw >= d->ci && c_off >= 0 && c_off + d->ci <= ldw && c_off % 4 == 0 && ldw % 4 == 0,
+                   "conv2d_wgrad_halo_slice_f32x3: slice [%d, %d) of rows of %d channels", c_off, c_off + d->ci, ldw);
+  if (!udaseg_conv2d_wgrad_halo_f32x3_ok(d, 0)) {
+    set_error("conv2d_wgrad_halo_slice_f32x3: geometry not supported (ask udaseg_conv2d_wgrad_halo_f32x3_ok on the slice's descriptor)");
+    return UDASEG_E_UNSUPPORTED;
+  }
+  hipStream_t st = as_stream(stream);
+  prof_begin(1, st);
+  const int rc = launch_wgrad_h2(d, x, nullptr, 0, dy, dw, true, st, nullptr, nullptr, 0, 0.f, ldw, c_off);
   prof_end(1, st, udaseg_conv_flops(d), 2, d);
   return rc;
 }

@@ -39,7 +39,8 @@ struct WgradH2Args {
   const void* x;      // [n][h][w][cx], or the half-resolution a [n][h/2][w/2][up_ca] of a fused decoder input
   const void* x2;     // fused decoder input: the skip tensor [n][h][w][ci - up_ca]
   const void* dy;     // [n][h][w][co]
-  float* dw;          // [co][9][ci] fp32, accumulated onto
+  float* dw;          // [co][9][ldw] fp32, accumulated onto: channels [dw_coff, dw_coff + ci) of every row (ldw = ci, dw_coff = 0: the whole row)
+  int ldw, dw_coff;
   int n, h, w, ci, co, up_ca;
   int ntx, nty, ntiles, ncib, pairs, P;
   unsigned x_bytes, x2_bytes, dy_bytes;
@@ -336,7 +337,7 @@ __device__ __forceinline__ void wgrad_h2_role(const WgradH2Args& a, char* smem, 
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
         const int co_g = cob * C::COB + coq * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
-        atomicAdd(a.dw + ((size_t)co_g * 9 + dy * 3 + DX0 + dxi) * a.ci + ci_g, acc[dy * NDX + dxi][v]);
+        atomicAdd(a.dw + ((size_t)co_g * 9 + dy * 3 + DX0 + dxi) * a.ldw + a.dw_coff + ci_g, acc[dy * NDX + dxi][v]);
       }
 }
 
@@ -387,6 +388,7 @@ struct H2In {        // WgradH2Args::in_*
   const float* shift = nullptr;
   int act = 0;
   float slope = 0.f;
+  int ldw = 0, dw_coff = 0;      // > 0: dW rows are ldw channels long and this launch fills [dw_coff, dw_coff + ci) (a slice of a wider layer)
 };
 
 template <int PL, int COQ, int CIQ, int TR, int TWK, int NSTW, bool DB = false>
@@ -395,6 +397,7 @@ static int launch_h2_t(const udaseg_conv_desc* d, const void* x, const void* x2,
   using C = H2<PL, COQ, CIQ, TR, TWK, NSTW, DB>;
   WgradH2Args a = {};
   a.x = x; a.x2 = x2; a.dy = dy; a.dw = dw;
+  a.ldw = in.ldw > 0 ? in.ldw : d->ci; a.dw_coff = in.ldw > 0 ? in.dw_coff : 0;
   a.in_scale = in.scale; a.in_shift = in.shift; a.in_act = in.act; a.in_slope = in.slope;
   a.n = d->n; a.h = d->hi; a.w = d->wi; a.ci = d->ci; a.co = d->co; a.up_ca = up_ca;
   a.ntx = cdiv(d->wi, C::TW); a.nty = cdiv(d->hi, C::TR); a.ntiles = d->n * a.ntx * a.nty;
@@ -408,13 +411,13 @@ static int launch_h2_t(const udaseg_conv_desc* d, const void* x, const void* x2,
   a.x2_bytes = (unsigned)(up_ca > 0 ? px * (d->ci - up_ca) * C::ES : 0);
   a.dy_bytes = (unsigned)(px * d->co * C::ES);
   auto kern = conv_wgrad_h2_kernel<PL, COQ, CIQ, TR, TWK, NSTW, DB>;
-  static bool attr_done = false;
+  static std::atomic<bool> attr_done{false};
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv_wgrad_h2)");
     attr_done = true;
   }
-  static int kid = -1;
+  static std::atomic<int> kid{-1};
   if (kid < 0) {
     char nm[96];
     snprintf(nm, sizeof(nm), "conv_wgrad_h2_kernel<%d, %d, %d, %d, %d, %d, %s, false, false>", PL, COQ, CIQ, TR, TWK, NSTW, DB ? "true" : "false");
@@ -422,9 +425,10 @@ static int launch_h2_t(const udaseg_conv_desc* d, const void* x, const void* x2,
   }
   hipEvent_t ev = kprof_begin(s);
   if constexpr (PL == 3 && COQ == 2 && CIQ == 2 && TWK == 2) {      // the dominant configuration has a stamped twin (diagnosis only)
-    if (g_timeline != nullptr && (long long)a.pairs * P * 16 <= (long long)g_timeline_blocks * 6) {
+    // (never for a launch that transforms x while staging: the twin has no XF form and would multiply the RAW tensor)
+    if (g_timeline != nullptr && a.in_scale == nullptr && (long long)a.pairs * P * 16 <= (long long)g_timeline_blocks * 6) {
       auto kern_tl = conv_wgrad_h2_kernel<PL, COQ, CIQ, TR, TWK, NSTW, DB, true>;
-      static bool tl_attr = false;
+      static std::atomic<bool> tl_attr{false};
       if (!tl_attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern_tl), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv_wgrad_h2 timeline twin)");
@@ -440,13 +444,13 @@ static int launch_h2_t(const udaseg_conv_desc* d, const void* x, const void* x2,
   if constexpr (PL == 3) {
     if (a.in_scale != nullptr) {          // the instantiation that transforms x while it stages (WgradH2Args::in_scale)
       auto kern_xf = conv_wgrad_h2_kernel<PL, COQ, CIQ, TR, TWK, NSTW, DB, false, true>;
-      static bool xf_attr = false;
+      static std::atomic<bool> xf_attr{false};
       if (!xf_attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern_xf), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv_wgrad_h2, in-staging transform)");
         xf_attr = true;
       }
-      static int kid_xf = -1;
+      static std::atomic<int> kid_xf{-1};
       if (kid_xf < 0) {
         char nm[112];
         snprintf(nm, sizeof(nm), "conv_wgrad_h2_kernel<%d, %d, %d, %d, %d, %d, %s, false, true>", PL, COQ, CIQ, TR, TWK, NSTW, DB ? "true" : "false");
@@ -465,9 +469,10 @@ static int launch_h2_t(const udaseg_conv_desc* d, const void* x, const void* x2,
 }
 
 int launch_wgrad_h2(const udaseg_conv_desc* d, const void* x, const void* x2, int up_ca, const void* dy, float* dw, bool f32,
-                    hipStream_t s, const float* in_scale, const float* in_shift, int in_act, float in_slope) {
+                    hipStream_t s, const float* in_scale, const float* in_shift, int in_act, float in_slope, int ldw, int dw_coff) {
   H2In in;
   in.scale = in_scale; in.shift = in_shift; in.act = in_act; in.slope = in_slope;
+  in.ldw = ldw; in.dw_coff = dw_coff;
   if (in_scale != nullptr && (!f32 || up_ca != 0 || in_shift == nullptr)) {
     set_error("conv2d_wgrad_halo: the in-staging transform needs fp32 operands and a single plain source");
     return UDASEG_E_UNSUPPORTED;
@@ -506,4 +511,308 @@ int launch_wgrad_h2(const udaseg_conv_desc* d, const void* x, const void* x2, in
   return launch_h2_t<1, 1, 1, 8, 2, 8>(d, x, x2, up_ca, dy, dw, s, tbf);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Round 5: the weight gradient of a decoder conv1's UP-SAMPLED half in the phase form of conv_up_f32x3.hip.
+//   conv3x3(nearest_x2(a)) = four 2x2 phase convolutions of a with pre-summed weights W'_{py,px}[u][v], so
+//   T_{py,px}[u][v][co][ci] = sum_{q,r} dy[2q+py, 2r+px][co] * a[q + py - 1 + u, r + px - 1 + v][ci]          (16 correlations at a's size)
+//   dW[ky][kx] += T_{py,px}[u][v]  for every (py, u) with ky in Ky(py, u) and (px, v) with kx in Kx(px, v)      (each tap: 4 of the 16)
+// -- 16 tap evaluations per pixel of `a` instead of 4 x 9 = 36 (reference: loss.backward(), src/models/train.py:343, through
+// aten::upsample_nearest2d + aten::_convolution of smp's DecoderBlock).  The h2 scheme in a's coordinates: a block owns a
+// (32 COQ) x (32 CIQ) block of dW and ONE column phase px, and walks tiles of TR rows x 16 TWK pixels of `a`; it stages the a-halo
+// once per tile and the 2 TR rows x TW pixels of dy that are the phases (0, px), (1, px) of the tile (pixels two apart in memory:
+// the same 16-byte pieces as any other gather); waves 0-3 own the halo column offset ex = px (v = 0), waves 4-7 ex = px + 1 (v = 1),
+// each its (py, u) in {0,1}^2 accumulators of a 32 x 32 quadrant: an x fragment of halo row rr feeds the dy rows 2 (rr - py - u) + py.
+// All eight waves stage (the MFMA work per staged byte is 4/9 of the nine-tap kernel's); two LDS buffers, one barrier per tile.
+// The accumulators leave as fp32 atomics into the one, two or four taps their phase tap stands for.
+struct WgradUpArgs {
+  const float* x;     // a [n][h][w][ca]
+  const float* dy;    // [n][2h][2w][co]
+  float* dw;          // [co][9][ldw] fp32, accumulated onto (channels [0, ca) of the rows)
+  int n, h, w, ca, co, ldw;
+  int ntx, nty, ntiles, ncib, pairs, P;
+  unsigned x_bytes, dy_bytes;
+};
+
+template <int COQ_, int CIQ_, int TR_, int TWK_>
+struct H2Up {
+  static constexpr int PL = 3, COQ = COQ_, CIQ = CIQ_, TR = TR_, TWK = TWK_;
+  static constexpr int NT = 512;
+  static constexpr int COB = 32 * COQ, CIB = 32 * CIQ, TW = 16 * TWK;
+  static constexpr int HR = TR + 2, HWD = TW + 2, HP = HR * HWD, TP = 2 * TR * TW;       // dy: rows 2 q + py of the tile
+  static constexpr int NQ = COQ * CIQ, KS = 4 / NQ;
+  static constexpr int KSH = KS < TWK ? KS : TWK, KSR = KS / KSH;
+  static constexpr int RW = TR / KSR, NHF = TWK / KSH;
+  static constexpr int XSP = h2_pad(HP * 64), DSP = h2_pad(TP * 64);
+  static constexpr int XPLANE = CIQ * XSP, DPLANE = COQ * DSP;
+  static constexpr int BUF = PL * (XPLANE + DPLANE);
+  static constexpr int LDS = 2 * BUF;
+  static constexpr int XO = CIB / 8, DO = COB / 8;
+  static constexpr int XPC = HP * XO, DPC = TP * DO;
+  static constexpr int NX = (XPC + NT - 1) / NT, ND = (DPC + NT - 1) / NT;
+  static_assert(NQ == 2 || NQ == 4, "2 or 4 quadrants");
+  static_assert(TR % KSR == 0 && TWK % KSH == 0 && KSH * KSR == KS, "K split tiles the tile");
+  static_assert(LDS <= 160 * 1024, "LDS");
+};
+
+template <typename C, int V>
+__device__ __forceinline__ void wgrad_up_role(const WgradUpArgs& a, char* smem, int tid, int lane, int wave) {
+  constexpr int PL = 3;
+  char* const Xs = smem;
+  char* const Ds = smem + PL * C::XPLANE;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int grp = lane >> 4, cb = 16 * (grp & 1), hk = grp >> 1, tq = (lane & 15) >> 2, tp = lane & 3;
+  const int q = wave & 3;
+  const int qi = q % C::NQ, ks = q / C::NQ;
+  const int coq = qi / C::CIQ, ciq = qi % C::CIQ;
+  const int ksh = ks % C::KSH, r0 = (ks / C::KSH) * C::RW;
+  int bidx = (int)blockIdx.x;
+  const int px = bidx & 1;                 // this block's column phase
+  bidx >>= 1;
+  const int pair = bidx % a.pairs, split = bidx / a.pairs;
+  const int cob = pair / a.ncib, cib = pair % a.ncib;
+  const int H = a.h, W = a.w;
+  __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, (int)a.dy_bytes, 0x00020000);
+  u32x4 sx[C::NX][2], sd[C::ND][2];
+  auto load_tile = [&](int tile) {
+    const int tx = tile % a.ntx;
+    const int t2 = tile / a.ntx;
+    const int ty = t2 % a.nty, img = t2 / a.nty;
+    const int y0 = ty * C::TR, x0 = tx * C::TW;
+#pragma unroll
+    for (int i = 0; i < C::NX; ++i) {
+      const int pc = tid + i * C::NT;
+      const int pix = pc / C::XO, oct = pc % C::XO;
+      const int hy = pix / C::HWD, hx = pix - hy * C::HWD;
+      const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+      const bool ok = pc < C::XPC && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      const unsigned off = ok ? (unsigned)((((img * H + iy) * W + ix) * a.ca + cib * C::CIB + oct * 8) * 4) : 0x80000000u;
+#pragma unroll
+      for (int l = 0; l < 2; ++l) sx[i][l] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)off, 16 * l, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < C::ND; ++i) {
+      const int pc = tid + i * C::NT;
+      const int pix = pc / C::DO, oct = pc % C::DO;
+      const int row2 = pix / C::TW, col = pix % C::TW;          // row2 = 2 (row of the tile) + py
+      const int qy = y0 + (row2 >> 1), qx = x0 + col;
+      const bool ok = pc < C::DPC && qy < H && qx < W;
+      const unsigned off = ok ? (unsigned)((((img * 2 * H + 2 * qy + (row2 & 1)) * (2 * W) + 2 * qx + px) * a.co + cob * C::COB + oct * 8) * 4)
+                              : 0x80000000u;
+#pragma unroll
+      for (int l = 0; l < 2; ++l) sd[i][l] = __builtin_amdgcn_raw_buffer_load_b128(rs_d, (int)off, 16 * l, 0);
+    }
+  };
+  auto store_piece = [&](char* dst, int plane_bytes, const u32x4 (&v)[2], unsigned sgn) {
+    u32x4 p0, p1, p2;
+    split3(v[0] ^ sgn, v[1] ^ sgn, p0, p1, p2);
+    *reinterpret_cast<u32x4*>(dst) = p0;
+    *reinterpret_cast<u32x4*>(dst + plane_bytes) = p1;
+    *reinterpret_cast<u32x4*>(dst + 2 * plane_bytes) = p2;
+  };
+  const int nseq = split < a.ntiles ? (a.ntiles - split + a.P - 1) / a.P : 0;
+  const int sq1 = (nseq + 2) / 4, sq3 = nseq - sq1;             // + - - + over the block's tile sequence (see wgrad_h2_role)
+  auto store_tile = [&](int bo, int seq) {
+    const unsigned dsgn = (seq >= sq1 && seq < sq3) ? 0x80000000u : 0u;
+#pragma unroll
+    for (int i = 0; i < C::NX; ++i) {
+      const int pc = tid + i * C::NT;
+      const int pix = pc / C::XO, oct = pc % C::XO;
+      if (i < C::NX - 1 || pc < C::XPC) store_piece(Xs + bo + (oct >> 2) * C::XSP + pix * 64 + (oct & 3) * 16, C::XPLANE, sx[i], 0u);
+    }
+#pragma unroll
+    for (int i = 0; i < C::ND; ++i) {
+      const int pc = tid + i * C::NT;
+      const int pix = pc / C::DO, oct = pc % C::DO;
+      if (i < C::ND - 1 || pc < C::DPC) store_piece(Ds + bo + (oct >> 2) * C::DSP + pix * 64 + (oct & 3) * 16, C::DPLANE, sd[i], dsgn);
+    }
+  };
+
+  f32x16 acc[4];        // [py * 2 + u]
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+
+  const int lane_off = (8 * hk + tq) * 64 + (cb + 4 * tp) * 2;
+  const char* const dbase0 = Ds + coq * C::DSP + (2 * r0 * C::TW + 16 * ksh) * 64 + lane_off;
+  const char* const xbase0 = Xs + ciq * C::XSP + (r0 * C::HWD + 16 * ksh + px + V) * 64 + lane_off;
+
+  int cur = 0;
+  if (split < a.ntiles) load_tile(split);
+  store_tile(0, 0);
+  if (split + a.P < a.ntiles) load_tile(split + a.P);
+  __syncthreads();
+  int seq = 0;
+  bool negated = false;
+  for (int tile = split; tile < a.ntiles; tile += a.P, ++seq) {
+    if ((seq >= sq1 && seq < sq3) != negated) {
+      negated = !negated;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = -acc[t];
+    }
+    if (tile + a.P < a.ntiles) {
+      store_tile(cur ^ C::BUF, seq + 1);
+      if (tile + 2 * a.P < a.ntiles) load_tile(tile + 2 * a.P);
+    }
+    const char* const dbase = dbase0 + cur;
+    const char* const xbase = xbase0 + cur;
+    cur ^= C::BUF;
+#pragma unroll
+    for (int hfi = 0; hfi < C::NHF; ++hfi) {
+      // dy fragments: D0[j] = phase row py = 0 of tile row j (LDS row 2 j), D1[j] = py = 1 (LDS row 2 j + 1); at halo row rr the
+      // taps (py, u) read D_py[rr - py - u]: D0[rr] and D1[rr - 1] are new, D0[rr - 1] and D1[rr - 2] come from the step before
+      bf16x8 D0[2][PL], D1[2][PL];
+#pragma unroll
+      for (int rr = 0; rr < C::RW + 2; ++rr) {
+        if (rr < C::RW) {
+#pragma unroll
+          for (int pl = 0; pl < PL; ++pl)
+            D0[rr & 1][pl] = h2_tr_fragment(dbase + pl * C::DPLANE + ((2 * rr) * C::TW + 16 * C::KSH * hfi) * 64);
+        }
+        if (rr >= 1 && rr - 1 < C::RW) {
+#pragma unroll
+          for (int pl = 0; pl < PL; ++pl)
+            D1[(rr - 1) & 1][pl] = h2_tr_fragment(dbase + pl * C::DPLANE + ((2 * (rr - 1) + 1) * C::TW + 16 * C::KSH * hfi) * 64);
+        }
+        bf16x8 B[PL];
+#pragma unroll
+        for (int pl = 0; pl < PL; ++pl) B[pl] = h2_tr_fragment(xbase + pl * C::XPLANE + (rr * C::HWD + 16 * C::KSH * hfi) * 64);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int py = t >> 1, u = t & 1;
+          const int j = rr - py - u;           // tile row whose tap (py, u) reads halo row rr
+          if (j >= 0 && j < C::RW) {
+#pragma unroll
+            for (int ij = 2; ij >= 0; --ij)
+#pragma unroll
+              for (int i = 0; i <= ij; ++i)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(py ? D1[j & 1][i] : D0[j & 1][i], B[ij - i], acc[t], 0, 0, 0);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (negated) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = -acc[t];
+  }
+  // dW[co][ky][kx][ci] += T: the kernel rows Ky(py, u) x columns Kx(px, V) this phase tap stands for
+  const int ci_g = cib * C::CIB + ciq * 32 + lr;
+  const int kx0 = px == 0 ? (V ? 1 : 0) : (V ? 2 : 0), kx1 = px == 0 ? (V ? 2 : 0) : (V ? 2 : 1);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int py = t >> 1, u = t & 1;
+    const int ky0 = py == 0 ? (u ? 1 : 0) : (u ? 2 : 0), ky1 = py == 0 ? (u ? 2 : 0) : (u ? 2 : 1);
+#pragma unroll
+    for (int ky = ky0; ky <= ky1; ++ky)
+      for (int kx = kx0; kx <= kx1; ++kx)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int co_g = cob * C::COB + coq * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
+          atomicAdd(a.dw + ((size_t)co_g * 9 + ky * 3 + kx) * a.ldw + ci_g, acc[t][v]);
+        }
+  }
+}
+
+template <int COQ, int CIQ, int TR, int TWK>
+__global__ __launch_bounds__(512, 2) void conv_wgrad_up_kernel(const WgradUpArgs a) {
+  using C = H2Up<COQ, CIQ, TR, TWK>;
+  extern __shared__ __attribute__((aligned(16))) char h2smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (wave < 4) wgrad_up_role<C, 0>(a, h2smem, tid, lane, wave);
+  else wgrad_up_role<C, 1>(a, h2smem, tid, lane, wave);
+}
+
+// 0: not served; 1: 64 x 64 channel blocks, 1 x 32 a-pixel tiles; 2: 64 x 64, 2 x 16 (16-pixel-wide a); 3: 32 produced x 64 gathered
+static int h2up_config(const udaseg_conv_desc* d, int up_ca) {
+  if (!d || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1) return 0;
+  if (d->n <= 0 || d->hi < 2 || d->wi < 2 || d->ho != d->hi || d->wo != d->wi || d->hi % 2 || d->wi % 2) return 0;
+  if (up_ca <= 0 || up_ca > d->ci || up_ca % 64 != 0 || d->co % 32 != 0) return 0;
+  const long long px = (long long)d->n * d->hi * d->wi;
+  if (px * d->co * 4 >= (1LL << 31) || px / 4 * up_ca * 4 >= (1LL << 31)) return 0;
+  const int wa = d->wi / 2;
+  if (wa < 16) return 0;
+  if (d->co % 64 != 0) return wa >= 32 ? 3 : 0;
+  return wa >= 32 ? 1 : 2;
+}
+
+template <int COQ, int CIQ, int TR, int TWK>
+static int launch_h2up_t(const udaseg_conv_desc* d, const float* a_, int up_ca, const float* dy, float* dw, hipStream_t s, int target) {
+  using C = H2Up<COQ, CIQ, TR, TWK>;
+  WgradUpArgs a = {};
+  a.x = a_; a.dy = dy; a.dw = dw;
+  a.n = d->n; a.h = d->hi / 2; a.w = d->wi / 2; a.ca = up_ca; a.co = d->co; a.ldw = d->ci;
+  a.ntx = cdiv(a.w, C::TW); a.nty = cdiv(a.h, C::TR); a.ntiles = a.n * a.ntx * a.nty;
+  a.ncib = up_ca / C::CIB; a.pairs = a.ncib * (d->co / C::COB);
+  int P = target / (2 * a.pairs);
+  if (P < 1) P = 1;
+  if (P > a.ntiles) P = a.ntiles;
+  a.P = P;
+  const long long pa = (long long)a.n * a.h * a.w;
+  a.x_bytes = (unsigned)(pa * up_ca * 4);
+  a.dy_bytes = (unsigned)(4 * pa * d->co * 4);
+  auto kern = conv_wgrad_up_kernel<COQ, CIQ, TR, TWK>;
+  static std::atomic<bool> attr_done{false};
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv_wgrad_up)");
+    attr_done = true;
+  }
+  static std::atomic<int> kid{-1};
+  if (kid < 0) {
+    char nm[96];
+    snprintf(nm, sizeof(nm), "conv_wgrad_up_kernel<%d, %d, %d, %d>", COQ, CIQ, TR, TWK);
+    kid = kprof_id(nm);
+  }
+  hipEvent_t ev = kprof_begin(s);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(2 * a.pairs * P)), dim3(C::NT), C::LDS, s, a);
+  kprof_end(kid, ev, s, 2.0 * (double)pa * d->co * 16.0 * up_ca);
+  UDASEG_LAUNCH_CHECK("conv_wgrad_up launch");
+  return UDASEG_OK;
+}
+
+static int g_wgrad_up_blocks = 0;      // tests / tuning (udaseg_wgrad_up_set_blocks): 0 = the default below
+
 }  // namespace udaseg
+
+using namespace udaseg;
+
+extern "C" int udaseg_conv2d_wgrad_up_f32x3_ok(const udaseg_conv_desc* d, int up_ca) {
+  return f32_split_enabled() && h2up_config(d, up_ca) != 0 ? 1 : 0;
+}
+
+extern "C" int udaseg_wgrad_up_set_blocks(int blocks) {
+  UDASEG_CHECK_ARG(blocks >= 0 && blocks <= 4096, "wgrad_up_set_blocks: 0 (default) .. 4096");
+  g_wgrad_up_blocks = blocks;
+  return UDASEG_OK;
+}
+
+// dW[co][9][ci] (rows of d->ci channels, the first up_ca of them) += the weight gradient of conv3x3(nearest_x2(a)) in the phase form
+extern "C" int udaseg_conv2d_wgrad_up_f32x3(const udaseg_conv_desc* d, const float* a, int up_ca, const float* dy, float* dw,
+                                            void* stream) {
+  UDASEG_CHECK_ARG(d && a && dy && dw, "conv2d_wgrad_up_f32x3: NULL pointer");
+  const int cfg = f32_split_enabled() ? h2up_config(d, up_ca) : 0;
+  if (cfg == 0) {
+    set_error("conv2d_wgrad_up_f32x3: geometry not supported (ask udaseg_conv2d_wgrad_up_f32x3_ok first)");
+    return UDASEG_E_UNSUPPORTED;
+  }
+  int target = g_wgrad_up_blocks > 0 ? g_wgrad_up_blocks : 128;
+  static int env_cfg = -1, env_blocks = -1;      // TEMPORARY tuning aids
+  if (env_cfg < 0) { env_cfg = h2_env("UDASEG_WGUP_CFG", 0); env_blocks = h2_env("UDASEG_WGUP_BLOCKS", 0); }
+  if (env_blocks > 0 && g_wgrad_up_blocks == 0) target = env_blocks;
+  hipStream_t st = as_stream(stream);
+  udaseg_conv_desc dd = *d;
+  dd.ci = up_ca;
+  const double flops = 2.0 * (double)d->n * (d->hi / 2) * (d->wi / 2) * d->co * 16.0 * up_ca;
+  prof_begin(1, st);
+  int rc;
+  if (cfg == 1 && env_cfg == 2) rc = launch_h2up_t<2, 2, 2, 1>(d, a, up_ca, dy, dw, st, target);
+  else if (cfg == 1) rc = launch_h2up_t<2, 2, 1, 2>(d, a, up_ca, dy, dw, st, target);
+  else if (cfg == 2) rc = launch_h2up_t<2, 2, 2, 1>(d, a, up_ca, dy, dw, st, target);
+  else rc = launch_h2up_t<1, 2, 1, 2>(d, a, up_ca, dy, dw, st, target);
+  prof_end(1, st, flops, 2, &dd);
+  return rc;
+}

@@ -565,7 +565,7 @@ extern "C" int udaseg_bn_apply_bf16(const void* y, const double* sums, const flo
   UDASEG_CHECK_ARG(y && sums && gamma && beta && z, "bn_apply_bf16: NULL pointer");
   const int64_t n8 = pixels * (c / 8);
   const StreamShape s = stream_shape(n8, c / 8, 2048, apply_per_thread());
-  static int kid_bn_apply_bf16_kernel = -1;
+  static std::atomic<int> kid_bn_apply_bf16_kernel{-1};
   KTimer kt_bn_apply_bf16_kernel(&kid_bn_apply_bf16_kernel, "bn_apply_bf16_kernel", as_stream(stream), (double)pixels * c * 2.0 * (residual ? 3.0 : 2.0));
   hipLaunchKernelGGL(bn_apply_bf16_kernel, dim3(s.grid), dim3(s.bs), (size_t)2 * c * sizeof(float), as_stream(stream),
                      (const f32x4*)y, sums, gamma, beta, (const f32x4*)residual, (f32x4*)z, n8, s.c4, pixels, eps, momentum,
@@ -580,7 +580,7 @@ extern "C" int udaseg_bn_stats_bf16(const void* y, int64_t pixels, int c, double
   UDASEG_CHECK_ARG(y && sums, "bn_stats_bf16: NULL pointer");
   const int64_t n8 = pixels * (c / 8);
   const StreamShape s = stream_shape(n8, c / 8, reduce_max_blocks());
-  static int kid_bn_stats_bf16_kernel = -1;
+  static std::atomic<int> kid_bn_stats_bf16_kernel{-1};
   KTimer kt_bn_stats_bf16_kernel(&kid_bn_stats_bf16_kernel, "bn_stats_bf16_kernel", as_stream(stream), (double)pixels * c * 2.0);
   hipLaunchKernelGGL(bn_stats_bf16_kernel, dim3(s.grid), dim3(s.bs), 0, as_stream(stream), (const f32x4*)y, n8, s.c4, sums);
   UDASEG_LAUNCH_CHECK("bn_stats_bf16 launch");
@@ -595,7 +595,7 @@ extern "C" int udaseg_bn_bwd_reduce_bf16(const void* dz, const void* z, const vo
   UDASEG_CHECK_ARG(dz && y && save_mean && save_rstd && bsums && (act == UDASEG_ACT_NONE || z), "bn_bwd_reduce_bf16: NULL pointer");
   const int64_t n8 = pixels * (c / 8);
   const StreamShape s = stream_shape(n8, c / 8, reduce_max_blocks());
-  static int kid_bn_bwd_reduce_bf16_kernel = -1;
+  static std::atomic<int> kid_bn_bwd_reduce_bf16_kernel{-1};
   KTimer kt_bn_bwd_reduce_bf16_kernel(&kid_bn_bwd_reduce_bf16_kernel, "bn_bwd_reduce_bf16_kernel", as_stream(stream), (double)pixels * c * 2.0 * (act != UDASEG_ACT_NONE ? 3.0 : 2.0));
   hipLaunchKernelGGL(bn_bwd_reduce_bf16_kernel, dim3(s.grid), dim3(s.bs), 0, as_stream(stream), (const f32x4*)dz,
                      (const f32x4*)z, (const f32x4*)y, save_mean, save_rstd, n8, s.c4, bsums, act, slope);
@@ -614,7 +614,7 @@ extern "C" int udaseg_bn_bwd_apply_bf16(const void* dz, const void* z, const voi
   UDASEG_CHECK_ARG((size_t)5 * c * sizeof(float) <= 65536, "bn_bwd_apply_bf16: too many channels");
   const int64_t n8 = pixels * (c / 8);
   const StreamShape s = stream_shape(n8, c / 8, 2048, apply_per_thread());
-  static int kid_bwa = -1;
+  static std::atomic<int> kid_bwa{-1};
   KTimer kt_bwa(&kid_bwa, "bn_bwd_apply_bf16_kernel", as_stream(stream), (double)pixels * c * 2.0 * ((act != UDASEG_ACT_NONE ? 4.0 : 3.0) + (dres ? 1.0 : 0.0)));
   hipLaunchKernelGGL(bn_bwd_apply_bf16_kernel, dim3(s.grid), dim3(s.bs), (size_t)5 * c * sizeof(float), as_stream(stream),
                      (const f32x4*)dz, (const f32x4*)z, (const f32x4*)y, save_mean, save_rstd, gamma, bsums, (f32x4*)dy,
@@ -635,7 +635,7 @@ extern "C" int udaseg_bn_bwd_apply_recompute_bf16(const void* dz, const void* y,
   UDASEG_CHECK_ARG((size_t)7 * c * sizeof(float) <= 65536, "bn_bwd_apply_recompute_bf16: too many channels");
   const int64_t n8 = pixels * (c / 8);
   const StreamShape s = stream_shape(n8, c / 8, 2048, apply_per_thread());
-  static int kid_bwr = -1;
+  static std::atomic<int> kid_bwr{-1};
   KTimer kt_bwr(&kid_bwr, "bn_bwd_apply_bf16_kernel", as_stream(stream), (double)pixels * c * 2.0 * 3.0);
   hipLaunchKernelGGL(bn_bwd_apply_bf16_kernel, dim3(s.grid), dim3(s.bs), (size_t)7 * c * sizeof(float), as_stream(stream),
                      (const f32x4*)dz, (const f32x4*)nullptr, (const f32x4*)y, save_mean, save_rstd, gamma, bsums, (f32x4*)dy,

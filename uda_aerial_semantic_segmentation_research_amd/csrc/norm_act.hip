@@ -357,7 +357,7 @@ extern "C" int udaseg_bn_apply(const float* y, const double* sums, const float* 
   UDASEG_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "bn_apply: running_mean/var must come together");
   const int64_t n4 = pixels * (c / 4);
   const StreamShape s = stream_shape(n4, c / 4, 2048, apply_per_thread());
-  static int kid_ba = -1;
+  static std::atomic<int> kid_ba{-1};
   KTimer kt_ba(&kid_ba, "bn_apply_kernel", as_stream(stream), (double)pixels * c * 4.0 * (residual ? 3.0 : 2.0));
   hipLaunchKernelGGL(bn_apply_kernel, dim3(s.grid), dim3(s.bs), (size_t)2 * s.c4 * sizeof(float4), as_stream(stream), (const f32x4*)y, sums, gamma, beta,
                      (const f32x4*)residual, (f32x4*)z, n4, s.c4, pixels, eps, momentum, running_mean, running_var,
@@ -390,7 +390,7 @@ extern "C" int udaseg_bn_bwd_reduce(const float* dz, const float* z, const float
                    "bn_bwd_reduce: an activation follows the norm: pass z, or gamma and beta to re-evaluate its argument");
   const int64_t n4 = pixels * (c / 4);
   const StreamShape s = stream_shape(n4, c / 4, reduce_max_blocks());
-  static int kid_br = -1;
+  static std::atomic<int> kid_br{-1};
   KTimer kt_br(&kid_br, "bn_bwd_reduce_kernel", as_stream(stream), (double)pixels * c * 4.0 * (z ? 3.0 : 2.0));
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(s.grid), dim3(s.bs), 0, as_stream(stream), (const f32x4*)dz, (const f32x4*)z,
                      (const f32x4*)y, save_mean, save_rstd, gamma, beta, n4, s.c4, bsums, act, slope);
@@ -410,7 +410,7 @@ extern "C" int udaseg_bn_bwd_apply(const float* dz, const float* z, const float*
                    "bn_bwd_apply: an activation follows the norm: pass z, or beta to re-evaluate its argument");
   const int64_t n4 = pixels * (c / 4);
   const StreamShape s = stream_shape(n4, c / 4, 2048, apply_per_thread());
-  static int kid_bw = -1;
+  static std::atomic<int> kid_bw{-1};
   KTimer kt_bw(&kid_bw, "bn_bwd_apply_kernel", as_stream(stream), (double)pixels * c * 4.0 * ((z ? 4.0 : 3.0) + (dres ? 1.0 : 0.0)));
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(s.grid), dim3(s.bs), (size_t)6 * s.c4 * sizeof(float4), as_stream(stream), (const f32x4*)dz, (const f32x4*)z,
                      (const f32x4*)y, save_mean, save_rstd, gamma, beta, bsums, (f32x4*)dy, (f32x4*)dres, dgamma, dbeta, n4, s.c4,

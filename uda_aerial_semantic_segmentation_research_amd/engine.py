@@ -45,6 +45,7 @@ USE_F32_SPLIT = os.environ.get("UDASEG_F32_SPLIT", "1") != "0"
 # half is a plain 3x3 convolution of its own).  UDASEG_UP_PHASE=0: the nine-tap gather over the virtual concatenation (A/B; tests
 # flip the module attribute to cross-check)
 USE_UP_PHASE = os.environ.get("UDASEG_UP_PHASE", "1") != "0"
+USE_UP_PHASE_WGRAD = os.environ.get("UDASEG_UP_PHASE_WGRAD", "1") != "0"     # ... and the weight gradient (conv_wgrad_up_kernel)
 
 
 # bf16 storage: BatchNorm + activation of a layer whose ONLY consumer is a convolution on the bf16-first kernels is not written at
@@ -801,6 +802,20 @@ class Plan:
         if self.side_stream is not None:
             self.side_stream.wait_stream(self.main_stream)      # zeroed gradient arena is visible to the side stream
 
+    def _wgrad_up_ok(self, conv, d, x):
+        """May this fused decoder input's weight gradient run in the phase form?  (fp32 split kernels on, both halves served.)"""
+        if self.bf16 or not (USE_UP_PHASE and USE_UP_PHASE_WGRAD and self._wgrad_halo and USE_F32_SPLIT) or isinstance(x.a, LazyAct):
+            return False
+        cache = self.net.__dict__.setdefault("_wgup_cache", {})
+        key = (id(conv), d.n, d.hi, d.wi, d.ci, d.co, x.a.shape[-1])
+        v = cache.get(key)
+        if v is None:
+            v = K.conv2d_wgrad_up_ok(d, x.a.shape[-1])
+            if v and x.skip is not None:
+                v = K.conv2d_wgrad_halo_ok(K.conv_desc(d.n, d.hi, d.wi, x.skip.shape[-1], d.co, 3, 1, 1), f32=True)
+            cache[key] = v
+        return v
+
     def packed_wt(self, conv):
         o = self.net._wt_off[id(conv)]
         n = conv.cout_p * conv.k * conv.k * conv.cin_p
@@ -832,6 +847,12 @@ class Plan:
             if isinstance(x.a, LazyAct):
                 assert x.skip is None
                 K.conv2d_wgrad_bnin(d, x.a.y, x.a.scale, x.a.shift, x.a.act, x.a.slope, dy, gw, True, wst, up=True)
+            elif self._wgrad_up_ok(conv, d, x):
+                # phase form: 16 phase-tap correlations at a's resolution for the up-sampled half, the skip half as a slice
+                K.conv2d_wgrad_up(d, x.a, dy, gw, st=wst)
+                if x.skip is not None:
+                    ds = K.conv_desc(d.n, d.hi, d.wi, x.skip.shape[-1], d.co, 3, 1, 1)
+                    K.conv2d_wgrad_halo_slice(ds, x.skip, dy, gw, x.a.shape[-1], st=wst)
             elif self._wgrad_halo and x.skip is not None and K.conv2d_wgrad_halo_ok(d, x.a.shape[-1], f32=not self.bf16):
                 K.conv2d_wgrad_halo(d, x.a, x.skip, dy, gw, up=True, st=wst)      # both sources in one launch
             else:

@@ -265,6 +265,21 @@ def conv2d_dgrad_up(d, dy, up_ca, wfrag_up_t, da, accumulate=False, st=None):
     check(ops.udaseg_conv2d_dgrad_up_f32x3(d, dy, up_ca, wfrag_up_t, da, int(accumulate), st), "conv2d_dgrad_up_f32x3")
 
 
+def conv2d_wgrad_up_ok(d, up_ca):
+    return bool(ops.udaseg_conv2d_wgrad_up_f32x3_ok(d, up_ca))
+
+
+def conv2d_wgrad_up(d, a, dy, dw, st=None):
+    """dW[..., :ca] += weight gradient of conv3x3(nearest_x2(a)) in the phase form (16 phase taps at a's resolution); d: the whole
+    decoder conv1, dW its [co][3][3][ci] gradient."""
+    check(ops.udaseg_conv2d_wgrad_up_f32x3(d, a, a.shape[-1], dy, dw, st), "conv2d_wgrad_up_f32x3")
+
+
+def conv2d_wgrad_halo_slice(d_slice, x, dy, dw, c_off, st=None):
+    """dW[..., c_off:c_off + x channels] += halo-resident weight gradient of the slice (d_slice: the slice as its own convolution)."""
+    check(ops.udaseg_conv2d_wgrad_halo_slice_f32x3(d_slice, x, dy, dw, dw.shape[-1], c_off, st), "conv2d_wgrad_halo_slice_f32x3")
+
+
 def conv_frag_ok(d, dgrad=False, up_ca=0, f32=False):
     if f32:
         return bool(ops.udaseg_conv_f32x3_ok(d, int(dgrad), up_ca))
