@@ -67,22 +67,28 @@ def synthetic(n, h, w, classes, seed, device):
     return x.to(device), y.to(device)
 
 
-def pmc_traffic(kernel, prefer=None):
+def pmc_traffic(kernel, prefer=None, run_symbols=None):
     """(HBM-side bytes per launch of `kernel`, source file) from the newest committed PMC reduction (rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE in separate passes, corrected as MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py).  The PMC
     passes cannot run inside this script (counter collection needs its own rocprofv3 process): the value is a committed
-    measurement of the same kernel symbol, (None, None) when no committed file knows the symbol."""
+    measurement of the same kernel symbol, (None, None) when no committed file knows the symbol.
+    run_symbols: the convolution symbols THIS run launched -- a file collected on another build (one whose kernel list does not
+    hold every symbol of the run that makes up >= 2 % of the conv time) is refused: its numbers describe other kernels."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")), reverse=True)
     if prefer:      # the same symbol runs other shapes in another configuration: take the file collected on THIS workload first
         files.sort(key=lambda f: prefer not in os.path.basename(f))
     for f in files:
         try:
-            k = json.load(open(f))["kernels"].get(kernel)
+            ks = json.load(open(f))["kernels"]
         except Exception:
             continue
-        if k:
-            return k["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
+        k = ks.get(kernel)
+        if not k:
+            continue
+        if run_symbols and any(sym not in ks for sym in run_symbols):
+            continue
+        return k["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
     return None, None
 
 
@@ -109,6 +115,62 @@ def host_cores():
         except (OSError, ValueError, IndexError):
             continue
     return n
+
+
+def _cpulist(txt):
+    out = []
+    for part in txt.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out.extend(range(int(a), int(b or a) + 1))
+    return out
+
+
+def pin_to_gpu_numa_node(device_index, local_rank, local_world):
+    """N > 1: each rank's launcher thread (Python + ctypes + hipLaunchKernel: ~4 ms of host time per 8 ms step) runs on cores of ITS
+    GPU's NUMA node -- the node's allowed cores are dealt out among the ranks whose GPUs sit on that node, so eight launchers do not
+    pile onto the same cores or launch across the socket link.  The PCI address comes from torch.cuda.get_device_properties (no
+    context is created); without NUMA information the allowed cores are split evenly among the local ranks.  Returns a dict for the
+    JSON line ({"cores": n, "numa_node": k | None}) or None when pinning is not possible (no sched_setaffinity)."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return None
+    node, cores = None, None
+    try:
+        pr = torch.cuda.get_device_properties(device_index)
+        bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+        if node >= 0:
+            on_node = [c for c in _cpulist(open(f"/sys/devices/system/node/node{node}/cpulist").read()) if c in allowed]
+            # ranks sharing this node: those whose device has the same numa_node
+            peers = []
+            for r in range(local_world):
+                try:
+                    q = torch.cuda.get_device_properties(r)
+                    b2 = f"{q.pci_domain_id:04x}:{q.pci_bus_id:02x}:{q.pci_device_id:02x}.0"
+                    if int(open(f"/sys/bus/pci/devices/{b2}/numa_node").read()) == node:
+                        peers.append(r)
+                except Exception:
+                    peers.append(r)
+            if on_node and local_rank in peers:
+                k, m = peers.index(local_rank), len(peers)
+                per = max(1, len(on_node) // m)
+                cores = on_node[k * per:(k + 1) * per] or on_node
+        else:
+            node = None
+    except Exception:
+        node = None
+    if not cores:
+        per = max(1, len(allowed) // max(local_world, 1))
+        cores = allowed[local_rank * per:(local_rank + 1) * per] or allowed
+    try:
+        os.sched_setaffinity(0, cores)
+        torch.set_num_threads(max(1, min(len(cores), 4)))
+    except OSError:
+        return None
+    return {"cores": len(cores), "numa_node": node}
 
 
 def cpu_baseline(encoder, classes, hw, workload="segmentation", batch=8, warmups=2, timed=5, budget_s=30.0):
@@ -209,15 +271,33 @@ def build_leg(workload, encoder, dtype, batch, size, classes, dev, rank, world, 
     return step, model, trainer
 
 
+# every convolution kernel symbol of the library, classed EXPLICITLY by the matrix pipe it runs on (a heuristic on the
+# template-argument count mispriced launches silently whenever a kernel's template list changed; an unknown symbol now raises)
+SPLIT_PREFIXES = ("conv3x3_f32x3_kernel<", "conv3x3_f32x3_ws_kernel<", "conv_wgrad_h2_kernel<3,", "conv_wgrad_x3_kernel<",
+                  "conv_up_fwd_f32x3_kernel<", "conv_up_dgrad_f32x3_kernel<", "conv_wgrad_up_kernel<")
+NATIVE_PREFIXES = ("conv_wgrad_kernel<", "conv3x3_small_", "conv_wgrad_bf16_kernel<", "conv_wgrad_h2_kernel<1,", "conv_halo_bf16_kernel<",
+                   "conv1x1_stream_bf16_kernel<", "conv1x1_gemm_bf16_kernel", "conv_halo_s2", "conv_small", "conv2d_folded")
+# conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, BF16, UNI, UP[, X3]>: the three-term instantiations carry an EIGHTH argument "true"
+IGEMM_TEMPLATE_ARGS = (7, 8)
+
+
 def pipe_of(symbol, dtype):
     """(bf16-MFMA products per counted product, peak TFLOP/s of the pipe the kernel symbol runs on).  The fp32 three-term-split
-    kernels (conv3x3_f32x3*, conv_wgrad_h2_kernel<3, ...>, conv_wgrad_x3_kernel, conv_igemm_kernel<..., X3 = true>) evaluate every fp32 product as SIX bf16 MFMA
-    products: the pipe that bounds them is the bf16 one and the work it does is 6 x the algorithmic FLOPs."""
-    x3_igemm = symbol.startswith("conv_igemm_kernel<") and symbol.count(",") == 7 and symbol.rstrip(">").rstrip().endswith("true")
-    split = "f32x3" in symbol or symbol.startswith("conv_wgrad_h2_kernel<3,") or symbol.startswith("conv_wgrad_x3_kernel") or x3_igemm
-    if split:
+    kernels evaluate every fp32 product as SIX bf16 MFMA products: the pipe that bounds them is the bf16 one and the work it does
+    is 6 x the algorithmic FLOPs."""
+    native = (1, BF16_MFMA_PEAK_TFLOPS if dtype == "bf16" else FP32_MFMA_PEAK_TFLOPS)
+    if symbol.startswith("conv_igemm_kernel<"):
+        args = [a.strip() for a in symbol[symbol.index("<") + 1:symbol.rindex(">")].split(",")]
+        if args[0] == "*":                  # legacy lump of the bf16 instantiations (fixed table, unused since round 2)
+            return native
+        if len(args) not in IGEMM_TEMPLATE_ARGS or any(a not in ("true", "false") for a in args[4:]):
+            raise RuntimeError(f"bench.py: conv_igemm_kernel's template list changed ({symbol}): update IGEMM_TEMPLATE_ARGS / pipe_of")
+        return (F32X3_MFMA_PRODUCTS, BF16_MFMA_PEAK_TFLOPS) if (len(args) == 8 and args[7] == "true") else native
+    if symbol.startswith(SPLIT_PREFIXES):
         return F32X3_MFMA_PRODUCTS, BF16_MFMA_PEAK_TFLOPS
-    return 1, (BF16_MFMA_PEAK_TFLOPS if dtype == "bf16" else FP32_MFMA_PEAK_TFLOPS)
+    if symbol.startswith(NATIVE_PREFIXES):
+        return native
+    raise RuntimeError(f"bench.py: convolution kernel symbol {symbol!r} is not classed by matrix pipe (SPLIT_PREFIXES / NATIVE_PREFIXES)")
 
 
 def percentile(v, q):
@@ -350,7 +430,8 @@ def roofline_leg(step, model, trainer, dtype, psteps=3, layer_table=False, pmc_t
     achieved = algorithmic * mult
     # pipe-relative utilisation of the whole single-stream conv time: every kernel's pipe work against ITS pipe's dense peak
     pipe_ms = sum(k[2] * pipe_of(k[0], dtype)[0] / (pipe_of(k[0], dtype)[1] * 1e12) * 1e3 for k in kern) / psteps
-    traffic, traffic_src = pmc_traffic(dom[0], pmc_tag)
+    conv_total = max(sum(k[1] for k in kern), 1e-9)
+    traffic, traffic_src = pmc_traffic(dom[0], pmc_tag, run_symbols=[k[0] for k in kern if k[1] >= 0.02 * conv_total])
     return {"bound": "mfma", "kernel": dom[0], "achieved": round(achieved, 2), "peak": peak,
             "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
             "algorithmic_tflops": round(algorithmic, 2),
@@ -463,6 +544,8 @@ def main():
     share = os.environ.get("UDASEG_BENCH_SHARE_GPU", "0") == "1"
     backend = os.environ.get("UDASEG_BENCH_BACKEND", "nccl")
     local = 0 if share else local
+    pinned = pin_to_gpu_numa_node(local, int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))) \
+        if world > 1 else None
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     rehearse = os.environ.get("UDASEG_DDP_REHEARSE", "0") in ("1", "2", "3")   # run the N>1 code path (NCCL, side stream) at world 1
@@ -497,11 +580,21 @@ def main():
                      "images_per_s": round(args.batch * n_sus / ds, 2)}
 
     roofline = None
+    store = dist.distributed_c10d._get_default_store() if (world > 1 and dist.is_initialized()) else None
     if not args.no_roofline and rank == 0:
-        # only rank 0 runs this leg (the other ranks are already at the barrier below)
+        # only rank 0 runs this leg.  The other ranks wait on the HOST (a key of the rendezvous store), not inside a collective: an
+        # NCCL barrier would park a spinning kernel on seven GPUs for the seconds this takes
         tag = "cfg3" if args.workload == "adversarial" else ("cfg5" if args.encoder == "resnet50" else "fp32")
-        roofline = roofline_leg(step, model, trainer, args.dtype, layer_table=args.layer_table, pmc_tag=tag)
+        try:
+            roofline = roofline_leg(step, model, trainer, args.dtype, layer_table=args.layer_table, pmc_tag=tag)
+        finally:
+            if store is not None:
+                store.set("udaseg_bench_roofline_done", "1")
+    elif store is not None and not args.no_roofline:
+        import datetime
+        store.wait(["udaseg_bench_roofline_done"], datetime.timedelta(seconds=600))
     if world > 1:
+        torch.cuda.synchronize()
         dist.barrier()
 
     if rank == 0:
@@ -519,6 +612,8 @@ def main():
                                    f"batch {args.batch}x3x{args.size}x{args.size} per GPU, {args.classes} classes, random init",
                        "global_batch": args.batch * world, "image": f"{args.size}x{args.size}", "parallelism": f"dp{world}",
                        "final_loss": round(final_loss, 5),
+                       "host_cores_per_rank": (pinned or {}).get("cores") if world > 1 else host_cores(),
+                       "launcher_numa_node": (pinned or {}).get("numa_node") if world > 1 else None,
                        "arithmetic": ARITHMETIC_FP32 if args.dtype == "fp32" else
                        "bf16 storage of activations / weight copies, bf16 MFMA with fp32 accumulation, fp32 master weights, "
                        "statistics, gradients and optimizer state",
@@ -548,11 +643,13 @@ def main():
                 also_leg("BASELINE cfg 5 (per-GPU work)", "segmentation", "resnet50", "bf16", 8, 768, args.classes, dev),
             ]
             out["also"] = also
-            # the driver's record keeps `config`: a compact copy of the three legs goes there too
-            out["config"]["also"] = {name: {"value": a["value"], "unit": a["unit"], "ms_per_step": a["ms_per_step"],
-                                            "dominant_kernel": a["roofline"]["kernel"], "frac": a["roofline"]["frac"],
-                                            "conv_pipe_util": a["conv_pipe_util"]}
-                                     for name, a in zip(("fp32_mfma_only", "cfg3", "cfg5"), also)}
+            # the driver's record keeps the SCALAR keys of `config` only (round 4's nested copy was dropped): one flat key per figure
+            for name, a in zip(("fp32_mfma_only", "cfg3", "cfg5"), also):
+                out["config"][f"{name}_images_per_s"] = a["value"]
+                out["config"][f"{name}_ms_per_step"] = a["ms_per_step"]
+                out["config"][f"{name}_frac"] = a["roofline"]["frac"]
+                out["config"][f"{name}_dominant_kernel"] = a["roofline"]["kernel"]
+                out["config"][f"{name}_conv_pipe_util"] = a["conv_pipe_util"]
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()

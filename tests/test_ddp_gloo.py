@@ -69,3 +69,57 @@ def test_bucket_ranges_short_tail_for_the_last_gradients():
     assert all(r[i][0] == r[i + 1][1] for i in range(len(r) - 1)) and sum(b - a for a, b in r) == total
     assert all(b - a <= big for a, b in r)
     assert bucket_ranges(100, 64, 1000) == [(0, 100)] and bucket_ranges(100, 64, 0) == [(36, 100), (0, 36)]
+
+
+# ---- world 8 with the REAL network's arena, offsets and bucket plan: what the driver's 8-GPU run does, on gloo
+def _worker8(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from uda_aerial_semantic_segmentation_research_amd.ddp import GradAllReducer
+    from uda_aerial_semantic_segmentation_research_amd.engine import ConvP
+    from uda_aerial_semantic_segmentation_research_amd.unet import Unet
+    net = Unet("resnet18", encoder_weights=None, in_channels=3, classes=23)        # CPU: the arena layout only, no kernel runs
+    total = net._arena.numel()
+    idx = net.entry_index()
+    # the offsets Unet._backward_plan reports, in its order: head, decoder blocks last to first, encoder blocks last to first, 0
+    offs = [idx[(id(net.segmentation_head[0]), "weight")][0]]
+    blocks = [b for st in net.encoder.stages() for b in st] + list(net.decoder.blocks)
+    for blk in reversed(blocks):
+        first = next(m for m in blk.modules() if isinstance(m, ConvP))
+        offs.append(idx[(id(first), "weight")][0])
+    offs.append(0)
+    red = GradAllReducer(net, bucket_bytes=32 << 20)                               # bench.py's plan: 32 MiB buckets, 4 MiB tail
+
+    class P:
+        pass
+    plan = P()
+    plan.garena = torch.full((total,), float(rank + 1))
+    launched_at = []
+    for o in offs:
+        net.grad_ready_hook(plan, o)
+        launched_at.append(len(red.launched))
+    red.finish()
+    mib = [round((b - a) * 4 / 2 ** 20) for a, b in red.launched]
+    ok = torch.all(plan.garena == (world + 1) / 2).item()                          # mean of 1..world, every element, exactly
+    ok = ok and red.launched[0][1] == total and red.launched[-1] == (0, (4 << 20) // 4) and mib == [32, 19, 4]
+    ok = ok and all(red.launched[i][0] == red.launched[i + 1][1] for i in range(len(red.launched) - 1))
+    ok = ok and offs == sorted(offs, reverse=True) and launched_at[-1] == 3
+    # the 32 MiB bucket leaves while the encoder's backward still runs (before the report of the first encoder stage)
+    first_enc = offs.index(idx[(id(next(m for m in blocks[0].modules() if isinstance(m, ConvP))), "weight")][0])
+    ok = ok and launched_at[first_enc - 1] >= 1
+    ret[rank] = (bool(ok), mib, total)
+    dist.destroy_process_group()
+
+
+def test_reducer_world8_gloo_real_arena_and_bucket_plan():
+    """Eight gloo ranks, the r18-Unet's real 14.3 M-element gradient arena, the offsets its backward plan reports and the 32 / 19 /
+    4 MiB bucket plan of bench.py --gpus 8: buckets tile the arena back to front, leave as soon as complete, every element ends at
+    the mean over ranks."""
+    world = 8
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker8, args=(world, 29531, ret), nprocs=world, join=True)
+    assert all(ret[r][0] for r in range(world)), dict(ret)
+    assert ret[0][2] == 14335040

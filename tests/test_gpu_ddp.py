@@ -52,3 +52,27 @@ def test_two_ranks_real_unet(tmp_path):
         assert res["weights_equal_after_steps"] and res["weights_moved"]
         assert res["bn_buffers_local"]
         assert res["double_backward_raises"]
+
+
+def test_bench_n_gt_1_control_flow_four_ranks_one_gpu():
+    """bench.py's N > 1 path end to end as the driver launches it (torch.distributed.run, one JSON line from rank 0): four ranks
+    sharing device 0 over gloo (UDASEG_BENCH_SHARE_GPU / UDASEG_BENCH_BACKEND: this pool hands out one-GPU boxes and allows six
+    GPU processes; the real run is one rank per GPU over RCCL).  Asserts what the driver parses: n_gpus, global batch, weak
+    scaling, a whole-job value, the roofline leg run by rank 0 while the others wait on the rendezvous store (host side), and that
+    every rank exits cleanly."""
+    from uda_aerial_semantic_segmentation_research_amd import _lib
+    _lib.require_gpu()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", UDASEG_BENCH_SHARE_GPU="1", UDASEG_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1"]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 4 and out["config"]["global_batch"] == 32 and out["scaling"] == "weak" and out["steps"] == 2
+    assert out["metric"] == "training images/sec at 512x512" and out["value"] > 0
+    assert abs(out["value"] - 32 * 2 / (out["ms_per_step"] * 2e-3)) <= 0.01 * out["value"]      # whole-job images / max-over-ranks time
+    assert out["roofline"] is not None and out["roofline"]["frac"] > 0
+    assert out["config"]["host_cores_per_rank"] >= 1
+    assert "cpu_baseline" not in out                       # N = 1 only

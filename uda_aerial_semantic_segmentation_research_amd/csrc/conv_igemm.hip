@@ -851,7 +851,7 @@ static int launch_cfg_t(const IgemmArgs& a, hipStream_t s) {
   constexpr int tile_id = (BM == 128 && BN == 128) ? 0 : (BM == 128 && BN == 64) ? 1 : (BM == 64) ? 2 : 3;
   int kid = UP ? 20 + tile_id : (UNI ? 14 + tile_id : tile_id);
   if constexpr (BF || X3) {      // bf16 / X3 instantiations report under their own rocprofv3 symbol (round 2 lumped them into one id)
-    static int bf_kid = -1;
+    static std::atomic<int> bf_kid{-1};
     if (bf_kid < 0) {
       char nm[96];
       snprintf(nm, sizeof(nm), "conv_igemm_kernel<%d, %d, %d, %d, %s, %s, %s%s>", BM, BN, WAVES_M, WAVES_N, BF ? "true" : "false",

@@ -726,7 +726,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_up_kernel(const WgradUpArgs
   else wgrad_up_role<C, 1>(a, h2smem, tid, lane, wave);
 }
 
-// 0: not served; 1: 64 x 64 channel blocks, 1 x 32 a-pixel tiles; 2: 64 x 64, 2 x 16 (16-pixel-wide a); 3: 32 produced x 64 gathered
+// 0: not served; 1 / 2: 64 x 64 channel blocks, 2 x 16 a-pixel tiles (a 1 x 32 tile form for wide images was measured and dropped: its
+// three-row halo for one row of pixels triples the staged x bytes); 3: 32 produced x 64 gathered channels, 1 x 32 tiles
 static int h2up_config(const udaseg_conv_desc* d, int up_ca) {
   if (!d || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1) return 0;
   if (d->n <= 0 || d->hi < 2 || d->wi < 2 || d->ho != d->hi || d->wo != d->wi || d->hi % 2 || d->wi % 2) return 0;
@@ -799,19 +800,17 @@ extern "C" int udaseg_conv2d_wgrad_up_f32x3(const udaseg_conv_desc* d, const flo
     set_error("conv2d_wgrad_up_f32x3: geometry not supported (ask udaseg_conv2d_wgrad_up_f32x3_ok first)");
     return UDASEG_E_UNSUPPORTED;
   }
-  int target = g_wgrad_up_blocks > 0 ? g_wgrad_up_blocks : 128;
-  static int env_cfg = -1, env_blocks = -1;      // TEMPORARY tuning aids
-  if (env_cfg < 0) { env_cfg = h2_env("UDASEG_WGUP_CFG", 0); env_blocks = h2_env("UDASEG_WGUP_BLOCKS", 0); }
-  if (env_blocks > 0 && g_wgrad_up_blocks == 0) target = env_blocks;
+  // blocks per launch: few and long-lived like the nine-tap kernel.  Same-box sweep inside the overlapped step (images/s, phase weight
+  // gradient off 983.7 / 996.7): 2 x 16 tiles at 64 / 128 / 256 blocks 995.2 / 990.1-994.4 / 969.7, 1 x 32 tiles at 128 / 256 blocks
+  // 984.8 / 966.1 (profiles/r05_up_phase.txt) -- the 16-pixel tile everywhere, 96 blocks
+  const int target = g_wgrad_up_blocks > 0 ? g_wgrad_up_blocks : 96;
   hipStream_t st = as_stream(stream);
   udaseg_conv_desc dd = *d;
   dd.ci = up_ca;
   const double flops = 2.0 * (double)d->n * (d->hi / 2) * (d->wi / 2) * d->co * 16.0 * up_ca;
   prof_begin(1, st);
   int rc;
-  if (cfg == 1 && env_cfg == 2) rc = launch_h2up_t<2, 2, 2, 1>(d, a, up_ca, dy, dw, st, target);
-  else if (cfg == 1) rc = launch_h2up_t<2, 2, 1, 2>(d, a, up_ca, dy, dw, st, target);
-  else if (cfg == 2) rc = launch_h2up_t<2, 2, 2, 1>(d, a, up_ca, dy, dw, st, target);
+  if (cfg == 1 || cfg == 2) rc = launch_h2up_t<2, 2, 2, 1>(d, a, up_ca, dy, dw, st, target);
   else rc = launch_h2up_t<1, 2, 1, 2>(d, a, up_ca, dy, dw, st, target);
   prof_end(1, st, flops, 2, &dd);
   return rc;

@@ -45,7 +45,12 @@ USE_F32_SPLIT = os.environ.get("UDASEG_F32_SPLIT", "1") != "0"
 # half is a plain 3x3 convolution of its own).  UDASEG_UP_PHASE=0: the nine-tap gather over the virtual concatenation (A/B; tests
 # flip the module attribute to cross-check)
 USE_UP_PHASE = os.environ.get("UDASEG_UP_PHASE", "1") != "0"
-USE_UP_PHASE_WGRAD = os.environ.get("UDASEG_UP_PHASE_WGRAD", "1") != "0"     # ... and the weight gradient (conv_wgrad_up_kernel)
+# ... and the weight gradient (conv_wgrad_up_kernel: 16 phase-tap correlations at the half resolution).  Built, graded against f64
+# (tests/test_gpu_up.py) and OFF by default: inside the overlapped step it is neutral (same box, images/s: off 983.7 / 996.7, on
+# 984.8 - 995.2 over two tile shapes and three block counts, profiles/r05_up_phase.txt) -- it does 4/9 of the nine-tap kernel's matrix
+# work but stages the same bytes per pixel for it, and the weight gradients share the chip with the main stream's chain, so what
+# counts is CU-time, not FLOPs.  UDASEG_UP_PHASE_WGRAD=1 switches it on.
+USE_UP_PHASE_WGRAD = os.environ.get("UDASEG_UP_PHASE_WGRAD", "0") == "1"
 
 
 # bf16 storage: BatchNorm + activation of a layer whose ONLY consumer is a convolution on the bf16-first kernels is not written at
