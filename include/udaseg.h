@@ -495,9 +495,12 @@ int udaseg_pack_up_batched_f32x3(const float* w32, const float* wt32, void* pack
  * stats != NULL: BatchNorm statistics of y AFTER the accumulation ([R][2][co] f64, accumulated) */
 int udaseg_conv2d_fwd_up_f32x3(const udaseg_conv_desc* d, const float* a, int up_ca, const void* wfrag_up, float* y, int accumulate,
                                double* stats, void* stream);
-/* da[n][hi/2][wi/2][up_ca] (+)= gradient of `a` through conv3x3(nearest_x2(a)) given dy[n][hi][wi][co] (co a multiple of 8) */
+/* da[n][hi/2][wi/2][up_ca] (+)= gradient of `a` through conv3x3(nearest_x2(a)) given dy[n][hi][wi][co] (co a multiple of 8).
+ * prev_y != NULL (the conv output [n][hi/2][wi/2][up_ca] of the conv + BatchNorm + activation layer that produced a, when this
+ * convolution is a's only consumer): also that layer's two BatchNorm-backward sums, as udaseg_conv2d_dgrad_f32x3 */
 int udaseg_conv2d_dgrad_up_f32x3(const udaseg_conv_desc* d, const float* dy, int up_ca, const void* wfrag_up_t, float* da,
-                                 int accumulate, void* stream);
+                                 const float* prev_y, const float* save_mean, const float* save_rstd, const float* gamma,
+                                 const float* beta, int bn_act, float bn_slope, double* bsums, int accumulate, void* stream);
 /* tests / tuning: one tile configuration (1..8, csrc/conv_up_f32x3.hip up_choice) for every launch; 0 = the heuristic again */
 int udaseg_up_f32x3_force_config(int cfg);
 /* The weight gradient in the same form (csrc/conv_wgrad_halo2.hip, conv_wgrad_up_kernel): the 16 phase-tap correlations

@@ -251,3 +251,38 @@ def test_up_phase_wgrad_fp32_grade(K, case, blocks):
     for ky in range(3):
         for kx in range(3):
             assert err2(got[:, ky, kx, :ca], ref[:, ky, kx, :ca]) <= 2e-6, (ky, kx)
+
+
+@pytest.mark.parametrize("n,h,w,ca,co,act,slope", [(2, 32, 64, 64, 64, 1, 0.0), (1, 20, 36, 32, 16, 1, 0.2), (8, 64, 64, 128, 64, 1, 0.0),
+                                                    (2, 32, 32, 256, 128, 1, 0.0)])
+def test_up_phase_dgrad_with_bn_backward_reductions(K, n, h, w, ca, co, act, slope):
+    """The phase data gradient's epilogue also makes the two BatchNorm-backward sums of the layer that produced `a` (its only consumer
+    is this convolution, and da is complete here -- no 2x2 sum-pool follows): the gradient is untouched, the sums equal the
+    definition in f64 on the stored gradient."""
+    g = torch.Generator().manual_seed(n * 1000 + h + ca)
+    R = K.bn_replicas()
+    wt = torch.randn(co, ca, 3, 3, generator=g) / math.sqrt(ca * 9)
+    dy = torch.randn(n, co, h, w, generator=g)
+    prev_y = torch.randn(n, h // 2, w // 2, ca, generator=g)
+    mean, var = prev_y.reshape(-1, ca).mean(0), prev_y.reshape(-1, ca).var(0, unbiased=False)
+    rstd = (var + 1e-5).rsqrt()
+    gamma, beta = torch.rand(ca, generator=g) + 0.5, torch.randn(ca, generator=g) * 0.3
+    d = K.conv_desc(n, h, w, ca, co, 3, 1, 1)
+    P = pack_up(K, wt, ca)
+    dyd = nhwc(dy)
+    da = torch.full((n, h // 2, w // 2, ca), float("nan"), device="cuda", dtype=f32)
+    bs = torch.zeros(R * 2 * ca, dtype=f64, device="cuda")
+    K.conv2d_dgrad_up(d, dyd, ca, P["up_bwd"], da, bn=(prev_y.cuda(), mean.cuda(), rstd.cuda(), gamma.cuda(), beta.cuda(), act, slope, bs))
+    plain = torch.empty_like(da)
+    K.conv2d_dgrad_up(d, dyd, ca, P["up_bwd"], plain)
+    assert torch.equal(da, plain)
+    gz = da.cpu().double().reshape(-1, ca)
+    yy = prev_y.double().reshape(-1, ca)
+    sc = (gamma * rstd).double()
+    arg = yy * sc + (beta.double() - mean.double() * sc)
+    mask = torch.where(arg > 0, torch.ones_like(arg), torch.full_like(arg, slope))
+    gg = gz * mask
+    s1, s2 = gg.sum(0), (gg * (yy - mean.double()) * rstd.double()).sum(0)
+    tot = bs.view(R, 2, ca).sum(0).cpu()
+    assert ((tot[0] - s1).abs().max() / s1.abs().max()).item() <= 1e-5
+    assert ((tot[1] - s2).abs().max() / s2.abs().max()).item() <= 1e-5

@@ -57,12 +57,12 @@ for n, h, w, ca, cs, co in SHAPES:
     p9 = torch.empty(3 * K.frag_elems(co, ca, 3), device="cuda", dtype=bf)
     K.pack_frag_batched(w9, None, p9, torch.tensor([[0, 0, 0, co, ca, 3]], dtype=torch.int32, device="cuda"))
     us9 = timed(lambda: K.conv2d_fwd_frag(d9, a, None, p9, None, y, stats=st, up=True))
-    print(f"== {n}x{h}x{w} up {ca} (+ skip {cs}) -> {co}: nine-tap gather forward {us9:7.1f} us ({gf / us9 * 1e-3:6.1f} TF/s nine-tap-equivalent)")
+    print(f"== {n}x{h}x{w} up {ca} (+ skip {cs}) -> {co}: nine-tap gather forward {us9:7.1f} us ({gf / us9 * 1e3:6.1f} TF/s nine-tap-equivalent)")
     for cfg in cfgs:
         lib.udaseg_up_f32x3_force_config(cfg)
         uf = timed(lambda: K.conv2d_fwd_up(d, a, packed[:n_uf], y, accumulate=cs > 0, stats=st))
         ub = timed(lambda: K.conv2d_dgrad_up(d, dy, ca, packed[n_uf:], da))
-        print(f"   cfg {cfg}: forward {uf:7.1f} us ({gf / uf * 1e-3:6.1f} TF/s nine-tap-equivalent)   data gradient {ub:7.1f} us ({gf / ub * 1e-3:6.1f})")
+        print(f"   cfg {cfg}: forward {uf:7.1f} us ({gf / uf * 1e3:6.1f} TF/s nine-tap-equivalent)   data gradient {ub:7.1f} us ({gf / ub * 1e3:6.1f})")
     lib.udaseg_up_f32x3_force_config(0)
     uf = timed(lambda: K.conv2d_fwd_up(d, a, packed[:n_uf], y, accumulate=cs > 0, stats=st))
     ub = timed(lambda: K.conv2d_dgrad_up(d, dy, ca, packed[n_uf:], da))

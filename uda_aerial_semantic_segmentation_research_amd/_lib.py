@@ -139,7 +139,7 @@ SIGNATURES = {
     "udaseg_conv_up_f32x3_ok": (_I, [_D, _I]),
     "udaseg_pack_up_batched_f32x3": (_I, [_P, _P, _P, _P, _I, _P]),
     "udaseg_conv2d_fwd_up_f32x3": (_I, [_D, _P, _I, _P, _P, _I, _P, _P]),
-    "udaseg_conv2d_dgrad_up_f32x3": (_I, [_D, _P, _I, _P, _P, _I, _P]),
+    "udaseg_conv2d_dgrad_up_f32x3": (_I, [_D, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _F, _P, _I, _P]),
     "udaseg_up_f32x3_force_config": (_I, [_I]),
     "udaseg_conv2d_wgrad_up_f32x3_ok": (_I, [_D, _I]),
     "udaseg_conv2d_wgrad_up_f32x3": (_I, [_D, _P, _I, _P, _P, _P]),

@@ -120,7 +120,10 @@ OPERANDS = {
     "udaseg_conv2d_fwd_up_f32x3": [D, T("a", f32, _HALF + "*up_c"), I("up_c"), T("wfrag_up", bf16, "3*frag(co,up_c,4)"),
                                    T("y", f32, "Y"), I("accumulate"), T("stats", f64, "2*co*R", True), S],
     "udaseg_conv2d_dgrad_up_f32x3": [D, T("dy", f32, "Y"), I("up_c"), T("wfrag_up_t", bf16, "3*frag(up_c,co,4)"),
-                                     T("da", f32, _HALF + "*up_c"), I("accumulate"), S],
+                                     T("da", f32, _HALF + "*up_c"), T("prev_y", f32, _HALF + "*up_c", True),
+                                     T("save_mean", f32, "up_c", True), T("save_rstd", f32, "up_c", True), T("gamma", f32, "up_c", True),
+                                     T("beta", f32, "up_c", True), I("bn_act"), F("bn_slope"), T("bsums", f64, "2*up_c*R", True),
+                                     I("accumulate"), S],
     "udaseg_conv2d_wgrad_up_f32x3": [D, T("a", f32, _HALF + "*up_c"), I("up_c"), T("dy", f32, "Y"), T("dw", f32, "W"), S],
     "udaseg_conv2d_wgrad_halo_slice_f32x3": [D, T("x", f32, "X"), T("dy", f32, "Y"), T("dw", f32, "co*kh*kw*ldw_"), I("ldw_"),
                                              I("c_off"), S],

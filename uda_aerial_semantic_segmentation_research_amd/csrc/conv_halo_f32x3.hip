@@ -349,7 +349,13 @@ struct F3WsCfg {
   static constexpr int TH = WM * RPW * RL;
   static constexpr int NJ = RL * RPW + 2;                  // fragment start rows a wave reads per (dx) group
   static constexpr int HR = TH + 2, HWD = TW + 2;
-  static constexpr int PLANE = HR * HWD * 32;
+  // LDS pitch of a halo row, in pixels (32 bytes each).  16-pixel rows: a fragment spans TWO halo rows, and ds_read_b128 serves
+  // lanes {0-3, 12-15, 20-27} in one cycle -- columns 0-3 / 12-15 of row r with columns 4-11 of row r + 1: conflict-free only if the
+  // rows are a multiple of 256 bytes apart (24 pixels).  With the natural 18-pixel pitch (576 bytes = +4 slots of 16 bytes) columns
+  // 4-7 of row r + 1 landed on the banks of columns 0-1 / 6-7 of row r: PMC SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.24 on the
+  // r18 layer4 launches of round 4 (profiles/r04_pmc_sq.txt).
+  static constexpr int HWP = TW == 16 ? 24 : HWD;
+  static constexpr int PLANE = HR * HWP * 32;
   static constexpr int LDS_HALO = 3 * PLANE;
   static constexpr int NPIECE = HR * HWD * 2;
   static constexpr int NI = (NPIECE + NLD - 1) / NLD;
@@ -425,7 +431,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_f32x3_ws_kernel(const F3Args a
         voff[i] = ok ? (unsigned)((((img * H + iy) * W + ix) * cx + oct * 8) * 4) : 0x80000000u;
         voff2[i] = 0x80000000u;
       }
-      soffl[i] = (unsigned)(pix * 32 + ((oct ^ ((hx >> 3) & 1)) * 16));
+      soffl[i] = (unsigned)((hy * C::HWP + hx) * 32 + ((oct ^ ((hx >> 3) & 1)) * 16));
       if constexpr (XF) {
         if (ok && hy >= 1 && hy <= C::TH && hx >= 1 && hx <= C::TW) zmask |= 1u << i;       // the tile's own pixels (F3Args::z_out)
       }
@@ -571,7 +577,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_f32x3_ws_kernel(const F3Args a
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) {
       const int hx = lp % C::TW + dx;
-      poff[dx] = ((wm * RPW * C::RL + lp / C::TW) * C::HWD + hx) * 32 + ((lh ^ ((hx >> 3) & 1)) * 16);
+      poff[dx] = ((wm * RPW * C::RL + lp / C::TW) * C::HWP + hx) * 32 + ((lh ^ ((hx >> 3) & 1)) * 16);
     }
     const int wrd = (wn * 9) * 1024 + lane * 16;
     __syncthreads();                               // group 0 is staged
@@ -598,7 +604,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_f32x3_ws_kernel(const F3Args a
           if (s + 1 < C::NJ) {
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl)
-              pf[(s + 1) & 1][pl] = *reinterpret_cast<const u32x4*>(hb + pl * C::PLANE + poff[dx] + (s + 1) * C::HWD * 32);
+              pf[(s + 1) & 1][pl] = *reinterpret_cast<const u32x4*>(hb + pl * C::PLANE + poff[dx] + (s + 1) * C::HWP * 32);
           }
 #pragma unroll
           for (int ij = 2; ij >= 0; --ij)

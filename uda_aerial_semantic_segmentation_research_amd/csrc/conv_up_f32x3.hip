@@ -49,6 +49,15 @@ struct UpArgs {
   int ntx, nty, ncb, nk16;
   int q1, q3;           // groups [q1, q3) run on negated weights and a negated accumulator
   unsigned x_bytes, w_plane_bytes, y_bytes;
+  // data gradient: the conv output of the conv + BatchNorm + activation layer that PRODUCED a (a's only consumer is this convolution,
+  // so da is that activation's complete gradient) -> its two BatchNorm-backward sums into stats, as conv_halo_f32x3_epilogue.inc
+  const float* bnb_y;
+  const float* bnb_mean;
+  const float* bnb_rstd;
+  const float* bnb_gamma;
+  const float* bnb_beta;
+  int bnb_act;
+  float bnb_slope;
 };
 
 __host__ __device__ inline void up_negated_groups(int ng, int& q1, int& q3) {
@@ -66,7 +75,8 @@ struct UpCfg {
   static constexpr int TH = WM * RPW * RL;
   static constexpr int NJ = RL * RPW + 2;                  // fragment start rows per halo column offset
   static constexpr int HR = TH + 2, HWD = TW + 2;
-  static constexpr int PLANE = HR * HWD * 32;
+  static constexpr int HWP = TW == 16 ? 24 : HWD;          // LDS pitch of a halo row in pixels (conv_halo_f32x3.hip F3WsCfg::HWP)
+  static constexpr int PLANE = HR * HWP * 32;
   static constexpr int LDS_HALO = 3 * PLANE;
   static constexpr int NPIECE = HR * HWD * 2;
   static constexpr int NI = (NPIECE + NLD - 1) / NLD;
@@ -95,7 +105,7 @@ __device__ __forceinline__ void up_loader_role(const UpArgs& a, char* smem, char
     const bool ok = piece < C::NPIECE && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
     if (S2D) voff[i] = ok ? (unsigned)((((img * 2 * H + 2 * iy) * (2 * W) + 2 * ix) * a.ci + oct * 8) * 4) : 0x80000000u;
     else voff[i] = ok ? (unsigned)((((img * H + iy) * W + ix) * a.ci + oct * 8) * 4) : 0x80000000u;
-    soffl[i] = (unsigned)(pix * 32 + ((oct ^ ((hx >> 3) & 1)) * 16));
+    soffl[i] = (unsigned)((hy * C::HWP + hx) * 32 + ((oct ^ ((hx >> 3) & 1)) * 16));
   }
   __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wf), 0, (int)(3u * a.w_plane_bytes), 0x00020000);
@@ -227,7 +237,7 @@ __global__ __launch_bounds__(512, 1) void conv_up_fwd_f32x3_kernel(const UpArgs 
 #pragma unroll
   for (int ex = 0; ex < 3; ++ex) {
     const int hx = lp % C::TW + ex;
-    poff[ex] = ((wm * RPW * C::RL + lp / C::TW) * C::HWD + hx) * 32 + ((lh ^ ((hx >> 3) & 1)) * 16);
+    poff[ex] = ((wm * RPW * C::RL + lp / C::TW) * C::HWP + hx) * 32 + ((lh ^ ((hx >> 3) & 1)) * 16);
   }
   const int wrd = (wn * 4 * 3) * 1024 + lane * 16;
   __syncthreads();                                 // group 0 is staged
@@ -258,7 +268,7 @@ __global__ __launch_bounds__(512, 1) void conv_up_fwd_f32x3_kernel(const UpArgs 
         if (s + 1 < C::NJ) {
 #pragma unroll
           for (int pl = 0; pl < 3; ++pl)
-            pf[(s + 1) & 1][pl] = *reinterpret_cast<const u32x4*>(hb + pl * C::PLANE + poff[ex] + (s + 1) * C::HWD * 32);
+            pf[(s + 1) & 1][pl] = *reinterpret_cast<const u32x4*>(hb + pl * C::PLANE + poff[ex] + (s + 1) * C::HWP * 32);
         }
 #pragma unroll
         for (int ij = 2; ij >= 0; --ij)
@@ -384,6 +394,7 @@ __global__ __launch_bounds__(512, 1) void conv_up_dgrad_f32x3_kernel(const UpArg
 
   if (loader) {
     up_loader_role<C, true, 1>(a, smem, wlds, tid - 256, lane, mw, cb, img, y0, x0, nvc, nvc);
+    if (a.stats != nullptr) __syncthreads();       // the reduction of the BatchNorm-backward sums has one block barrier
     return;
   }
 
@@ -400,7 +411,7 @@ __global__ __launch_bounds__(512, 1) void conv_up_dgrad_f32x3_kernel(const UpArg
 #pragma unroll
   for (int ex = 0; ex < 3; ++ex) {
     const int hx = lp % C::TW + ex;
-    poff[ex] = ((wm * RPW * C::RL + lp / C::TW) * C::HWD + hx) * 32 + ((lh ^ ((hx >> 3) & 1)) * 16);
+    poff[ex] = ((wm * RPW * C::RL + lp / C::TW) * C::HWP + hx) * 32 + ((lh ^ ((hx >> 3) & 1)) * 16);
   }
   const int wrd = (wn * 4 * 3) * 1024 + lane * 16;
   __syncthreads();                                 // group 0 is staged
@@ -422,7 +433,7 @@ __global__ __launch_bounds__(512, 1) void conv_up_dgrad_f32x3_kernel(const UpArg
         for (int pl = 0; pl < 3; ++pl) bf[jy][pl] = *reinterpret_cast<const u32x4*>(wb + ((e * 2 + jy) * 3 + pl) * 1024);
       const int po = ex == 0 ? poff[0] : (ex == 1 ? poff[1] : poff[2]);
       const int ey0 = py ? 0 : 1;
-      const char* hrow = hb + po + ey0 * C::HWD * 32;        // the rows this phase reads start at halo row ey0
+      const char* hrow = hb + po + ey0 * C::HWP * 32;        // the rows this phase reads start at halo row ey0
       u32x4 pf[2][3];
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) pf[0][pl] = *reinterpret_cast<const u32x4*>(hrow + pl * C::PLANE);
@@ -432,7 +443,7 @@ __global__ __launch_bounds__(512, 1) void conv_up_dgrad_f32x3_kernel(const UpArg
         if (s + 1 < NS) {
 #pragma unroll
           for (int pl = 0; pl < 3; ++pl)
-            pf[(s + 1) & 1][pl] = *reinterpret_cast<const u32x4*>(hrow + pl * C::PLANE + (s + 1) * C::HWD * 32);
+            pf[(s + 1) & 1][pl] = *reinterpret_cast<const u32x4*>(hrow + pl * C::PLANE + (s + 1) * C::HWP * 32);
         }
 #pragma unroll
         for (int ij = 2; ij >= 0; --ij)
@@ -452,16 +463,32 @@ __global__ __launch_bounds__(512, 1) void conv_up_dgrad_f32x3_kernel(const UpArg
 
   const int cbase = nb * 32;
   __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)a.y_bytes, 0x00020000);
+  const bool want_bnb = a.stats != nullptr;
+  __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(want_bnb ? a.bnb_y : a.x), 0,
+                                                                  (int)(want_bnb ? a.y_bytes : 0u), 0x00020000);
+  float sA[16], sB[16];
 #pragma unroll
-  for (int r = 0; r < RPW; ++r) {
-    const int oy = y0 + (wm * RPW + r) * C::RL + lp / C::TW, ox = x0 + lp % C::TW;
-    const bool pv = wave_live && oy < H && ox < W;
-    const unsigned pixoff = (unsigned)((img * H + oy) * W + ox);
+  for (int v = 0; v < 16; ++v) sA[v] = sB[v] = 0.f;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int c0 = cbase + 8 * g + 4 * lh;
-      const bool cv = pv && c0 < a.co;
-      const unsigned off = cv ? (pixoff * (unsigned)a.co + (unsigned)c0) * 4u : 0x80000000u;
+  for (int g = 0; g < 4; ++g) {
+    const int c0 = cbase + 8 * g + 4 * lh;
+    const bool cok = wave_live && c0 < a.co;
+    f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = sc, mu = sc, rsd = sc;
+    if (want_bnb && cok) {
+      mu = *reinterpret_cast<const f32x4*>(a.bnb_mean + c0);
+      rsd = *reinterpret_cast<const f32x4*>(a.bnb_rstd + c0);
+      const f32x4 gm = *reinterpret_cast<const f32x4*>(a.bnb_gamma + c0), bt = *reinterpret_cast<const f32x4*>(a.bnb_beta + c0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        sc[e] = gm[e] * rsd[e];                     // as bn_apply forms them
+        sh[e] = bt[e] - mu[e] * sc[e];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      const int oy = y0 + (wm * RPW + r) * C::RL + lp / C::TW, ox = x0 + lp % C::TW;
+      const bool cv = cok && oy < H && ox < W;
+      const unsigned off = cv ? (((unsigned)((img * H + oy) * W + ox)) * (unsigned)a.co + (unsigned)c0) * 4u : 0x80000000u;
       float val[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) val[e] = acc[r][4 * g + e];
@@ -474,6 +501,48 @@ __global__ __launch_bounds__(512, 1) void conv_up_dgrad_f32x3_kernel(const UpArg
 #pragma unroll
       for (int e = 0; e < 4; ++e) d[e] = __builtin_bit_cast(unsigned, val[e]);
       __builtin_amdgcn_raw_buffer_store_b128(d, rs_y, (int)off, 0, 0);
+      if (want_bnb) {
+        const f32x4 yv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_p, (int)off, 0, 0));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float yy = yv[e];
+          const float gg = cv ? val[e] * act_grad(__builtin_fmaf(yy, sc[e], sh[e]), a.bnb_act, a.bnb_slope) : 0.f;
+          sA[4 * g + e] += gg;
+          sB[4 * g + e] = __builtin_fmaf(gg, (yy - mu[e]) * rsd[e], sB[4 * g + e]);
+        }
+      }
+    }
+  }
+  if (want_bnb) {
+    asm volatile("s_nop 1");
+    halfwave_sum_n(sA);
+    halfwave_sum_n(sB);
+    asm volatile("s_nop 1");
+    float* red = reinterpret_cast<float*>(smem);   // [2][4 waves][32]; the K loop ended with a barrier
+    if (lp == 31) {
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int cl = (v & 3) + 8 * (v >> 2) + 4 * lh;
+        red[mw * 32 + cl] = wave_live ? sA[v] : 0.f;
+        red[4 * 32 + mw * 32 + cl] = wave_live ? sB[v] : 0.f;
+      }
+    }
+    __syncthreads();
+    if (tid < 32 * WN) {
+      const int wc = tid >> 5, cl = tid & 31;
+      const int c = (cb * WN + wc) * 32 + cl;
+      if (c < a.co) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int m = 0; m < WM; ++m) {
+          t1 += red[(m * WN + wc) * 32 + cl];
+          t2 += red[4 * 32 + (m * WN + wc) * 32 + cl];
+        }
+        double* rep = a.sscr != nullptr ? a.sscr + (size_t)(blockIdx.x % HALO_SCR_REPLICAS) * 2 * a.co
+                                        : a.stats + (size_t)(blockIdx.x % HALO_STATS_REPLICAS) * 2 * a.co;
+        atomicAdd(rep + c, (double)t1);
+        atomicAdd(rep + a.co + c, (double)t2);
+      }
     }
   }
 }
@@ -729,10 +798,16 @@ extern "C" int udaseg_conv2d_fwd_up_f32x3(const udaseg_conv_desc* d, const float
 }
 
 // da (+)= the gradient of `a` through conv3x3(nearest_x2(a)): the whole chain (convolution transpose + the up-sampling's 2 x 2
-// sum) in one pass at a's resolution.  wfrag_up_t: mode-3 packing of the dgrad-packed weights.
+// sum) in one pass at a's resolution.  wfrag_up_t: mode-3 packing of the dgrad-packed weights.  prev_y != NULL: also the
+// BatchNorm-backward sums of the layer that produced a (udaseg_conv2d_dgrad_f32x3's contract; no accumulation then).
 extern "C" int udaseg_conv2d_dgrad_up_f32x3(const udaseg_conv_desc* d, const float* dy, int up_ca, const void* wfrag_up_t, float* da,
-                                            int accumulate, void* stream) {
+                                            const float* prev_y, const float* save_mean, const float* save_rstd, const float* gamma,
+                                            const float* beta, int bn_act, float bn_slope, double* bsums, int accumulate, void* stream) {
   UDASEG_CHECK_ARG(d && dy && wfrag_up_t && da, "conv2d_dgrad_up_f32x3: NULL pointer");
+  const bool bn = prev_y != nullptr;
+  UDASEG_CHECK_ARG(!bn || (save_mean && save_rstd && gamma && beta && bsums && !accumulate),
+                   "conv2d_dgrad_up_f32x3: the BatchNorm-backward sums need mean, rstd, gamma, beta, bsums and no accumulation");
+  UDASEG_CHECK_ARG(bn || bsums == nullptr, "conv2d_dgrad_up_f32x3: bsums without prev_y");
   if (!up_applicable(d, up_ca) || d->co % 8 != 0) {
     set_error("conv2d_dgrad_up_f32x3: geometry not supported (ask udaseg_conv_up_f32x3_ok first; co a multiple of 8)");
     return UDASEG_E_UNSUPPORTED;
@@ -741,6 +816,10 @@ extern "C" int udaseg_conv2d_dgrad_up_f32x3(const udaseg_conv_desc* d, const flo
   u.x = dy; u.wf = wfrag_up_t; u.y = da;
   u.n = d->n; u.h = d->hi / 2; u.w = d->wi / 2; u.ci = d->co; u.co = up_ca;
   u.accumulate = accumulate;
+  if (bn) {
+    u.bnb_y = prev_y; u.bnb_mean = save_mean; u.bnb_rstd = save_rstd; u.bnb_gamma = gamma; u.bnb_beta = beta;
+    u.bnb_act = bn_act; u.bnb_slope = bn_slope; u.stats = bsums;
+  }
   const long long pa = (long long)d->n * u.h * u.w;
   u.x_bytes = (unsigned)(4 * pa * d->co * 4);
   u.w_plane_bytes = (unsigned)(udaseg_frag_elems(up_ca, d->co, 4) * 2);

@@ -517,6 +517,7 @@ class Plan:
         self.conv_flops = 0.0
         self._packed = None
         self._bnb = {}                    # id(conv output y) -> BN-backward sums already made by the consumer's data gradient
+        self._producer = {}               # id(activation) -> the conv+BN+activation record that produced it (decoder block outputs)
         self._wgrad_halo = USE_WGRAD_HALO and (self.bf16 or USE_F32_SPLIT)      # halo-resident weight gradients (bf16 / fp32 split)
         if training and save and SIDE_STREAM_WGRAD and PREPACK_DGRAD:
             self._prepack_dgrad_weights()
@@ -867,7 +868,16 @@ class Plan:
             assert not dx_acc and conv.bias is None
             if isinstance(dx, UpGrad):          # phase form: the gradient of the half-resolution source at its own resolution
                 upw = self.up_frag(conv, d, x.a.shape[-1])
-                K.conv2d_dgrad_up(d, dy, x.a.shape[-1], upw["up_bwd"], dx.da, accumulate=dx.acc, st=self.st)
+                # prev: the record of the layer that produced x.a, whose only consumer this convolution is -- da is then that
+                # activation's complete gradient (no 2x2 sum-pool pass follows any more) and the epilogue makes its BatchNorm-backward sums
+                bn = None
+                if (prev is not None and FUSE_BN_REDUCE and not dx.acc and not prev[9] and prev[7] != ACT_NONE
+                        and not isinstance(prev[5], LazyAct) and prev[4].shape == dx.da.shape):
+                    p_bn, p_y, (p_mean, p_rstd) = prev[1], prev[4], prev[6]
+                    bs = self._next_bstats(ceil4(p_bn.c))
+                    bn = (p_y, p_mean, p_rstd, self.pvec(p_bn, "weight"), self.pvec(p_bn, "bias"), prev[7], prev[8], bs)
+                    self._bnb[id(p_y)] = bs
+                K.conv2d_dgrad_up(d, dy, x.a.shape[-1], upw["up_bwd"], dx.da, accumulate=dx.acc, bn=bn, st=self.st)
                 if x.skip is not None:
                     ds = K.conv_desc(d.n, d.hi, d.wi, x.skip.shape[-1], d.co, 3, 1, 1)
                     K.conv2d_dgrad_frag(ds, dy, upw["skip_bwd"], dx.d_skip, st=self.st)

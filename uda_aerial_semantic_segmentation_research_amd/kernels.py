@@ -260,9 +260,12 @@ def conv2d_fwd_up(d, a, wfrag_up, y, accumulate=False, stats=None, st=None):
     check(ops.udaseg_conv2d_fwd_up_f32x3(d, a, a.shape[-1], wfrag_up, y, int(accumulate), stats, st), "conv2d_fwd_up_f32x3")
 
 
-def conv2d_dgrad_up(d, dy, up_ca, wfrag_up_t, da, accumulate=False, st=None):
-    """da (+)= gradient of a through conv3x3(nearest_x2(a)), at a's resolution."""
-    check(ops.udaseg_conv2d_dgrad_up_f32x3(d, dy, up_ca, wfrag_up_t, da, int(accumulate), st), "conv2d_dgrad_up_f32x3")
+def conv2d_dgrad_up(d, dy, up_ca, wfrag_up_t, da, accumulate=False, bn=None, st=None):
+    """da (+)= gradient of a through conv3x3(nearest_x2(a)), at a's resolution.
+    bn = (prev_y, save_mean, save_rstd, gamma, beta, act, slope, bsums): BatchNorm-backward reductions of the layer that produced a."""
+    py, mu, rs, ga, be, act, slope, bs = bn if bn is not None else (None, None, None, None, None, ACT_NONE, 0.0, None)
+    check(ops.udaseg_conv2d_dgrad_up_f32x3(d, dy, up_ca, wfrag_up_t, da, py, mu, rs, ga, be, act, slope, bs, int(accumulate), st),
+          "conv2d_dgrad_up_f32x3")
 
 
 def conv2d_wgrad_up_ok(d, up_ca):

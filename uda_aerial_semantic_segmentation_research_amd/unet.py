@@ -158,6 +158,8 @@ class DecoderBlock(nn.Module):
             cat = K.upsample2x_concat_fwd(x, skip, P.st)
         a1, r1 = P.conv_bn_act(self.conv1[0], self.conv1[1], cat, *RELU, lazy_for=self.conv2[0])   # a1 feeds conv2 only
         out, r2 = P.conv_bn_act(self.conv2[0], self.conv2[1], a1, *RELU, lazy_for=lazy_for, lazy_up=lazy_up)
+        if r2 is not None:
+            P._producer[id(out)] = r2          # the next block's conv1 may be its only consumer (Plan.conv_bwd, phase form)
         return out, (x, skip, cat, a1, r1, r2)
 
     @staticmethod
@@ -179,7 +181,7 @@ class DecoderBlock(nn.Module):
             # phase form (csrc/conv_up_f32x3.hip): conv1's data gradient lands in dx at x's own resolution -- no gradient of the
             # up-sampled tensor, no 2x2 sum-pool pass
             d_skip = (torch.empty_like(skip) if ds_acc else ds) if skip is not None else None
-            P.conv_bn_act_bwd(r1, d_a1, dx=UpGrad(dx, dx_acc, d_skip))
+            P.conv_bn_act_bwd(r1, d_a1, dx=UpGrad(dx, dx_acc, d_skip), prev=None if dx_acc else P._producer.get(id(x)))
             if ds_acc:
                 ds.add_(d_skip)
             return
