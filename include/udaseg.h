@@ -516,6 +516,19 @@ int udaseg_conv2d_wgrad_halo_slice_f32x3(const udaseg_conv_desc* d, const float*
 /* tests / tuning: blocks per launch of the phase-form weight gradient (0 = the default, 128) */
 int udaseg_wgrad_up_set_blocks(int blocks);
 
+/* ---- sixteen produced channels on a sixteen-wide matrix tile (round 5, csrc/conv_n16_f32x3.hip): the full-resolution tail of
+ *      smp.Unet's decoder (decoder_channels[-1] = 16: block 4 conv2 forward and data gradient, the head's data gradient; reference
+ *      src/test_system.py:90-95, src/models/train.py:341,343).  v_mfma_f32_16x16x32_bf16 with K = two taps of a 16-channel chunk:
+ *      0.28 of the matrix-pipe cycles of the 32-row tile these layers half-filled.  fp32 tensors, three-term split; stride-1 3x3,
+ *      produced channels == 16, gathered channels a multiple of 8 up to 32.  Weight fragments: udaseg_pack_up_batched_f32x3 mode 4
+ *      (forward, from the OHWI arena) / mode 5 (data gradient, from the dgrad packing), 3 planes of ceil(K / 16) * 5 * 512 bf16. ---- */
+int udaseg_conv_n16_f32x3_ok(const udaseg_conv_desc* d, int dgrad);
+int udaseg_conv2d_fwd_n16_f32x3(const udaseg_conv_desc* d, const float* x, const float* in_scale, const float* in_shift, int in_act,
+                                float in_slope, const void* wfrag, float* y, double* stats, void* stream);
+int udaseg_conv2d_dgrad_n16_f32x3(const udaseg_conv_desc* d, const float* dy, const void* wfrag_t, float* dx, const float* prev_y,
+                                  const float* save_mean, const float* save_rstd, const float* gamma, const float* beta, int bn_act,
+                                  float bn_slope, double* bsums, void* stream);
+
 /* ---- diagnosis: while a device buffer of 6 * blocks u64 is registered, every implicit-GEMM launch of at most `blocks` blocks
  *      writes per block {entry, first tile load, end of K loop, exit} (100 MHz wall-clock ticks), HW_ID and XCC_ID into it
  *      (tools/igemm_timeline.py).  NULL switches it off.  Not for timed runs. ---- */

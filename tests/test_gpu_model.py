@@ -478,7 +478,8 @@ def test_bn_backward_reductions_in_the_dgrad_epilogue(pkg):
     x, y, _ = synthetic_batch(8, 256, 256, seed=6)
     xd, yd = x.cuda(), y.cuda()
     calls = {"fused": 0, "reduce": 0}
-    orig_f, orig_r, orig_h, orig_u = K.conv2d_dgrad_bnreduce, K.bn_bwd_reduce, K.conv2d_dgrad_frag, K.conv2d_dgrad_up
+    orig_f, orig_r, orig_h, orig_u, orig_n = (K.conv2d_dgrad_bnreduce, K.bn_bwd_reduce, K.conv2d_dgrad_frag, K.conv2d_dgrad_up,
+                                               K.conv2d_dgrad_n16)
 
     def count_f(*a, **k):
         calls["fused"] += 1
@@ -493,10 +494,15 @@ def test_bn_backward_reductions_in_the_dgrad_epilogue(pkg):
         calls["up"] = calls.get("up", 0) + int(k.get("bn") is not None)
         return orig_u(*a, **k)
 
+    def count_n(*a, **k):          # round 5: the sixteen-wide tile (decoder block 4 conv2's data gradient)
+        calls["fused"] += int(k.get("bn") is not None)
+        return orig_n(*a, **k)
+
     def count_r(*a, **k):
         calls["reduce"] += 1
         return orig_r(*a, **k)
-    K.conv2d_dgrad_bnreduce, K.bn_bwd_reduce, K.conv2d_dgrad_frag, K.conv2d_dgrad_up = count_f, count_r, count_h, count_u
+    K.conv2d_dgrad_bnreduce, K.bn_bwd_reduce, K.conv2d_dgrad_frag, K.conv2d_dgrad_up, K.conv2d_dgrad_n16 = (count_f, count_r, count_h,
+                                                                                                            count_u, count_n)
     out = {}
     try:
         for fused in (False, True):
@@ -507,7 +513,8 @@ def test_bn_backward_reductions_in_the_dgrad_epilogue(pkg):
             out[fused] = (net._grad_arena.clone(), dict(calls))
     finally:
         E.FUSE_BN_REDUCE = True
-        K.conv2d_dgrad_bnreduce, K.bn_bwd_reduce, K.conv2d_dgrad_frag, K.conv2d_dgrad_up = orig_f, orig_r, orig_h, orig_u
+        K.conv2d_dgrad_bnreduce, K.bn_bwd_reduce, K.conv2d_dgrad_frag, K.conv2d_dgrad_up, K.conv2d_dgrad_n16 = (orig_f, orig_r, orig_h,
+                                                                                                                orig_u, orig_n)
     assert out[True][1]["up"] == 4, out[True][1]           # the outputs of decoder blocks 0..3: their only consumer is the next conv1
     assert out[False][1]["fused"] == 0 and out[False][1]["reduce"] == 30
     assert out[True][1]["fused"] >= 4 and out[True][1]["fused"] + out[True][1]["reduce"] == 30, out[True][1]

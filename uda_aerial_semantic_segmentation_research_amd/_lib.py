@@ -145,6 +145,9 @@ SIGNATURES = {
     "udaseg_conv2d_wgrad_up_f32x3": (_I, [_D, _P, _I, _P, _P, _P]),
     "udaseg_conv2d_wgrad_halo_slice_f32x3": (_I, [_D, _P, _P, _P, _I, _I, _P]),
     "udaseg_wgrad_up_set_blocks": (_I, [_I]),
+    "udaseg_conv_n16_f32x3_ok": (_I, [_D, _I]),
+    "udaseg_conv2d_fwd_n16_f32x3": (_I, [_D, _P, _P, _P, _I, _F, _P, _P, _P, _P]),
+    "udaseg_conv2d_dgrad_n16_f32x3": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _P, _P]),
     "udaseg_set_workspace": (_I, [_P, C.c_size_t]),
     "udaseg_workspace_bytes": (C.c_size_t, [_D]),
     "udaseg_debug_set_timeline": (_I, [_P, _I]),

@@ -554,6 +554,7 @@ __global__ __launch_bounds__(512, 1) void conv_up_dgrad_f32x3_kernel(const UpArg
 //   mode 1: plain 3x3 data-gradient packing from wt32 [N][9][K] (ldk = K): rows [up_ca, ci) of the dgrad packing = d skip;
 //   mode 2: phase packing for conv_up_fwd_f32x3_kernel from w32 OHWI [N][3][3][ldk], channels [0, K);
 //   mode 3: phase packing for conv_up_dgrad_f32x3_kernel from wt32 [ci][9][K = co] rows [0, N).
+//   mode 4 / 5: sixteen-wide-tile packings (conv_n16_f32x3.hip), N == 16, plane stride = ceil(K / 16) * 5 * 512 elements.
 // plane stride = frag_elems(N, K, 3) (modes 0, 1) / frag_elems(N, K, 4) (modes 2, 3).
 __device__ __forceinline__ void up_taps(int ph, int uv, int& k0, int& k1) {      // Ky(py, u) / Kx(px, v) as a range [k0, k1]
   if (ph == 0) { k0 = uv ? 1 : 0; k1 = uv ? 2 : 0; }
@@ -592,6 +593,40 @@ __global__ void pack_up_batched_f32x3_kernel(const float* __restrict__ w32, cons
       u32x4 p0, p1, p2;
       split3(lo, hi, p0, p1, p2);
       if (3 * kk + dx >= q1 && 3 * kk + dx < q3) {
+        p0 ^= 0x80008000u;
+        p1 ^= 0x80008000u;
+        p2 ^= 0x80008000u;
+      }
+      *reinterpret_cast<u32x4*>(dst + i * 8) = p0;
+      *reinterpret_cast<u32x4*>(dst + plane + i * 8) = p1;
+      *reinterpret_cast<u32x4*>(dst + 2 * plane + i * 8) = p2;
+    }
+    return;
+  }
+  if (mode >= 4) {
+    // sixteen-wide tile (conv_n16_f32x3.hip): plane[p][chunk][pair j][lane][8], lane l: channel n = l & 15 (N == 16), K slice
+    // g = l >> 4: tap 2 j + (g >> 1) (the ninth tap's partner: zeros), channels 16 chunk + 8 (g & 1) .. + 7 of the chunk.
+    // mode 4: forward, w32 OHWI [16][9][ldk]; mode 5: data gradient, wt32 [16 = ci][9][ldk = co], window flipped
+    const long long total = (long long)nk16 * 5 * 64;
+    const long long plane = total * 8;
+    int q1 = 0, q3 = 0;
+    if (signs) up_negated_groups(5 * nk16, q1, q3);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+      const int lane = (int)(i & 63);
+      const int G = (int)(i >> 6);
+      const int kk = G / 5, j = G - 5 * kk;
+      const int n = lane & 15, gsl = lane >> 4;
+      const int tapl = 2 * j + (gsl >> 1), k0 = kk * 16 + 8 * (gsl & 1);
+      u32x4 lo = {0u, 0u, 0u, 0u}, hi = lo;
+      if (n < N && tapl < 9 && k0 < K) {
+        const int tap = mode == 5 ? 8 - tapl : tapl;
+        const float* sp = src + ((size_t)n * 9 + tap) * ldk + k0;
+        lo = *reinterpret_cast<const u32x4*>(sp);
+        if (k0 + 4 < K) hi = *reinterpret_cast<const u32x4*>(sp + 4);
+      }
+      u32x4 p0, p1, p2;
+      split3(lo, hi, p0, p1, p2);
+      if (G >= q1 && G < q3) {
         p0 ^= 0x80008000u;
         p1 ^= 0x80008000u;
         p2 ^= 0x80008000u;

@@ -51,6 +51,9 @@ USE_UP_PHASE = os.environ.get("UDASEG_UP_PHASE", "1") != "0"
 # work but stages the same bytes per pixel for it, and the weight gradients share the chip with the main stream's chain, so what
 # counts is CU-time, not FLOPs.  UDASEG_UP_PHASE_WGRAD=1 switches it on.
 USE_UP_PHASE_WGRAD = os.environ.get("UDASEG_UP_PHASE_WGRAD", "0") == "1"
+# fp32 storage (round 5): 3x3 layers that produce exactly 16 channels (decoder block 4 conv2 forward / data gradient, the head's data
+# gradient) on the sixteen-wide matrix tile (csrc/conv_n16_f32x3.hip).  UDASEG_N16=0: the 32-row tile (A/B, cross-check)
+USE_N16 = os.environ.get("UDASEG_N16", "1") != "0"
 
 
 # bf16 storage: BatchNorm + activation of a layer whose ONLY consumer is a convolution on the bf16-first kernels is not written at
@@ -373,6 +376,26 @@ class ArenaModule(nn.Module):
                         ent[key] = (foff, ne)
                         foff += ne
                     self._up_off[id(m)] = ent
+            # fp32: sixteen-wide-tile packings (csrc/conv_n16_f32x3.hip) of the 3x3 layers that produce (forward) or return gradients
+            # for (data gradient) exactly 16 channels: decoder block 4 conv2, the head's data gradient
+            self._n16_off = {}
+            if f32 and USE_N16:
+                for m in self.modules():
+                    if not (isinstance(m, ConvP) and m.k == 3 and m.stride == 1 and m.pad == 1 and m.up_ca == 0):
+                        continue
+                    ent = {}
+                    if m.cout_p == 16 and m.cin_p % 8 == 0 and m.cin_p <= 32 and m.bias is None:
+                        ne = K.n16_frag_elems(m.cin_p)
+                        urows_f.append([4, self._idx[(id(m), "weight")][0], foff, 16, m.cin_p, m.cin_p, 0, 0])
+                        ent["fwd"] = (foff, ne)
+                        foff += ne
+                    if m.cin_p == 16 and m.needs_dgrad and m.cout_p % 8 == 0 and m.cout_p <= 32:
+                        ne = K.n16_frag_elems(m.cout_p)
+                        urows_b.append([5, self._wt_off[id(m)], foff, 16, m.cout_p, m.cout_p, 0, 0])
+                        ent["bwd"] = (foff, ne)
+                        foff += ne
+                    if ent:
+                        self._n16_off[id(m)] = ent
             self._up_fwd_table = torch.tensor(urows_f, dtype=torch.int32, device=device) if urows_f else None
             self._up_bwd_table = torch.tensor(urows_b, dtype=torch.int32, device=device) if urows_b else None
             if frows:
@@ -606,6 +629,26 @@ class Plan:
         cache[key] = (self.net._frag_arena, views)
         return views
 
+    def n16_frag(self, conv, d, dgrad):
+        """The conv's sixteen-wide-tile packing (forward or data gradient) when this launch can take csrc/conv_n16_f32x3.hip."""
+        if not (self.frag and USE_N16 and USE_F32_SPLIT and not self.bf16):
+            return None
+        ent = getattr(self.net, "_n16_off", {}).get(id(conv))
+        key2 = "bwd" if dgrad else "fwd"
+        if ent is None or key2 not in ent:
+            return None
+        cache = self.net.__dict__.setdefault("_n16_cache", {})
+        key = (id(conv), d.n, d.hi, d.wi, d.ci, d.co, bool(dgrad))
+        hit = cache.get(key)
+        if hit is not None and hit[0] is self.net._frag_arena:
+            return hit[1]
+        view = None
+        if K.conv_n16_ok(d, dgrad):
+            o, n = ent[key2]
+            view = self.net._frag_arena[o:o + n]
+        cache[key] = (self.net._frag_arena, view)
+        return view
+
     # -- forward pieces
     def conv(self, conv, x, act=ACT_NONE, slope=0.0, out_dtype=None):
         n, h, w, ci = x.shape
@@ -732,6 +775,14 @@ class Plan:
                     ds = K.conv_desc(n, h, w, x.skip.shape[3], conv.cout_p, 3, 1, 1)
                     K.conv2d_fwd_frag(ds, x.skip, None, upw["skip_fwd"], None, y, st=self.st)
                 K.conv2d_fwd_up(d, x.a, upw["up_fwd"], y, accumulate=x.skip is not None, stats=sums[0], st=self.st)
+            elif (not up and bias is None and not (lazy_in and x.z is not None)
+                  and self.n16_frag(conv, d, False) is not None):          # 16 produced channels: the sixteen-wide tile
+                n16 = self.n16_frag(conv, d, False)
+                if lazy_in:
+                    K.conv2d_fwd_n16(d, x.y, n16, y, stats=sums[0], in_scale=x.scale, in_shift=x.shift, in_act=x.act, in_slope=x.slope,
+                                     st=self.st)
+                else:
+                    K.conv2d_fwd_n16(d, x, n16, y, stats=sums[0], st=self.st)
             elif lazy_in:
                 assert wf is not None, "a LazyAct input needs the bf16-first kernels (decided by the producer)"
                 K.conv2d_fwd_frag(d, x.y, None, wf, bias, y, stats=sums[0], in_scale=x.scale, in_shift=x.shift, in_act=x.act,
@@ -906,21 +957,27 @@ class Plan:
                 K.channel_sum(dy, self.gvec(conv, "bias"), True, wst)
         if dx is not None:
             wfd = self.wfrag(conv, d, dgrad=True)
+            n16 = self.n16_frag(conv, d, True) if not dx_acc else None      # 16 gradient channels: the sixteen-wide tile
             fuse = (prev is not None and FUSE_BN_REDUCE and not dx_acc and not prev[9] and prev[7] != ACT_NONE
-                    and prev[4].shape == dx.shape and (wfd is not None or K.conv2d_dgrad_bnreduce_ok(d, dy.dtype)))
+                    and prev[4].shape == dx.shape and (wfd is not None or n16 is not None or K.conv2d_dgrad_bnreduce_ok(d, dy.dtype)))
             if prev is not None and isinstance(prev[5], LazyAct) and not fuse and self.bf16:
                 raise RuntimeError("internal: the producer's activation was not written, its consumer's data gradient must make "
                                    "the BatchNorm-backward sums")
             if fuse:
                 p_bn, p_y, (p_mean, p_rstd) = prev[1], prev[4], prev[6]
                 bs = self._next_bstats(p_y.shape[-1] if self.bf16 else ceil4(p_bn.c))
-                if wfd is not None:
+                if n16 is not None:
+                    K.conv2d_dgrad_n16(d, dy, n16, dx, bn=(p_y, p_mean, p_rstd, self.pvec(p_bn, "weight"), self.pvec(p_bn, "bias"),
+                                                           prev[7], prev[8], bs), st=self.st)
+                elif wfd is not None:
                     K.conv2d_dgrad_frag(d, dy, wfd, dx, bn=(p_y, p_mean, p_rstd, self.pvec(p_bn, "weight"), self.pvec(p_bn, "bias"),
                                                             prev[7], prev[8], bs), st=self.st)
                 else:
                     K.conv2d_dgrad_bnreduce(d, dy, self.packed_wt(conv), dx, p_y, p_mean, p_rstd, self.pvec(p_bn, "weight"),
                                             self.pvec(p_bn, "bias"), prev[7], prev[8], bs, self.st)
                 self._bnb[id(p_y)] = bs
+            elif n16 is not None:
+                K.conv2d_dgrad_n16(d, dy, n16, dx, st=self.st)
             elif wfd is not None:
                 K.conv2d_dgrad_frag(d, dy, wfd, dx, accumulate=dx_acc, st=self.st)
             else:

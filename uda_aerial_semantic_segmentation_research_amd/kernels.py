@@ -283,6 +283,26 @@ def conv2d_wgrad_halo_slice(d_slice, x, dy, dw, c_off, st=None):
     check(ops.udaseg_conv2d_wgrad_halo_slice_f32x3(d_slice, x, dy, dw, dw.shape[-1], c_off, st), "conv2d_wgrad_halo_slice_f32x3")
 
 
+def conv_n16_ok(d, dgrad=False):
+    return bool(ops.udaseg_conv_n16_f32x3_ok(d, int(dgrad)))
+
+
+def n16_frag_elems(k_in):
+    """bf16 elements of the three-plane sixteen-wide-tile packing of a convolution gathering k_in channels."""
+    return 3 * ((k_in + 15) // 16) * 5 * 512
+
+
+def conv2d_fwd_n16(d, x, wfrag, y, stats=None, in_scale=None, in_shift=None, in_act=ACT_NONE, in_slope=0.0, st=None):
+    """Forward 3x3 convolution producing 16 channels on the sixteen-wide matrix tile (csrc/conv_n16_f32x3.hip)."""
+    check(ops.udaseg_conv2d_fwd_n16_f32x3(d, x, in_scale, in_shift, in_act, in_slope, wfrag, y, stats, st), "conv2d_fwd_n16_f32x3")
+
+
+def conv2d_dgrad_n16(d, dy, wfrag_t, dx, bn=None, st=None):
+    """Data gradient of a 3x3 convolution with 16 input channels on the sixteen-wide tile; bn as conv2d_dgrad_frag."""
+    py, mu, rs, ga, be, act, slope, bs = bn if bn is not None else (None, None, None, None, None, ACT_NONE, 0.0, None)
+    check(ops.udaseg_conv2d_dgrad_n16_f32x3(d, dy, wfrag_t, dx, py, mu, rs, ga, be, act, slope, bs, st), "conv2d_dgrad_n16_f32x3")
+
+
 def conv_frag_ok(d, dgrad=False, up_ca=0, f32=False):
     if f32:
         return bool(ops.udaseg_conv_f32x3_ok(d, int(dgrad), up_ca))
