@@ -13,8 +13,9 @@
 // The two taps of a pair read two different halo pixels: lanes 0-31 at tap 2j, lanes 32-63 at tap 2j + 1 -- per-lane LDS
 // addresses, 32-byte pixel rows with NO swizzle (ds_read_b128 serves lanes {0-3, 12-15, 20-27} together: pixels 0-3 / 12-15 at
 // octet 0 with pixels 4-11 at octet 1 -- sixteen distinct 16-byte slots of a 256-byte line for any column shift).
-// One-role kernel (every wave loads, splits, stages and multiplies: one or two chunks of K, nothing to pipeline across), 8 x 32 pixel
-// tiles, weights of the whole layer resident in LDS (15 KB per chunk).  Options: the unwritten BatchNorm activation as input
+// One-role kernel (every wave loads, splits, stages and multiplies), PERSISTENT over 8 x 32 pixel tiles: the weights of the whole layer
+// stay in LDS (15 KB per chunk), the next tile's fp32 halo is in flight during the current tile's MFMAs and epilogue, the statistics
+// leave the block once.  Options: the unwritten BatchNorm activation as input
 // (F3Args::in_scale of conv_halo_f32x3.hip), BatchNorm statistics of the output (forward), BatchNorm-backward sums of the producing
 // layer (data gradient).  Weight fragments: udaseg_pack_up_batched_f32x3 modes 4 / 5, plane[p][chunk][pair][lane][8].
 #include <stdlib.h>
@@ -87,30 +88,34 @@ __global__ __launch_bounds__(256, 2) void conv3x3_n16_f32x3_kernel(const N16Args
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int p = lane & 15, g = lane >> 4;          // pixel of the 16-pixel block / K slice (g >> 1: tap of the pair, g & 1: octet)
 
-  int bid = blockIdx.x;
-  {
-    const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int tx = bid % a.ntx;
-  int t = bid / a.ntx;
-  const int ty = t % a.nty;
-  const int img = t / a.nty;
-  const int y0 = ty * C::TH, x0 = tx * C::TW;
   const int H = a.h, W = a.w;
-
+  const int ntiles = a.n * a.nty * a.ntx;
+  // persistent: block b takes tiles b, b + gridDim.x, ...; the fp32 halo of the NEXT tile is requested before the MFMAs and the
+  // epilogue of the current one (with one or two chunks of K a tile has nothing to pipeline inside itself, and these layers move
+  // 0.27-0.4 GB per launch: what bounds them is bytes in flight, not the matrix pipe any more)
   const int oct = tid & 1;
   unsigned voff[C::NI], soffl[C::NI];
+  unsigned inmask = 0;                             // XF: bit i = piece i of the staged chunk lies inside the image
 #pragma unroll
-  for (int i = 0; i < C::NI; ++i) {
-    const int piece = tid + i * C::NT;
-    const int pix = piece >> 1;
-    const int hy = pix / C::HWD, hx = pix - hy * C::HWD;
-    const int iy = y0 + hy - 1, ix = x0 + hx - 1;
-    const bool ok = piece < C::NPIECE && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-    voff[i] = ok ? (unsigned)((((img * H + iy) * W + ix) * a.ci + oct * 8) * 4) : 0x80000000u;
-    soffl[i] = (unsigned)(pix * 32 + oct * 16);
-  }
+  for (int i = 0; i < C::NI; ++i) soffl[i] = (unsigned)(((tid + i * C::NT) >> 1) * 32 + oct * 16);
+  int img = 0, y0 = 0, x0 = 0;                     // the tile the loads were last issued for
+  auto tile_setup = [&](int tl) {
+    const int tx = tl % a.ntx;
+    const int t2 = tl / a.ntx;
+    const int ty = t2 % a.nty;
+    img = t2 / a.nty;
+    y0 = ty * C::TH;
+    x0 = tx * C::TW;
+#pragma unroll
+    for (int i = 0; i < C::NI; ++i) {
+      const int piece = tid + i * C::NT;
+      const int pix = piece >> 1;
+      const int hy = pix / C::HWD, hx = pix - hy * C::HWD;
+      const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+      const bool ok = piece < C::NPIECE && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      voff[i] = ok ? (unsigned)((((img * H + iy) * W + ix) * a.ci + oct * 8) * 4) : 0x80000000u;
+    }
+  };
   __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wf), 0, (int)(3u * a.w_plane_bytes), 0x00020000);
 
@@ -118,10 +123,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_n16_f32x3_kernel(const N16Args
   auto load_chunk = [&](int c) {
     const int soff = c * 64;
     const unsigned kill = (c * 16 + oct * 8 < a.ci) ? 0u : 0x80000000u;
+    inmask = 0;
 #pragma unroll
     for (int i = 0; i < C::NI; ++i) {
       stage[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(voff[i] | kill), soff, 0);
       stage[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(voff[i] | kill), soff + 16, 0);
+      inmask |= (voff[i] != 0x80000000u ? 1u : 0u) << i;
     }
   };
   const bool xf_relu = a.in_act == UDASEG_ACT_LEAKY && a.in_slope == 0.f;
@@ -143,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_n16_f32x3_kernel(const N16Args
       if (i < C::NI - 1 || tid + i * C::NT < C::NPIECE) {
         u32x4 lo = stage[i][0], hi = stage[i][1];
         if constexpr (XF) {
-          const bool inside = voff[i] != 0x80000000u;        // zero padding is padding of the ACTIVATION: stays zero
+          const bool inside = (inmask >> i) & 1u;            // zero padding is padding of the ACTIVATION: stays zero
           f32x4 l = __builtin_bit_cast(f32x4, lo), h = __builtin_bit_cast(f32x4, hi);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -180,7 +187,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_n16_f32x3_kernel(const N16Args
       *reinterpret_cast<u32x4*>(wlds + (f * 3 + pl) * 1024 + ln * 16) = v;
     }
   }
-  load_chunk(0);
 
   // per-lane halo offsets of the five tap pairs: lanes with g >> 1 == 0 read tap 2j, the others tap 2j + 1 (the ninth tap's partner
   // carries zero weights: any valid address)
@@ -193,49 +199,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_n16_f32x3_kernel(const N16Args
   }
   const int pbase = ((wave * C::RPW) * C::HWD + p) * 32 + (g & 1) * 16;
 
-  f32x4v acc[C::NB];
-#pragma unroll
-  for (int b = 0; b < C::NB; ++b) acc[b] = f32x4v{0.f, 0.f, 0.f, 0.f};
-
-  for (int c = 0; c < a.nk16; ++c) {
-    store_chunk(c);
-    __syncthreads();                 // the chunk's halo (and, the first time, the weights) are visible
-    if (c + 1 < a.nk16) load_chunk(c + 1);
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-      const int G = 5 * c + j;
-      if (G == a.q1 || G == a.q3) {
-#pragma unroll
-        for (int b = 0; b < C::NB; ++b) acc[b] = -acc[b];
-      }
-      u32x4 A[3];
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) A[pl] = *reinterpret_cast<const u32x4*>(wlds + ((c * 5 + j) * 3 + pl) * 1024 + lane * 16);
-#pragma unroll
-      for (int b = 0; b < C::NB; ++b) {
-        const int r = b >> 1, bx = b & 1;
-        u32x4 B[3];
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-          B[pl] = *reinterpret_cast<const u32x4*>(smem + pl * C::PLANE + pbase + toff[j] + (r * C::HWD + bx * 16) * 32);
-        // smallest terms first (weight piece i x pixel piece ij - i, i + j <= 2)
-#pragma unroll
-        for (int ij = 2; ij >= 0; --ij)
-#pragma unroll
-          for (int i = 0; i <= ij; ++i)
-            acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[i]), __builtin_bit_cast(bf16x8, B[ij - i]), acc[b], 0, 0, 0);
-      }
-    }
-    __syncthreads();                 // every wave is done with the halo before the next chunk overwrites it
-  }
-
-  // ---- epilogue: acc[b][e] of lane (p, g): channel 4 g + e of pixel (row wave * RPW + (b >> 1), column 16 (b & 1) + p)
   __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)a.y_bytes, 0x00020000);
   const bool want_stats = a.stats != nullptr && a.bnb_y == nullptr;
   const bool want_bnb = a.bnb_y != nullptr;
   __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(want_bnb ? a.bnb_y : a.x), 0,
                                                                   (int)(want_bnb ? a.y_bytes : 0u), 0x00020000);
-  float s[8];                        // [0..3]: sums, [4..7]: second sums, of this lane's 4 channels
+  float s[8];                        // [0..3]: sums, [4..7]: second sums, of this lane's 4 channels, over all tiles of the block
 #pragma unroll
   for (int v = 0; v < 8; ++v) s[v] = 0.f;
   f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = sc, mu = sc, rsd = sc;
@@ -249,38 +218,88 @@ __global__ __launch_bounds__(256, 2) void conv3x3_n16_f32x3_kernel(const N16Args
       sh[e] = bt[e] - mu[e] * sc[e];
     }
   }
+
+  int tile = blockIdx.x;
+  if (tile < ntiles) {
+    tile_setup(tile);
+    load_chunk(0);
+  }
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int cimg = img, cy0 = y0, cx0 = x0;      // this tile (tile_setup moves on to the next one inside the loop)
+    f32x4v acc[C::NB];
 #pragma unroll
-  for (int b = 0; b < C::NB; ++b) {
-    const int oy = y0 + wave * C::RPW + (b >> 1), ox = x0 + 16 * (b & 1) + p;
-    const bool cv = oy < H && ox < W;
-    const unsigned off = cv ? (((unsigned)((img * H + oy) * W + ox)) * 16u + 4u * (unsigned)g) * 4u : 0x80000000u;
-    // (whole-vector cast: the element-wise form, bit_cast(unsigned, acc[b][e]) in a loop, compiled to FOUR COPIES OF ELEMENT 0 --
-    // hipcc 7.2; the same trap as the accumulate load in conv_halo_f32x3_epilogue.inc)
-    const u32x4 d = __builtin_bit_cast(u32x4, acc[b]);
-    __builtin_amdgcn_raw_buffer_store_b128(d, rs_y, (int)off, 0, 0);
-    if (want_stats) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float q = cv ? acc[b][e] : 0.f;
-        s[e] += q;
-        s[4 + e] = __builtin_fmaf(q, q, s[4 + e]);
+    for (int b = 0; b < C::NB; ++b) acc[b] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < a.nk16; ++c) {
+      store_chunk(c);
+      __syncthreads();               // the chunk's halo (and, the first time, the weights) are visible
+      if (c + 1 < a.nk16) {
+        load_chunk(c + 1);
+      } else if (tile + (int)gridDim.x < ntiles) {
+        tile_setup(tile + gridDim.x);
+        load_chunk(0);
       }
-    }
-    if (want_bnb) {
-      const f32x4 yv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_p, (int)off, 0, 0));
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float yy = yv[e];
-        const float gg = cv ? acc[b][e] * act_grad(__builtin_fmaf(yy, sc[e], sh[e]), a.bnb_act, a.bnb_slope) : 0.f;
-        s[e] += gg;
-        s[4 + e] = __builtin_fmaf(gg, (yy - mu[e]) * rsd[e], s[4 + e]);
+      for (int j = 0; j < 5; ++j) {
+        const int G = 5 * c + j;
+        if (G == a.q1 || G == a.q3) {
+#pragma unroll
+          for (int b = 0; b < C::NB; ++b) acc[b] = -acc[b];
+        }
+        u32x4 A[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) A[pl] = *reinterpret_cast<const u32x4*>(wlds + ((c * 5 + j) * 3 + pl) * 1024 + lane * 16);
+#pragma unroll
+        for (int b = 0; b < C::NB; ++b) {
+          const int r = b >> 1, bx = b & 1;
+          u32x4 B[3];
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl)
+            B[pl] = *reinterpret_cast<const u32x4*>(smem + pl * C::PLANE + pbase + toff[j] + (r * C::HWD + bx * 16) * 32);
+          // smallest terms first (weight piece i x pixel piece ij - i, i + j <= 2)
+#pragma unroll
+          for (int ij = 2; ij >= 0; --ij)
+#pragma unroll
+            for (int i = 0; i <= ij; ++i)
+              acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[i]), __builtin_bit_cast(bf16x8, B[ij - i]), acc[b], 0, 0, 0);
+        }
+      }
+      __syncthreads();               // every wave is done with the halo before the next chunk / tile overwrites it
+    }
+
+    // ---- epilogue: acc[b][e] of lane (p, g): channel 4 g + e of pixel (row wave * RPW + (b >> 1), column 16 (b & 1) + p)
+#pragma unroll
+    for (int b = 0; b < C::NB; ++b) {
+      const int oy = cy0 + wave * C::RPW + (b >> 1), ox = cx0 + 16 * (b & 1) + p;
+      const bool cv = oy < H && ox < W;
+      const unsigned off = cv ? (((unsigned)((cimg * H + oy) * W + ox)) * 16u + 4u * (unsigned)g) * 4u : 0x80000000u;
+      // (whole-vector cast: the element-wise form, bit_cast(unsigned, acc[b][e]) in a loop, compiled to FOUR COPIES OF ELEMENT 0 --
+      // hipcc 7.2; the same trap as the accumulate load in conv_halo_f32x3_epilogue.inc)
+      const u32x4 d = __builtin_bit_cast(u32x4, acc[b]);
+      __builtin_amdgcn_raw_buffer_store_b128(d, rs_y, (int)off, 0, 0);
+      if (want_stats) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float q = cv ? acc[b][e] : 0.f;
+          s[e] += q;
+          s[4 + e] = __builtin_fmaf(q, q, s[4 + e]);
+        }
+      }
+      if (want_bnb) {
+        const f32x4 yv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_p, (int)off, 0, 0));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float yy = yv[e];
+          const float gg = cv ? acc[b][e] * act_grad(__builtin_fmaf(yy, sc[e], sh[e]), a.bnb_act, a.bnb_slope) : 0.f;
+          s[e] += gg;
+          s[4 + e] = __builtin_fmaf(gg, (yy - mu[e]) * rsd[e], s[4 + e]);
+        }
       }
     }
   }
-  if (want_stats || want_bnb) {
+  if (want_stats || want_bnb) {      // once per block: the sums of all its tiles
     asm volatile("s_nop 1");
     row16_sum_n(s);
-    float* red = reinterpret_cast<float*>(smem);   // [4 waves][2][16]; the K loop ended with a barrier
+    float* red = reinterpret_cast<float*>(smem);   // [4 waves][2][16]; the tile loop ended with a barrier
     if (p == 0) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -291,9 +310,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_n16_f32x3_kernel(const N16Args
     __syncthreads();
     if (tid < 32) {
       const float tot = red[tid] + red[32 + tid] + red[64 + tid] + red[96 + tid];      // tid < 16: sums, else second sums
-      double* rep = a.sscr != nullptr ? a.sscr + (size_t)(blockIdx.x % HALO_SCR_REPLICAS) * 32
-                                      : a.stats + (size_t)(blockIdx.x % HALO_STATS_REPLICAS) * 32;
-      atomicAdd(rep + tid, (double)tot);
+      atomicAdd(a.stats + (size_t)(blockIdx.x % HALO_STATS_REPLICAS) * 32 + tid, (double)tot);
     }
   }
 }
@@ -319,10 +336,19 @@ static int launch_n16(N16Args a, hipStream_t s, double flops) {
     a.q3 = ng - a.q1;
   }
   const int lds = C::LDS_HALO + a.nk16 * C::WCHUNK;
-  const long long blocks = (long long)a.n * a.nty * a.ntx;
-  if (blocks <= 0) return UDASEG_OK;
+  const long long ntiles = (long long)a.n * a.nty * a.ntx;
+  if (ntiles <= 0) return UDASEG_OK;
+  if (ntiles >= (1LL << 31)) return UDASEG_E_UNSUPPORTED;
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0)
+              ? pr.multiProcessorCount : 256;
+  }
+  const long long resident = (long long)cus * (a.nk16 == 1 ? 3 : 2);      // blocks that fit the chip at once (48 / 63 KB of LDS each)
+  const long long blocks = ntiles < resident ? ntiles : resident;
   a.sscr = nullptr;
-  if (a.stats != nullptr && blocks > 1024) a.sscr = halo_stats_scratch(16);
   const bool xf = a.in_scale != nullptr;
   auto kern = xf ? conv3x3_n16_f32x3_kernel<true> : conv3x3_n16_f32x3_kernel<false>;
   static std::atomic<bool> attr_done[2] = {{false}, {false}};
@@ -338,10 +364,6 @@ static int launch_n16(N16Args a, hipStream_t s, double flops) {
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::NT), lds, s, a);
   kprof_end(kid[xf], ev, s, flops);
   UDASEG_LAUNCH_CHECK("conv3x3_n16_f32x3 launch");
-  if (a.sscr != nullptr) {
-    launch_halo_stats_fold(a.sscr, 16, a.stats, s);
-    UDASEG_LAUNCH_CHECK("halo_stats_fold launch");
-  }
   return UDASEG_OK;
 }
 
