@@ -36,17 +36,50 @@ extern "C" {
 #define UDASEG_ACT_LEAKY 1 /* y = x > 0 ? x : slope * x ; slope 0 => ReLU */
 
 int udaseg_version(void);
-/* runtime switches for cross-checks and tuning.  UDASEG_OPT_GENERIC_GATHER: 1 keeps the convolution kernels on their generic
- * gather loops, 0 allows the uniform-tap / row-uniform loops, -1 restores the environment default
- * (UDASEG_IGEMM_GENERIC / UDASEG_WGRAD_GENERIC).  Both loops accumulate in the same order: forward and dgrad results are
- * bit-identical between them.
- * UDASEG_OPT_F32_SPLIT: 0 keeps the shared-source fp32 kernels (udaseg_conv2d_fwd / _dgrad / _wgrad and their variants) on the
- * fp32 matrix pipe, 1 allows the three-term bf16 split there (conv_igemm_kernel X3, conv_wgrad_x3_kernel), -1 restores the
- * environment default (UDASEG_F32_SPLIT, UDASEG_IGEMM_X3, UDASEG_WGRAD_X3).  The halo-resident fp32 kernels (udaseg_conv2d_*_f32x3)
- * are entry points of their own and are not affected. */
-#define UDASEG_OPT_GENERIC_GATHER 0
-#define UDASEG_OPT_F32_SPLIT 1
+/* Runtime switches for cross-checks and tuning: ONE table (csrc/api.hip).  Every key has a default that an environment variable
+ * may supply (read once, at first use); udaseg_set_option(key, value) overrides it for the process (value -1: back to the default),
+ * udaseg_get_option reads the effective value, udaseg_option_name gives the key's environment variable, udaseg_option_epoch counts
+ * the overrides made so far (callers that cache routing answers compare it).  Both gather loops accumulate in the same order:
+ * forward and data-gradient results are bit-identical between GENERIC_GATHER 0 and 1. */
+#define UDASEG_OPT_GENERIC_GATHER 0        /* UDASEG_IGEMM_GENERIC: 1: the implicit-GEMM kernels keep their generic gather loop (cross-check of the uniform-tap loop); setting this key also sets WGRAD_GENERIC */
+#define UDASEG_OPT_F32_SPLIT 1             /* UDASEG_F32_SPLIT: 0: the SHARED-SOURCE fp32 kernels (udaseg_conv2d_fwd / _dgrad / _wgrad) stay on the fp32 matrix pipe */
+#define UDASEG_OPT_WGRAD_GENERIC 2         /* UDASEG_WGRAD_GENERIC: 1: the split-K weight gradients keep their generic gather loop */
+#define UDASEG_OPT_F32_HALO 3              /* UDASEG_F32_SPLIT: 0: the halo-resident three-term kernels (udaseg_conv2d_*_f32x3, _up_, _n16_) report 'not supported' (A/B: everything on the fp32 pipe) */
+#define UDASEG_OPT_F3_CFG 4                /* UDASEG_F3_CFG: conv_halo_f32x3.hip: one tile configuration 1..12 for every launch (udaseg_f32x3_force_config) */
+#define UDASEG_OPT_F3_WS 5                 /* UDASEG_F3_WS: 0: the one-role forward kernel everywhere (A/B of the wave-specialised form) */
+#define UDASEG_OPT_F3_SIGNS 6              /* UDASEG_F3_SIGNS: 0: no + - - + sign pattern in the split kernels and their packers (bias measurements) */
+#define UDASEG_OPT_IGEMM_TILE 7            /* UDASEG_IGEMM_TILE: conv_igemm.hip: 1 (128x128) | 2 (128x64) | 3 (64x64) | 4 (128x32) for every launch */
+#define UDASEG_OPT_IGEMM_X3 8              /* UDASEG_IGEMM_X3: three-term mode of the shared implicit GEMM: 0 off | 1 (64x64 tile) | 2 (128x64) | 3 (128x128) */
+#define UDASEG_OPT_NO_FOLD 9               /* UDASEG_NO_FOLD: 1: no pixel folding of the <= 32-channel bf16 layers */
+#define UDASEG_OPT_WGRAD_X3_BLOCKS 10       /* UDASEG_WGRAD_X3_BLOCKS: blocks of a conv_wgrad_x3_kernel launch */
+#define UDASEG_OPT_WGRAD_BLOCKS 11          /* UDASEG_WGRAD_BLOCKS: blocks of a split-K weight-gradient launch (0: 3072 fp32 / the bf16 rules) */
+#define UDASEG_OPT_WGRAD_NO_XCD 12          /* UDASEG_WGRAD_NO_XCD: 1: no XCD-aware block order in the bf16 split-K weight gradient */
+#define UDASEG_OPT_WGRAD_X3 13              /* UDASEG_WGRAD_X3: 0: conv_wgrad_x3_kernel off (shared-source weight gradients on the fp32 pipe) */
+#define UDASEG_OPT_NO_WGRAD_HALO 14         /* UDASEG_NO_WGRAD_HALO: 1: the per-tap split-K weight gradients everywhere */
+#define UDASEG_OPT_WGRAD_F3_BLOCKS 15       /* UDASEG_WGRAD_F3_BLOCKS: blocks of an fp32 halo weight-gradient launch */
+#define UDASEG_OPT_WGRAD_HALO_BLOCKS 16     /* UDASEG_WGRAD_HALO_BLOCKS: blocks of a bf16 halo weight-gradient launch */
+#define UDASEG_OPT_WGRAD_DEEP_BLOCKS 17     /* UDASEG_WGRAD_DEEP_BLOCKS: blocks of the 16-pixel-wide halo weight gradients (0: 128 fp32 / 256 bf16) */
+#define UDASEG_OPT_WGRAD_DB 18              /* UDASEG_WGRAD_DB: 0: the single-buffer 4-row form of the 64 x 64 fp32 halo weight gradient */
+#define UDASEG_OPT_REDUCE_BLOCKS 19         /* UDASEG_REDUCE_BLOCKS: cap on the blocks of the BatchNorm reduction kernels (0: 512) */
+#define UDASEG_OPT_BN_APPLY_PT 20           /* UDASEG_BN_APPLY_PT: vectors per thread of the BatchNorm apply kernels */
+#define UDASEG_OPT_GEMM_1X1_TILE 21         /* UDASEG_GEMM_1X1_TILE: conv1x1_gemm_bf16_kernel: 128 | 256 pixel tiles for every launch */
+#define UDASEG_OPT_GEMM_1X1 22              /* UDASEG_GEMM_1X1: 0: r50's 1x1 projections never take the small-GEMM kernel */
+#define UDASEG_OPT_GEMM_1X1_MAXM 23         /* UDASEG_GEMM_1X1_MAXM: most pixels of a launch the small-GEMM kernel takes */
+#define UDASEG_OPT_NO_STREAM 24             /* UDASEG_NO_STREAM: 1: 1x1 layers stay on the tile kernel */
+#define UDASEG_OPT_HALO_CFG 25              /* UDASEG_HALO_CFG: conv_halo_bf16.hip: one configuration for every launch */
+#define UDASEG_OPT_NO_HALO 26               /* UDASEG_NO_HALO: 1: every bf16 layer on the shared implicit-GEMM source */
+#define UDASEG_OPT_NO_HALO_S2 27            /* UDASEG_NO_HALO_S2: 1: the discriminator's 4x4 / stride 2 layers on the shared source */
+#define UDASEG_OPT_HALO_W16 28              /* UDASEG_HALO_W16: tile for widths 16 divides and 32 does not: 0 | 4 | 5 | 6 */
+#define UDASEG_OPT_HALO_DEEP 29             /* UDASEG_HALO_DEEP: 0: no 8 x 16-pixel tile for deep low-resolution layers */
+#define UDASEG_OPT_HALO_S2_CK 30            /* UDASEG_HALO_S2_CK: channels per staged chunk of the 4x4 / stride 2 halo form: 32 | 64 */
+#define UDASEG_OPT_UP_CFG 31                /* UDASEG_UP_CFG: conv_up_f32x3.hip: one tile configuration 1..8 for every launch (udaseg_up_f32x3_force_config) */
+#define UDASEG_OPT_WGRAD_UP_BLOCKS 32       /* UDASEG_WGRAD_UP_BLOCKS: blocks of a conv_wgrad_up_kernel launch (0: 96; udaseg_wgrad_up_set_blocks) */
+#define UDASEG_OPT_COUNT 33
 int udaseg_set_option(int key, int value);
+int udaseg_get_option(int key);
+int udaseg_option_count(void);
+const char* udaseg_option_name(int key);
+int udaseg_option_epoch(void);
 const char* udaseg_last_error(void);
 /* number of HIP devices visible to the library (0 on a CPU-only box; never initialises a context) */
 int udaseg_device_count(void);

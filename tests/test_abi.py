@@ -222,3 +222,36 @@ def test_every_entry_point_checks_its_operands_before_the_library_is_called():
         O.set_require_cuda(True)
         O._FN.clear()
         O._FN.update(saved)
+
+
+def test_python_option_mirror_matches_the_library_table():
+    """_lib.OPTIONS (the one Python mirror of the switchboard) against udaseg_option_count / udaseg_option_name; set / get / epoch
+    work without a GPU; the header declares every key."""
+    import re
+    from uda_aerial_semantic_segmentation_research_amd import _lib
+    lib = _lib.load()
+    n = lib.udaseg_option_count()
+    assert sorted(_lib.OPTIONS.values()) == list(range(n))
+    hdr = open(os.path.join(ROOT, "include", "udaseg.h")).read()
+    keys = dict(re.findall(r"#define UDASEG_OPT_(\w+) (\d+)", hdr))
+    assert int(keys.pop("COUNT")) == n
+    assert {k: int(v) for k, v in keys.items()} == _lib.OPTIONS
+    for name, key in _lib.OPTIONS.items():
+        env = lib.udaseg_option_name(key).decode()
+        assert env.startswith("UDASEG_"), (name, env)
+    e0 = lib.udaseg_option_epoch()
+    before = lib.udaseg_get_option(_lib.OPTIONS["F3_CFG"])
+    assert lib.udaseg_set_option(_lib.OPTIONS["F3_CFG"], 5) == 0 and lib.udaseg_get_option(_lib.OPTIONS["F3_CFG"]) == 5
+    assert lib.udaseg_set_option(_lib.OPTIONS["F3_CFG"], -1) == 0 and lib.udaseg_get_option(_lib.OPTIONS["F3_CFG"]) == before
+    assert lib.udaseg_option_epoch() == e0 + 2
+    assert lib.udaseg_set_option(n, 1) != 0 and lib.udaseg_set_option(0, -2) != 0
+    # one key for both gather loops, as before the table existed
+    lib.udaseg_set_option(_lib.OPTIONS["GENERIC_GATHER"], 1)
+    assert lib.udaseg_get_option(_lib.OPTIONS["WGRAD_GENERIC"]) == 1
+    lib.udaseg_set_option(_lib.OPTIONS["GENERIC_GATHER"], -1)
+    assert lib.udaseg_get_option(_lib.OPTIONS["WGRAD_GENERIC"]) == 0
+    # the library reads the environment in ONE place
+    import glob
+    csrc = os.path.join(ROOT, "uda_aerial_semantic_segmentation_research_amd", "csrc")
+    sites = [f for f in glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) if "getenv(" in open(f).read()]
+    assert [os.path.basename(f) for f in sites] == ["api.hip"], sites

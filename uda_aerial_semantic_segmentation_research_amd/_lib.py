@@ -27,6 +27,11 @@ _D = C.POINTER(ConvDesc)
 # name -> (restype, argtypes); every symbol include/udaseg.h declares
 SIGNATURES = {
     "udaseg_version": (_I, []),
+    "udaseg_set_option": (_I, [_I, _I]),
+    "udaseg_get_option": (_I, [_I]),
+    "udaseg_option_count": (_I, []),
+    "udaseg_option_name": (C.c_char_p, [_I]),
+    "udaseg_option_epoch": (_I, []),
     "udaseg_last_error": (C.c_char_p, []),
     "udaseg_device_count": (_I, []),
     "udaseg_memset_async": (_I, [_P, _I, C.c_size_t, _P]),
@@ -81,7 +86,6 @@ SIGNATURES = {
     "udaseg_bce_logits_target_fwd": (_I, [_P, _P, _I, _F, _P, _I, _P]),
     "udaseg_bce_logits_target_bwd": (_I, [_P, _P, _I, _F, _P, _P, _I, _P]),
     "udaseg_scale_f32": (_I, [_P, _P, _L, _F, _P]),
-    "udaseg_set_option": (_I, [_I, _I]),
     "udaseg_prepare_batch_u8": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _I, _P, _I, _P]),
     "udaseg_dice_bwd": (_I, [_P, _P, _P, _P, _F, _I, _L, _I, _I, _P, _I, _P]),
     "udaseg_focal_fwd": (_I, [_P, _P, _P, _F, _F, _L, _I, _I, _I, _P, _P, _I, _P]),
@@ -162,6 +166,10 @@ SIGNATURES = {
     "udaseg_prof_kernel_read": (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "udaseg_prof_records": (_I, [_I, _I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
 }
+
+# The library's switchboard (include/udaseg.h UDASEG_OPT_*, table in csrc/api.hip): name -> key.  The ONE Python mirror of it;
+# tests/test_abi.py checks it against udaseg_option_count / udaseg_option_name.  kernels.set_option / get_option take these names.
+OPTIONS = {"GENERIC_GATHER": 0, "F32_SPLIT": 1, "WGRAD_GENERIC": 2, "F32_HALO": 3, "F3_CFG": 4, "F3_WS": 5, "F3_SIGNS": 6, "IGEMM_TILE": 7, "IGEMM_X3": 8, "NO_FOLD": 9, "WGRAD_X3_BLOCKS": 10, "WGRAD_BLOCKS": 11, "WGRAD_NO_XCD": 12, "WGRAD_X3": 13, "NO_WGRAD_HALO": 14, "WGRAD_F3_BLOCKS": 15, "WGRAD_HALO_BLOCKS": 16, "WGRAD_DEEP_BLOCKS": 17, "WGRAD_DB": 18, "REDUCE_BLOCKS": 19, "BN_APPLY_PT": 20, "GEMM_1X1_TILE": 21, "GEMM_1X1": 22, "GEMM_1X1_MAXM": 23, "NO_STREAM": 24, "HALO_CFG": 25, "NO_HALO": 26, "NO_HALO_S2": 27, "HALO_W16": 28, "HALO_DEEP": 29, "HALO_S2_CK": 30, "UP_CFG": 31, "WGRAD_UP_BLOCKS": 32}
 
 _lib = None
 

@@ -55,7 +55,8 @@ OPERANDS = {
     # ---- library state / queries (no device pointers)
     "udaseg_version": [], "udaseg_last_error": [], "udaseg_device_count": [], "udaseg_bn_replicas": [], "udaseg_ce_partials": [],
     "udaseg_seg_partials": [], "udaseg_prof_reset": [], "udaseg_prof_kernel_count": [],
-    "udaseg_set_option": [I("key"), I("value")],
+    "udaseg_set_option": [I("key"), I("value")], "udaseg_get_option": [I("key")], "udaseg_option_count": [],
+    "udaseg_option_name": [I("key")], "udaseg_option_epoch": [],
     "udaseg_conv2d_dgrad_bnreduce_ok": [D], "udaseg_conv2d_dgrad_bnreduce_bf16_ok": [D], "udaseg_conv_flops": [D],
     "udaseg_conv2d_fwd_f32x3_bnin_ok": [D, I("up")], "udaseg_conv2d_wgrad_bnin_ok": [D, I("up")],
     "udaseg_conv2d_fwd_f32x3_bnin_writes": [D],

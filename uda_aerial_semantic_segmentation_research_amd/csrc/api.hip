@@ -4,6 +4,7 @@
 #include <vector>
 
 #include "common.h"
+#include "options.h"
 
 namespace udaseg {
 
@@ -243,18 +244,88 @@ extern "C" int udaseg_prof_records(int family, int max_records, double* ms, doub
   return n;
 }
 
+// ---- the switchboard (csrc/options.h): the ONLY place of the library that reads the environment
 namespace udaseg {
-int g_opt_generic_gather = -1;
-int g_opt_f32_split = -1;
+enum { K_INT, K_FLAG, K_OFF0 };      // the variable's integer value | 1 when the variable exists | 0 when it is set to 0, else 1
+struct OptRow {
+  const char* env;
+  int kind, dflt;
+};
+static const OptRow g_opt_rows[UDASEG_OPT_COUNT] = {
+    /*  0 GENERIC_GATHER */ {"UDASEG_IGEMM_GENERIC", K_INT, 0},
+    /*  1 F32_SPLIT */ {"UDASEG_F32_SPLIT", K_OFF0, 1},
+    /*  2 WGRAD_GENERIC */ {"UDASEG_WGRAD_GENERIC", K_INT, 0},
+    /*  3 F32_HALO */ {"UDASEG_F32_SPLIT", K_OFF0, 1},
+    /*  4 F3_CFG */ {"UDASEG_F3_CFG", K_INT, 0},
+    /*  5 F3_WS */ {"UDASEG_F3_WS", K_OFF0, 1},
+    /*  6 F3_SIGNS */ {"UDASEG_F3_SIGNS", K_OFF0, 1},
+    /*  7 IGEMM_TILE */ {"UDASEG_IGEMM_TILE", K_INT, 0},
+    /*  8 IGEMM_X3 */ {"UDASEG_IGEMM_X3", K_INT, 1},
+    /*  9 NO_FOLD */ {"UDASEG_NO_FOLD", K_FLAG, 0},
+    /* 10 WGRAD_X3_BLOCKS */ {"UDASEG_WGRAD_X3_BLOCKS", K_INT, 1024},
+    /* 11 WGRAD_BLOCKS */ {"UDASEG_WGRAD_BLOCKS", K_INT, 0},
+    /* 12 WGRAD_NO_XCD */ {"UDASEG_WGRAD_NO_XCD", K_FLAG, 0},
+    /* 13 WGRAD_X3 */ {"UDASEG_WGRAD_X3", K_OFF0, 1},
+    /* 14 NO_WGRAD_HALO */ {"UDASEG_NO_WGRAD_HALO", K_FLAG, 0},
+    /* 15 WGRAD_F3_BLOCKS */ {"UDASEG_WGRAD_F3_BLOCKS", K_INT, 120},
+    /* 16 WGRAD_HALO_BLOCKS */ {"UDASEG_WGRAD_HALO_BLOCKS", K_INT, 96},
+    /* 17 WGRAD_DEEP_BLOCKS */ {"UDASEG_WGRAD_DEEP_BLOCKS", K_INT, 0},
+    /* 18 WGRAD_DB */ {"UDASEG_WGRAD_DB", K_INT, 1},
+    /* 19 REDUCE_BLOCKS */ {"UDASEG_REDUCE_BLOCKS", K_INT, 0},
+    /* 20 BN_APPLY_PT */ {"UDASEG_BN_APPLY_PT", K_INT, 4},
+    /* 21 GEMM_1X1_TILE */ {"UDASEG_GEMM_1X1_TILE", K_INT, 0},
+    /* 22 GEMM_1X1 */ {"UDASEG_GEMM_1X1", K_OFF0, 1},
+    /* 23 GEMM_1X1_MAXM */ {"UDASEG_GEMM_1X1_MAXM", K_INT, 73728},
+    /* 24 NO_STREAM */ {"UDASEG_NO_STREAM", K_FLAG, 0},
+    /* 25 HALO_CFG */ {"UDASEG_HALO_CFG", K_INT, 0},
+    /* 26 NO_HALO */ {"UDASEG_NO_HALO", K_FLAG, 0},
+    /* 27 NO_HALO_S2 */ {"UDASEG_NO_HALO_S2", K_FLAG, 0},
+    /* 28 HALO_W16 */ {"UDASEG_HALO_W16", K_INT, 6},
+    /* 29 HALO_DEEP */ {"UDASEG_HALO_DEEP", K_OFF0, 1},
+    /* 30 HALO_S2_CK */ {"UDASEG_HALO_S2_CK", K_INT, 64},
+    /* 31 UP_CFG */ {"UDASEG_UP_CFG", K_INT, 0},
+    /* 32 WGRAD_UP_BLOCKS */ {"UDASEG_WGRAD_UP_BLOCKS", K_INT, 0}};
+int g_opt_val[UDASEG_OPT_COUNT];
+static int g_opt_default[UDASEG_OPT_COUNT];
+std::atomic<bool> g_opt_ready{false};
+static std::atomic<int> g_opt_epoch{0};
+static std::mutex g_opt_mutex;
+void opt_init() {
+  std::lock_guard<std::mutex> lk(g_opt_mutex);
+  if (g_opt_ready.load(std::memory_order_relaxed)) return;
+  for (int k = 0; k < UDASEG_OPT_COUNT; ++k) {
+    const OptRow& r = g_opt_rows[k];
+    const char* e = getenv(r.env);
+    int v = r.dflt;
+    if (r.kind == K_INT) v = e ? atoi(e) : r.dflt;
+    else if (r.kind == K_FLAG) v = e != nullptr ? 1 : 0;
+    else v = (e && atoi(e) == 0) ? 0 : 1;
+    g_opt_default[k] = g_opt_val[k] = v;
+  }
+  g_opt_ready.store(true, std::memory_order_release);
 }
+}  // namespace udaseg
 
 extern "C" int udaseg_set_option(int key, int value) {
-  UDASEG_CHECK_ARG(key == UDASEG_OPT_GENERIC_GATHER || key == UDASEG_OPT_F32_SPLIT, "set_option: unknown key %d", key);
-  UDASEG_CHECK_ARG(value >= -1 && value <= 1, "set_option: value must be -1 (environment default), 0 or 1");
-  if (key == UDASEG_OPT_GENERIC_GATHER) udaseg::g_opt_generic_gather = value;
-  else udaseg::g_opt_f32_split = value;
+  UDASEG_CHECK_ARG(key >= 0 && key < UDASEG_OPT_COUNT, "set_option: unknown key %d (0 .. %d)", key, UDASEG_OPT_COUNT - 1);
+  UDASEG_CHECK_ARG(value >= -1, "set_option: value must be >= 0, or -1 for the default");
+  udaseg::opt_get(key);           // the defaults are in place
+  std::lock_guard<std::mutex> lk(udaseg::g_opt_mutex);
+  udaseg::g_opt_val[key] = value < 0 ? udaseg::g_opt_default[key] : value;
+  if (key == UDASEG_OPT_GENERIC_GATHER)      // one key for both gather loops, as before the table existed
+    udaseg::g_opt_val[UDASEG_OPT_WGRAD_GENERIC] = value < 0 ? udaseg::g_opt_default[UDASEG_OPT_WGRAD_GENERIC] : value;
+  udaseg::g_opt_epoch.fetch_add(1);
   return UDASEG_OK;
 }
+
+extern "C" int udaseg_get_option(int key) {
+  if (key < 0 || key >= UDASEG_OPT_COUNT) return -1;
+  return udaseg::opt_get(key);
+}
+
+extern "C" int udaseg_option_count(void) { return UDASEG_OPT_COUNT; }
+extern "C" const char* udaseg_option_name(int key) { return key >= 0 && key < UDASEG_OPT_COUNT ? udaseg::g_opt_rows[key].env : ""; }
+extern "C" int udaseg_option_epoch(void) { return udaseg::g_opt_epoch.load(); }
 
 extern "C" int udaseg_prof_kernel_count(void) { return g_nkernels; }
 extern "C" const char* udaseg_prof_kernel_name(int kid) { return kname(kid); }

@@ -8,13 +8,11 @@
 #include <atomic>
 
 #include "../../include/udaseg.h"
+#include "options.h"
 
 namespace udaseg {
 
 void set_error(const char* fmt, ...);
-// runtime switches (udaseg_set_option): -1 = take the environment default
-extern int g_opt_generic_gather;   // 1: igemm / wgrad keep the generic gather loops (cross-check of the uniform paths)
-extern int g_opt_f32_split;        // 0: shared-source fp32 kernels stay on the fp32 matrix pipe (udaseg_set_option)
 int hip_fail(hipError_t e, const char* what);
 
 #define UDASEG_CHECK_ARG(cond, ...)                 \
@@ -102,13 +100,9 @@ __device__ __forceinline__ void block_fold_atomic(const T (&v)[V], T* __restrict
 // cost ~130 us per launch (measured, profiles/r01_kernel_stats_first.csv); 512 blocks over 16 replicas = 32 per address.
 constexpr int BN_REPLICAS = 16;
 constexpr int REDUCE_MAX_BLOCKS = 512;
-static inline int reduce_max_blocks() {   // UDASEG_REDUCE_BLOCKS: measurement override of the cap above
-  static const int v = [] {
-    const char* e = getenv("UDASEG_REDUCE_BLOCKS");
-    const int x = e ? atoi(e) : 0;
-    return x > 0 ? x : REDUCE_MAX_BLOCKS;
-  }();
-  return v;
+static inline int reduce_max_blocks() {   // UDASEG_OPT_REDUCE_BLOCKS: measurement override of the cap above
+  const int x = opt_get(UDASEG_OPT_REDUCE_BLOCKS);
+  return x > 0 ? x : REDUCE_MAX_BLOCKS;
 }
 
 // dgrad weight repack w[co][t][ci] -> wt[ci][t][co] of one table row, as 32x32 tile transposes through LDS: 128-byte row
@@ -207,13 +201,8 @@ static inline StreamShape stream_shape(int64_t n4, int c4, int max_blocks = 2048
 // ~6-7 us device time (tools/bn_bandwidth.py's 14 us floor is the host's launch rate) and the step is best at 4 (977 against 972
 // images/s at 16, same box).
 static inline int apply_per_thread() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("UDASEG_BN_APPLY_PT");
-    v = e ? atoi(e) : 4;
-    if (v < 1 || v > 256) v = 4;
-  }
-  return v;
+  const int v = opt_get(UDASEG_OPT_BN_APPLY_PT);
+  return (v < 1 || v > 256) ? 4 : v;
 }
 
 // small-channel direct 3x3 kernels (conv_small.hip)

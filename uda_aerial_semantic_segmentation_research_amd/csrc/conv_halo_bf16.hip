@@ -1267,11 +1267,7 @@ static int launch_gemm(HaloArgs a, hipStream_t s, double flops) {
   // 256 x 128 tiles while they occupy at least half the CUs; 128 x 128 below that (r50's 24^2 stage, 2048 -> 512: 72 tiles).
   // Stand-alone, us (tools/gemm1x1_probe.py, profiles/r04_gemm_1x1.txt), 256- / 128-pixel tiles: M 18432 K 1024 N 256 22.0 / 27.2;
   // M 4608 K 2048 N 512 30.7 / 23.6; M 4608 K 512 N 2048 26.8 / 27.7; M 73728 K 128 N 512 45.4 / 53.0
-  static int force = -1;      // UDASEG_GEMM_1X1_TILE = 128 | 256 (A/B)
-  if (force < 0) {
-    const char* e = getenv("UDASEG_GEMM_1X1_TILE");
-    force = e ? atoi(e) : 0;
-  }
+  const int force = opt_get(UDASEG_OPT_GEMM_1X1_TILE);      // 128 | 256 (A/B)
   const long long t256 = cdiv64((long long)a.n * a.h * a.w, 256) * cdiv(a.co, 128);
   const bool small = force == 128 || (force != 256 && t256 < 128);
   return small ? launch_gemm_t<1>(a, s, flops) : launch_gemm_t<2>(a, s, flops);
@@ -1281,14 +1277,8 @@ static int launch_gemm(HaloArgs a, hipStream_t s, double flops) {
 // transform of the gathered tensor (LDS-DMA moves bytes), and -- UDASEG_GEMM_1X1_MAXM, default 73728 = r50's 96^2 stage at batch 8 --
 // few enough pixels that the streaming kernel's one-tile-per-CU schedule is latency-bound.  UDASEG_GEMM_1X1=0: never (A/B).
 static bool gemm_applicable(const HaloArgs& a) {
-  static int on = -1;
-  static long long maxm = 0;
-  if (on < 0) {
-    const char* e = getenv("UDASEG_GEMM_1X1");
-    on = (e && atoi(e) == 0) ? 0 : 1;
-    const char* m = getenv("UDASEG_GEMM_1X1_MAXM");
-    maxm = m ? atoll(m) : 73728;
-  }
+  const int on = opt_get(UDASEG_OPT_GEMM_1X1);
+  const long long maxm = opt_get(UDASEG_OPT_GEMM_1X1_MAXM);
   // expanding layers below 512 gathered channels are bound by their output stream, which the streaming kernel writes as well:
   // 128 -> 512 at 96^2 45.1 us here against 38.6, 256 -> 1024 at 48^2 33.7 against 32.4 (profiles/r04_gemm_1x1.txt)
   if (a.co > a.ci && a.ci < 512) return false;
@@ -1298,8 +1288,7 @@ static bool gemm_applicable(const HaloArgs& a) {
 
 // The streamer takes the plain 1x1 launches: bf16 output, no fused decoder input, no split.
 static bool stream_applicable(const HaloArgs& a, int ks) {
-  static int off = -1;   // UDASEG_NO_STREAM=1: 1x1 layers stay on the tile kernel (A/B)
-  if (off < 0) off = getenv("UDASEG_NO_STREAM") != nullptr ? 1 : 0;
+  const int off = opt_get(UDASEG_OPT_NO_STREAM);   // 1: 1x1 layers stay on the tile kernel (A/B)
   return !off && ks == 1 && !a.out_f32 && a.up_ca == 0 && a.split_n == 0 && a.ci % 16 == 0;
 }
 
@@ -1315,23 +1304,15 @@ static int launch_stream(HaloArgs a, hipStream_t s, double flops) {
 }
 
 static int halo_cfg_override() {
-  static int v = -1;   // tuning aid: UDASEG_HALO_CFG = 1..n forces one configuration (0 / unset: heuristic)
-  if (v < 0) {
-    const char* e = getenv("UDASEG_HALO_CFG");
-    v = e ? atoi(e) : 0;
-  }
-  return v;
+  return opt_get(UDASEG_OPT_HALO_CFG);   // tuning aid: 1..n forces one configuration (0: heuristic)
 }
 
 // Can this convolution take the halo kernel?  gathered / produced: channel counts of the launch (for a data gradient: co / ci).
 bool halo_applicable(const udaseg_conv_desc* d, int gathered, int produced, int up_ca) {
-  static int off = -1;   // UDASEG_NO_HALO=1: keep every layer on the shared implicit-GEMM source (A/B, cross-check)
-  if (off < 0) off = getenv("UDASEG_NO_HALO") != nullptr ? 1 : 0;
-  if (off) return false;
+  if (opt_get(UDASEG_OPT_NO_HALO)) return false;   // 1: keep every layer on the shared implicit-GEMM source (A/B, cross-check)
   if (d->kh == 4 && d->kw == 4 && d->stride == 2 && d->pad == 1) {
     // the discriminator's convolutions, as 2 x 2 windows over parity phases (forward) / parity classes (data gradient)
-    static int s2off = -1;   // UDASEG_NO_HALO_S2=1: they stay on the shared implicit-GEMM source (A/B)
-    if (s2off < 0) s2off = getenv("UDASEG_NO_HALO_S2") != nullptr ? 1 : 0;
+    const int s2off = opt_get(UDASEG_OPT_NO_HALO_S2);   // 1: they stay on the shared implicit-GEMM source (A/B)
     if (s2off || up_ca != 0 || d->hi % 2 != 0 || d->wi % 2 != 0 || d->ho * 2 != d->hi || d->wo * 2 != d->wi) return false;
     if (d->ci % 8 != 0 || d->co % 8 != 0 || (d->ci & (d->ci - 1)) != 0) return false;      // real input channels: a power of two
     const long long pin = (long long)d->n * d->hi * d->wi, pout = (long long)d->n * d->ho * d->wo;
@@ -1371,8 +1352,7 @@ static int halo_choice(int ks, int h, int w, int n, int gathered, int produced, 
   if (ov > 0) return ov > 6 ? 3 : ov;
   const long long tiles = (long long)n * cdiv(h, 8) * cdiv(w, 32);
   if (ks == 1) {
-    static int off = -1;       // UDASEG_NO_STREAM=1 (A/B): without the streaming kernel only the expanding gradients pay
-    if (off < 0) off = getenv("UDASEG_NO_STREAM") != nullptr ? 1 : 0;
+    const int off = opt_get(UDASEG_OPT_NO_STREAM);       // 1 (A/B): without the streaming kernel only the expanding gradients pay
     if (off && (!dgrad || produced <= gathered)) return 0;
     return produced >= 128 ? 3 : 2;      // every 1x1 / stride 1 layer: conv1x1_stream_bf16_kernel (launch_halo routes it)
   }
@@ -1383,11 +1363,7 @@ static int halo_choice(int ks, int h, int w, int n, int gathered, int produced, 
     // outside the image; 8 x 16-pixel tiles x 64 channels instead (1.0 LDS reads per MFMA against 0.75, but no dead columns and
     // twice the blocks on a launch that had ~1 per CU): r50 step 18.44 -> 18.13 ms; 16 x 16 tiles 18.24, x 128 channels 18.37
     // (profiles/r03_halo_variants.txt).  UDASEG_HALO_W16 = 0 | 4 | 5 | 6 overrides.
-    static int w16 = -1;
-    if (w16 < 0) {
-      const char* e = getenv("UDASEG_HALO_W16");
-      w16 = e ? atoi(e) : 6;
-    }
+    const int w16 = opt_get(UDASEG_OPT_HALO_W16);
     if (w16 >= 4 && w16 <= 6 && gathered % 32 == 0 && w % 32 != 0 && w % 16 == 0 &&
         (long long)n * cdiv(h, 8) * cdiv(w, 16) * cdiv(produced, 64) >= 256)
       return w16;
@@ -1399,11 +1375,7 @@ static int halo_choice(int ks, int h, int w, int n, int gathered, int produced, 
     // reaches 256 blocks and at most a quarter of its columns are outside the image.  Forward, us per launch, this tile / the shared
     // source (tools/halo_deep_probe.py, profiles/r04_halo_deep.txt): 256 -> 256 at 8 x 32^2 19.5 / 24.0, 768 -> 256 at 32^2
     // 44.7 / 54.3, 512 -> 512 at 24^2 43.6 / 48.1; 512 -> 512 at 16^2 (128 blocks) 29.7 / 28.7 stays on the shared source
-    static int deep = -1;      // UDASEG_HALO_DEEP=0 (A/B)
-    if (deep < 0) {
-      const char* e = getenv("UDASEG_HALO_DEEP");
-      deep = (e && atoi(e) == 0) ? 0 : 1;
-    }
+    const int deep = opt_get(UDASEG_OPT_HALO_DEEP);      // 0 (A/B)
     const int wt = cdiv(w, 16);
     if (deep && gathered % 32 == 0 && 4 * w >= 3 * 16 * wt && (long long)n * cdiv(h, 8) * wt * cdiv(produced, 64) >= 256) return 6;
   }
@@ -1416,11 +1388,7 @@ int launch_halo(const udaseg_conv_desc* d, HaloArgs a, hipStream_t s, bool dgrad
     // are the launch's (virtual) channel counts; the FLOPs of the whole convolution are booked by the caller
     const double fl = 2.0 * (double)a.n * a.h * a.w * (double)a.co * (double)a.ci * 4.0 * (a.ncls > 1 ? a.ncls : 1);
     if (a.ci % 32 != 0) { set_error("conv_halo (4x4 / stride 2): gathered channels must be a multiple of 32"); return UDASEG_E_UNSUPPORTED; }
-    static int ck64 = -1;       // UDASEG_HALO_S2_CK = 32 | 64 (A/B): channels per staged chunk
-    if (ck64 < 0) {
-      const char* e = getenv("UDASEG_HALO_S2_CK");
-      ck64 = (e && atoi(e) == 32) ? 0 : 1;
-    }
+    const int ck64 = opt_get(UDASEG_OPT_HALO_S2_CK) == 32 ? 0 : 1;       // 32 | 64 (A/B): channels per staged chunk
     if (ck64 && a.ci % 64 == 0) {
       if (a.co <= 64) return launch_halo_t<2, 64, 2, 2, 4, 32>(a, s, fl);
       return launch_halo_t<2, 64, 2, 4, 4, 32>(a, s, fl);

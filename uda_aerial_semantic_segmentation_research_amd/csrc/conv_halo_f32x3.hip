@@ -834,14 +834,7 @@ static int launch_f3_t(F3Args a, hipStream_t s, double flops) {
   return UDASEG_OK;
 }
 
-static int f3_enabled() {
-  static int v = -1;   // UDASEG_F32_SPLIT=0: every fp32 layer stays on the fp32-MFMA kernels (A/B, cross-check)
-  if (v < 0) {
-    const char* e = getenv("UDASEG_F32_SPLIT");
-    v = (e && atoi(e) == 0) ? 0 : 1;
-  }
-  return v;
-}
+static int f3_enabled() { return f32_halo_enabled() ? 1 : 0; }      // UDASEG_OPT_F32_HALO = 0: every fp32 layer on the fp32-MFMA kernels
 
 // gathered / produced: channel counts of the launch (for a data gradient: co / ci)
 static bool f3_applicable(const udaseg_conv_desc* d, int gathered, int produced, int up_ca) {
@@ -856,13 +849,9 @@ static bool f3_applicable(const udaseg_conv_desc* d, int gathered, int produced,
 
 // 0: leave the layer to the fp32-MFMA kernels; 1: 8 x 32 pixels x 32 channels per block; 2: 8 x 32 x 64 channels (forced only);
 // 3: 4 x 32 pixels x 64 channels
-static int g_f3_force = -1;   // udaseg_f32x3_force_config / UDASEG_F3_CFG = 1 | 2: one configuration for every launch
 static int f3_choice(int h, int w, int n, int gathered, int produced) {
-  if (g_f3_force < 0) {
-    const char* e = getenv("UDASEG_F3_CFG");
-    g_f3_force = e ? atoi(e) : 0;
-  }
-  if (g_f3_force >= 1 && g_f3_force <= 12) return g_f3_force;
+  const int force = opt_get(UDASEG_OPT_F3_CFG);      // udaseg_f32x3_force_config: one configuration for every launch
+  if (force >= 1 && force <= 12) return force;
   if (w <= 16) return produced >= 64 ? 9 : 0;       // 16-pixel-wide images: 4 x 16 pixel tiles, two image rows per MFMA block
   if (w < 32) return 0;
   const long long tiles = (long long)n * cdiv(h, 8) * cdiv(w, 32);
@@ -872,11 +861,7 @@ static int f3_choice(int h, int w, int n, int gathered, int produced) {
   // 1 / 2 / 3 / 5 / 6): 64 -> 64 at 128^2 70 / 59 / 67 / 64 / 58; 128 -> 128 at 64^2 62 / 66 / 62 / 55 / 53; 256 -> 256 at 32^2
   // 75 / 101 / 74 / 80 / 59; 192 -> 64 at 128^2 179 / 163 / 180 / 158 / 167; 384 -> 128 at 64^2 172 / 179 / 172 / 156 / 160;
   // 768 -> 256 at 32^2 208 / 281 / 207 / 216 / 166 (profiles/r03_f32x3.txt).  Launches too small for that keep 32-channel blocks.
-  static int ws = -1;        // UDASEG_F3_WS=0 (A/B): the one-role kernel everywhere (4 x 32 pixel tiles x 64 channels)
-  if (ws < 0) {
-    const char* e = getenv("UDASEG_F3_WS");
-    ws = (e && atoi(e) == 0) ? 0 : 1;
-  }
+  const int ws = opt_get(UDASEG_OPT_F3_WS);        // 0 (A/B): the one-role kernel everywhere (4 x 32 pixel tiles x 64 channels)
   if (!ws) return tiles * cdiv(produced, 64) >= 256 ? 3 : 1;
   const long long ncb64 = cdiv(produced, 64);
   const long long blocks4 = (long long)n * cdiv(h, 4) * cdiv(w, 32) * ncb64;
@@ -916,8 +901,7 @@ extern "C" int udaseg_pack_frag_batched_f32x3(const float* w32, const float* wt3
 
 extern "C" int udaseg_f32x3_force_config(int cfg) {
   UDASEG_CHECK_ARG(cfg >= 0 && cfg <= 12, "f32x3_force_config: 0 (heuristic), 1 (8 x 32 px x 32 ch), 2 (8 x 32 x 64), 3 (4 x 32 x 64), 4 (16 x 32 x 64), 5 / 6 (wave-specialised 8 / 4 x 32 x 64), 7 / 8 (wave-specialised 8 / 16 x 32 x 32), 9 (wave-specialised 4 x 16 x 64)");
-  g_f3_force = cfg;
-  return UDASEG_OK;
+  return udaseg_set_option(UDASEG_OPT_F3_CFG, cfg);
 }
 
 extern "C" int udaseg_conv_f32x3_ok(const udaseg_conv_desc* d, int dgrad, int up_ca) {

@@ -885,15 +885,7 @@ static int launch_cfg(const IgemmArgs& a, hipStream_t s) {
   return launch_cfg_t<BM, BN, WAVES_M, WAVES_N, false, false, false>(a, s);
 }
 
-static int uniform_off() {
-  if (g_opt_generic_gather >= 0) return g_opt_generic_gather;
-  static int v = -1;   // tuning aid: UDASEG_IGEMM_GENERIC=1 keeps every layer on the generic gather loop
-  if (v < 0) {
-    const char* e = getenv("UDASEG_IGEMM_GENERIC");
-    v = e ? atoi(e) : 0;
-  }
-  return v;
-}
+static int uniform_off() { return opt_get(UDASEG_OPT_GENERIC_GATHER); }      // 1: every layer on the generic gather loop
 
 // Decide whether a fully described launch can take the uniform-tap loop and fill its tables.
 static void finish_args(IgemmArgs& a, long long x_elems, long long w_elems) {
@@ -926,12 +918,7 @@ static void finish_args(IgemmArgs& a, long long x_elems, long long w_elems) {
 
 static int tile_override() {
   // tuning aid: UDASEG_IGEMM_TILE = 1 (128x128) | 2 (128x64) | 3 (64x64) | 4 (128x32); unset/0 = heuristic
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("UDASEG_IGEMM_TILE");
-    v = e ? atoi(e) : 0;
-  }
-  return v;
+  return opt_get(UDASEG_OPT_IGEMM_TILE);
 }
 
 // fp32 launches on the bf16 matrix pipe (conv_igemm_kernel X3): > 32 produced channels.  UDASEG_IGEMM_X3 = 0 (off) | 1 (64 x 64 tile)
@@ -941,12 +928,8 @@ static int tile_override() {
 // 77 / 69 / 81; 1x1 / stride 2 unchanged (24-38 us, latency).  The split is VALU work every block repeats for its A rows AND the weights
 // (88 vector instructions per thread and K-tile beside 12 MFMAs per wave): these layers gain 10-25 %, not the 2.7x of the matrix rate.
 static int x3_tile() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("UDASEG_IGEMM_X3");
-    v = e ? atoi(e) : 1;
-    if (v < 0 || v > 3) v = 1;
-  }
+  int v = opt_get(UDASEG_OPT_IGEMM_X3);
+  if (v < 0 || v > 3) v = 1;
   return f32_split_enabled() ? v : 0;
 }
 template <int BM, int BN, int WAVES_M, int WAVES_N>
@@ -1061,9 +1044,7 @@ constexpr size_t FOLD_SCRATCH_BYTES = 256 << 10;
 static int fold_factor(int kh, int kw, int stride, int pad, int gathered_c, int produced_c, int width, int bf16) {
   if (!bf16 || kh != 3 || kw != 3 || stride != 1 || pad != 1) return 1;
   if (gathered_c != 16 && gathered_c != 32) return 1;
-  static int off = -1;   // UDASEG_NO_FOLD=1: tuning aid / A-B
-  if (off < 0) off = getenv("UDASEG_NO_FOLD") != nullptr ? 1 : 0;
-  if (off) return 1;
+  if (opt_get(UDASEG_OPT_NO_FOLD)) return 1;      // tuning aid / A-B
   const int F = 64 / gathered_c;
   if (width % F != 0 || produced_c % 8 != 0) return 1;
   // F x the multiplications and F x the output columns: measured per layer (r18 8x512^2 bf16, API-level events, folded vs generic

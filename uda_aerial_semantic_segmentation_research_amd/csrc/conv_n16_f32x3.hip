@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_n16_f32x3_kernel(const N16Args
 }
 
 static bool n16_applicable(const udaseg_conv_desc* d, int dgrad) {
-  if (!d || !f32_split_enabled()) return false;
+  if (!d || !f32_halo_enabled()) return false;
   if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->ho != d->hi || d->wo != d->wi) return false;
   const int gathered = dgrad ? d->co : d->ci, produced = dgrad ? d->ci : d->co;
   if (produced != 16 || gathered % 8 != 0 || gathered < 8 || gathered > 32 || d->n <= 0 || d->hi <= 0 || d->wi < 16) return false;

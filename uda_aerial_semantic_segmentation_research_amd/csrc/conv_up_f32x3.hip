@@ -694,7 +694,6 @@ __global__ void pack_up_batched_f32x3_kernel(const float* __restrict__ w32, cons
 }
 
 // ------------------------------------------------------------------------------------------------- host side
-static int g_up_force = 0;      // udaseg_set_option(UDASEG_OPT_UP_CONFIG): 0 = heuristic, 1..: one configuration for every launch
 
 template <int WM, int WN, int RPW, int TW, bool DGRAD>
 static int launch_up_t(UpArgs a, hipStream_t s, double flops) {
@@ -749,7 +748,8 @@ static int launch_up_t(UpArgs a, hipStream_t s, double flops) {
 // traffic, and two channel blocks per workgroup double it per staged halo; the DATA GRADIENT wants the 8 x 32 x 64 tile wherever
 // that still gives a block per CU (43 / 53 us on blocks 2 / 3), 4 x 32 x 64 below that, 32-channel blocks for <= 32 produced.
 static int up_choice(int n, int h, int w, int produced, bool dgrad) {
-  if (g_up_force > 0) return g_up_force;
+  const int force = opt_get(UDASEG_OPT_UP_CFG);      // udaseg_up_f32x3_force_config: one configuration for every launch
+  if (force > 0 && force <= 8) return force;
   if (w <= 16) return 7;
   if (!dgrad || produced <= 32) return 3;
   const long long ncb = cdiv(produced, 64);
@@ -775,7 +775,7 @@ static int launch_up(UpArgs a, hipStream_t s, double flops) {
 }
 
 static bool up_applicable(const udaseg_conv_desc* d, int up_ca) {
-  if (!d || !f32_split_enabled()) return false;
+  if (!d || !f32_halo_enabled()) return false;
   if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->ho != d->hi || d->wo != d->wi) return false;
   if (d->hi % 2 != 0 || d->wi % 2 != 0 || d->hi < 2 || d->wi < 2) return false;
   if (up_ca <= 0 || up_ca > d->ci || up_ca % 16 != 0 || d->co % 4 != 0 || d->ci % 4 != 0) return false;
@@ -790,8 +790,7 @@ using namespace udaseg;
 
 extern "C" int udaseg_up_f32x3_force_config(int cfg) {
   UDASEG_CHECK_ARG(cfg >= 0 && cfg <= 8, "up_f32x3_force_config: 0 (heuristic) .. 8");
-  g_up_force = cfg;
-  return UDASEG_OK;
+  return udaseg_set_option(UDASEG_OPT_UP_CFG, cfg);
 }
 
 extern "C" int udaseg_conv_up_f32x3_ok(const udaseg_conv_desc* d, int up_ca) { return up_applicable(d, up_ca) ? 1 : 0; }

@@ -830,12 +830,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(const WgradArgs a) {
 template <int BMW, int BNW, int WAVES_M, int WAVES_N>
 static int launch_wgrad_x3(WgradArgs a, int accumulate, hipStream_t s) {
   const int tiles = cdiv(a.co, BMW) * cdiv(a.J, BNW);
-  static int target = -1;
-  if (target < 0) {
-    const char* e = getenv("UDASEG_WGRAD_X3_BLOCKS");
-    target = e ? atoi(e) : 1024;
-    if (target < 64) target = 1024;
-  }
+  int target = opt_get(UDASEG_OPT_WGRAD_X3_BLOCKS);
+  if (target < 64) target = 1024;
   int splits = cdiv(target, tiles);
   const int max_splits = cdiv(a.M, 256);
   if (splits > max_splits) splits = max_splits;
@@ -858,9 +854,7 @@ static int launch_wgrad_x3(WgradArgs a, int accumulate, hipStream_t s) {
   constexpr int b_rows = 256 / (BNW / 8);
   const long long xb = (long long)a.M / (a.ho * a.wo) * (a.up ? (a.hi >> 1) * (a.wi >> 1) : a.hi * a.wi) * a.ci * 4,
                   dyb = (long long)a.M * a.co * 4;
-  static int generic = -1;
-  if (generic < 0) generic = getenv("UDASEG_WGRAD_GENERIC") != nullptr ? 1 : 0;
-  a.row_uniform = !(g_opt_generic_gather >= 0 ? g_opt_generic_gather : generic) && a.wo % b_rows == 0 && a.ci % 8 == 0 && a.co % 8 == 0 &&
+  a.row_uniform = !opt_get(UDASEG_OPT_WGRAD_GENERIC) && a.wo % b_rows == 0 && a.ci % 8 == 0 && a.co % 8 == 0 &&
                   xb <= (1LL << 30) && dyb <= (1LL << 30);
   a.x_bytes = (unsigned)xb;
   a.dy_bytes = (unsigned)dyb;
@@ -885,14 +879,9 @@ template <int BMW, int BNW, int WAVES_M, int WAVES_N>
 static int launch_wgrad(WgradArgs a, int accumulate, hipStream_t s, bool bf16 = false) {
   const int tiles = cdiv(a.co, BMW) * cdiv(a.J, BNW);
   // enough blocks for ~4 per CU, at least 256 pixels per split (UDASEG_WGRAD_BLOCKS: tuning aid)
-  static int target = -1;
-  static bool target_from_env = false;   // looked up once (the template's instantiations each keep their own copy)
-  if (target < 0) {
-    const char* e = getenv("UDASEG_WGRAD_BLOCKS");
-    target_from_env = e != nullptr;
-    target = e ? atoi(e) : 3072;  // measured sweep 512..8192: 68.7 / 79.4 / 80.3 / 85.9 / 87.0 / 89.1 / 88.8 / 88.1 TFLOP/s
-    if (target < 64) target = 3072;
-  }
+  int target = opt_get(UDASEG_OPT_WGRAD_BLOCKS);      // 0: the defaults below
+  const bool target_from_env = target >= 64;
+  if (!target_from_env) target = 3072;  // measured sweep 512..8192: 68.7 / 79.4 / 80.3 / 85.9 / 87.0 / 89.1 / 88.8 / 88.1 TFLOP/s
   // bf16: the MFMA phase of a split is 16x shorter, so the fp32 atomics of the partial tiles (blocks x 16 KB at ~1.3 TB/s)
   // are the launch: 512 blocks measured best (r18 8x512^2 step: 256 / 512 / 768 / 1024 / 2048 / 3072 blocks ->
   // 1285 / 1398 / 1366 / 1353 / 1326 / 1285 images/s; r50 768^2: 337 / 344 / 338 / 335 / 336 / 332)
@@ -929,9 +918,7 @@ static int launch_wgrad(WgradArgs a, int accumulate, hipStream_t s, bool bf16 = 
   dim3 grid((unsigned)tiles, (unsigned)splits), block(256);
   a.xcd_tiles = a.xcd_splits = 0;
   if (bf16 && splits % 8 == 0 && tiles > 1) {
-    static int no_remap = -1;      // UDASEG_WGRAD_NO_XCD=1: A/B
-    if (no_remap < 0) no_remap = getenv("UDASEG_WGRAD_NO_XCD") != nullptr ? 1 : 0;
-    if (!no_remap) {
+    if (!opt_get(UDASEG_OPT_WGRAD_NO_XCD)) {      // 1: A/B
       a.xcd_tiles = tiles;
       a.xcd_splits = splits;
       grid = dim3((unsigned)(tiles * splits), 1u);
@@ -942,9 +929,7 @@ static int launch_wgrad(WgradArgs a, int accumulate, hipStream_t s, bool bf16 = 
     constexpr int b_rows16 = 256 / (BNW / 8);
     const long long xb16 = (long long)a.M / (a.ho * a.wo) * (a.up ? (a.hi >> 1) * (a.wi >> 1) : a.hi * a.wi) * a.ci * 2,
                     dyb16 = (long long)a.M * a.co * 2;
-    static int generic16 = -1;
-    if (generic16 < 0) generic16 = getenv("UDASEG_WGRAD_GENERIC") != nullptr ? 1 : 0;
-    a.row_uniform = !(g_opt_generic_gather >= 0 ? g_opt_generic_gather : generic16) && a.wo % b_rows16 == 0 && xb16 <= (1LL << 30) && dyb16 <= (1LL << 30);
+    a.row_uniform = !opt_get(UDASEG_OPT_WGRAD_GENERIC) && a.wo % b_rows16 == 0 && xb16 <= (1LL << 30) && dyb16 <= (1LL << 30);
     a.x_bytes = (unsigned)xb16;
     a.dy_bytes = (unsigned)dyb16;
     if (a.row_uniform)
@@ -961,14 +946,9 @@ static int launch_wgrad(WgradArgs a, int accumulate, hipStream_t s, bool bf16 = 
     kprof_end(kid, ev, s, 2.0 * (double)a.M * a.co * a.J);
   } else {
     constexpr int b_rows = 256 / (BNW / 4);
-    static int generic = -1;   // tuning aid: UDASEG_WGRAD_GENERIC=1 keeps the generic gather loop
-    if (generic < 0) {
-      const char* e = getenv("UDASEG_WGRAD_GENERIC");
-      generic = e ? atoi(e) : 0;
-    }
     const long long xb = (long long)a.M / (a.ho * a.wo) * (a.up ? (a.hi >> 1) * (a.wi >> 1) : a.hi * a.wi) * a.ci * 4,
                     dyb = (long long)a.M * a.co * 4;
-    a.row_uniform = !(g_opt_generic_gather >= 0 ? g_opt_generic_gather : generic) && a.wo % b_rows == 0 && xb <= (1LL << 30) && dyb <= (1LL << 30);
+    a.row_uniform = !opt_get(UDASEG_OPT_WGRAD_GENERIC) && a.wo % b_rows == 0 && xb <= (1LL << 30) && dyb <= (1LL << 30);
     a.x_bytes = (unsigned)xb;
     a.dy_bytes = (unsigned)dyb;
     if (a.row_uniform)
@@ -1000,13 +980,8 @@ static int launch_wgrad(WgradArgs a, int accumulate, hipStream_t s, bool bf16 = 
 
 using namespace udaseg;
 
-static bool wgrad_x3_on() {      // UDASEG_WGRAD_X3=0 (A/B) or UDASEG_F32_SPLIT=0: the fp32-pipe kernel
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("UDASEG_WGRAD_X3");
-    v = (e && atoi(e) == 0) ? 0 : 1;
-  }
-  return v != 0 && udaseg::f32_split_enabled();
+static bool wgrad_x3_on() {      // UDASEG_OPT_WGRAD_X3 = 0 (A/B) or UDASEG_OPT_F32_SPLIT = 0: the fp32-pipe kernel
+  return udaseg::opt_get(UDASEG_OPT_WGRAD_X3) != 0 && udaseg::f32_split_enabled();
 }
 
 // One implementation behind the four entry points.  src_c / c_off / up describe a channel slice of dW (WgradArgs::ci_full):
@@ -1099,13 +1074,9 @@ int launch_wgrad_h2(const udaseg_conv_desc* d, const void* x, const void* x2, in
                     const float* in_scale = nullptr, const float* in_shift = nullptr, int in_act = 0, float in_slope = 0.f,
                     int ldw = 0, int dw_coff = 0);
 static bool wgrad_halo_off(bool f32) {
-  static int off = -1, off3 = -1;   // UDASEG_NO_WGRAD_HALO=1: the per-tap split-K kernels everywhere; UDASEG_F32_SPLIT=0: no fp32 split
-  if (off < 0) {
-    const char* e = getenv("UDASEG_F32_SPLIT");
-    off = getenv("UDASEG_NO_WGRAD_HALO") != nullptr ? 1 : 0;
-    off3 = (off || (e && atoi(e) == 0)) ? 1 : 0;
-  }
-  return f32 ? off3 != 0 : off != 0;
+  // UDASEG_OPT_NO_WGRAD_HALO = 1: the per-tap split-K kernels everywhere; UDASEG_OPT_F32_HALO = 0: no halo-resident fp32 split
+  const bool off = opt_get(UDASEG_OPT_NO_WGRAD_HALO) != 0;
+  return f32 ? (off || !f32_halo_enabled()) : off;
 }
 }  // namespace udaseg
 

@@ -351,11 +351,6 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_h2_kernel(const WgradH2Args
   else wgrad_h2_role<C, 2, 1, true, TL, XF>(a, h2smem, tid, lane, wave);
 }
 
-static int h2_env(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return e ? atoi(e) : dflt;
-}
-
 // which configuration serves (d, up_ca): 0 = none
 //   1: 64 x 64 channel blocks, 4 x 32 pixel tiles (f32x3) / 8 x 32 (bf16)      2: 64 x 64, 8 x 16 pixel tiles (16-pixel-wide images)
 //   3: 32 produced x 64 gathered channels, 4 x 32 (f32x3) / 8 x 32 (bf16)      4: 32 x 32 channels
@@ -484,20 +479,14 @@ int launch_wgrad_h2(const udaseg_conv_desc* d, const void* x, const void* x2, in
   }
   // blocks per launch: few and long-lived (one set of atomics per wave; the kernel runs beside the main stream's chain).
   // UDASEG_WGRAD_F3_BLOCKS / UDASEG_WGRAD_HALO_BLOCKS: tuning aids
-  static int tf3 = -1, tbf = -1, tdeep = -1, tdeep3 = -1;
-  if (tf3 < 0) {
-    tf3 = h2_env("UDASEG_WGRAD_F3_BLOCKS", 120);
-    tbf = h2_env("UDASEG_WGRAD_HALO_BLOCKS", 96);
-    tdeep = h2_env("UDASEG_WGRAD_DEEP_BLOCKS", 256);       // 16-pixel-wide images, bf16
-    tdeep3 = h2_env("UDASEG_WGRAD_DEEP_BLOCKS", 128);      // ... fp32 split: 64 / 96 / 128 / 160 / 256 / 384 blocks -> 979.3 / 980.6 / 987.3 /
-                                                           // 985.5 / 983.5 images/s on one box, 942.1 (128) / 942.3 (192) / 937.1 / 936.9 on another
-    if (tf3 < 1) tf3 = 120;
-    if (tbf < 1) tbf = 96;
-    if (tdeep < 1) tdeep = 256;
-    if (tdeep3 < 1) tdeep3 = 128;
-  }
-  static int db = -1;      // UDASEG_WGRAD_DB=0: the single-buffer 4-row form of the 64 x 64 fp32 configuration (A/B)
-  if (db < 0) db = h2_env("UDASEG_WGRAD_DB", 1);
+  int tf3 = opt_get(UDASEG_OPT_WGRAD_F3_BLOCKS), tbf = opt_get(UDASEG_OPT_WGRAD_HALO_BLOCKS);
+  const int tdeep_o = opt_get(UDASEG_OPT_WGRAD_DEEP_BLOCKS);
+  const int tdeep = tdeep_o >= 1 ? tdeep_o : 256;        // 16-pixel-wide images, bf16
+  const int tdeep3 = tdeep_o >= 1 ? tdeep_o : 128;       // ... fp32 split: 64 / 96 / 128 / 160 / 256 / 384 blocks -> 979.3 / 980.6 / 987.3 /
+                                                         // 985.5 / 983.5 images/s on one box, 942.1 (128) / 942.3 (192) / 937.1 / 936.9 on another
+  if (tf3 < 1) tf3 = 120;
+  if (tbf < 1) tbf = 96;
+  const int db = opt_get(UDASEG_OPT_WGRAD_DB);      // 0: the single-buffer 4-row form of the 64 x 64 fp32 configuration (A/B)
   if (f32) {
     if (cfg == 1 && db) return launch_h2_t<3, 2, 2, 2, 2, 4, true>(d, x, x2, up_ca, dy, dw, s, tf3, in);
     if (cfg == 1) return launch_h2_t<3, 2, 2, 4, 2, 4>(d, x, x2, up_ca, dy, dw, s, tf3, in);
@@ -775,27 +764,24 @@ static int launch_h2up_t(const udaseg_conv_desc* d, const float* a_, int up_ca, 
   return UDASEG_OK;
 }
 
-static int g_wgrad_up_blocks = 0;      // tests / tuning (udaseg_wgrad_up_set_blocks): 0 = the default below
-
 }  // namespace udaseg
 
 using namespace udaseg;
 
 extern "C" int udaseg_conv2d_wgrad_up_f32x3_ok(const udaseg_conv_desc* d, int up_ca) {
-  return f32_split_enabled() && h2up_config(d, up_ca) != 0 ? 1 : 0;
+  return f32_halo_enabled() && h2up_config(d, up_ca) != 0 ? 1 : 0;
 }
 
 extern "C" int udaseg_wgrad_up_set_blocks(int blocks) {
   UDASEG_CHECK_ARG(blocks >= 0 && blocks <= 4096, "wgrad_up_set_blocks: 0 (default) .. 4096");
-  g_wgrad_up_blocks = blocks;
-  return UDASEG_OK;
+  return udaseg_set_option(UDASEG_OPT_WGRAD_UP_BLOCKS, blocks);
 }
 
 // dW[co][9][ci] (rows of d->ci channels, the first up_ca of them) += the weight gradient of conv3x3(nearest_x2(a)) in the phase form
 extern "C" int udaseg_conv2d_wgrad_up_f32x3(const udaseg_conv_desc* d, const float* a, int up_ca, const float* dy, float* dw,
                                             void* stream) {
   UDASEG_CHECK_ARG(d && a && dy && dw, "conv2d_wgrad_up_f32x3: NULL pointer");
-  const int cfg = f32_split_enabled() ? h2up_config(d, up_ca) : 0;
+  const int cfg = f32_halo_enabled() ? h2up_config(d, up_ca) : 0;
   if (cfg == 0) {
     set_error("conv2d_wgrad_up_f32x3: geometry not supported (ask udaseg_conv2d_wgrad_up_f32x3_ok first)");
     return UDASEG_E_UNSUPPORTED;
@@ -803,7 +789,7 @@ extern "C" int udaseg_conv2d_wgrad_up_f32x3(const udaseg_conv_desc* d, const flo
   // blocks per launch: few and long-lived like the nine-tap kernel.  Same-box sweep inside the overlapped step (images/s, phase weight
   // gradient off 983.7 / 996.7): 2 x 16 tiles at 64 / 128 / 256 blocks 995.2 / 990.1-994.4 / 969.7, 1 x 32 tiles at 128 / 256 blocks
   // 984.8 / 966.1 (profiles/r05_up_phase.txt) -- the 16-pixel tile everywhere, 96 blocks
-  const int target = g_wgrad_up_blocks > 0 ? g_wgrad_up_blocks : 96;
+  const int target = opt_get(UDASEG_OPT_WGRAD_UP_BLOCKS) > 0 ? opt_get(UDASEG_OPT_WGRAD_UP_BLOCKS) : 96;
   hipStream_t st = as_stream(stream);
   udaseg_conv_desc dd = *d;
   dd.ci = up_ca;

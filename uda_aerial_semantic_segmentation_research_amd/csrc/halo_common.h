@@ -119,26 +119,15 @@ __host__ __device__ inline void f3_negated_groups(int nk16, int& q1, int& q3) {
   q1 = (ng + 2) / 4;
   q3 = ng - q1;
 }
-inline bool f3_signs_on() {       // UDASEG_F3_SIGNS=0 (A/B, bias measurements): every group positive -- read by the packer AND the kernels
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("UDASEG_F3_SIGNS");
-    v = (e && atoi(e) == 0) ? 0 : 1;
-  }
-  return v != 0;
+inline bool f3_signs_on() {       // UDASEG_OPT_F3_SIGNS = 0 (A/B, bias measurements): every group positive -- read by the packer AND the kernels
+  return opt_get(UDASEG_OPT_F3_SIGNS) != 0;
 }
 
-// UDASEG_F32_SPLIT=0: every fp32 layer stays on the fp32-MFMA kernels (A/B, cross-check); udaseg_set_option(UDASEG_OPT_F32_SPLIT)
-// overrides it for the shared-source kernels that ask here
-inline bool f32_split_enabled() {
-  if (g_opt_f32_split >= 0) return g_opt_f32_split != 0;
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("UDASEG_F32_SPLIT");
-    v = (e && atoi(e) == 0) ? 0 : 1;
-  }
-  return v != 0;
-}
+// The environment's UDASEG_F32_SPLIT=0 is the default of TWO keys: UDASEG_OPT_F32_SPLIT (the shared-source kernels' three-term
+// mode: conv_igemm X3, conv_wgrad_x3) and UDASEG_OPT_F32_HALO (whether the halo-resident three-term kernels report themselves
+// applicable).  Tests switch the first off alone to grade the second against the fp32 pipe on the same launch.
+inline bool f32_split_enabled() { return opt_get(UDASEG_OPT_F32_SPLIT) != 0; }
+inline bool f32_halo_enabled() { return opt_get(UDASEG_OPT_F32_HALO) != 0; }
 
 // f64 partial-sum scratch of launches with more than 1024 blocks (udaseg_set_stats_scratch): the current device's, when it holds
 // HALO_SCR_REPLICAS x 2 x co doubles, else nullptr; and the launch that folds it into the [R][2][co] accumulators

@@ -541,6 +541,9 @@ class Plan:
         self._packed = None
         self._bnb = {}                    # id(conv output y) -> BN-backward sums already made by the consumer's data gradient
         self._producer = {}               # id(activation) -> the conv+BN+activation record that produced it (decoder block outputs)
+        # the library's switchboard may change between two plans of one network (udaseg_set_option, the force_config entry points:
+        # tests, tuning): every cached routing answer below is keyed with the number of overrides made so far
+        self.epoch = K.option_epoch()
         self._wgrad_halo = USE_WGRAD_HALO and (self.bf16 or USE_F32_SPLIT)      # halo-resident weight gradients (bf16 / fp32 split)
         if training and save and SIDE_STREAM_WGRAD and PREPACK_DGRAD:
             self._prepack_dgrad_weights()
@@ -598,7 +601,7 @@ class Plan:
         # view cached with it (two ctypes calls and a slice per convolution and direction otherwise: host time, and cfg 3 runs close
         # to the host's launch rate)
         cache = self.net.__dict__.setdefault("_wfrag_cache", {})
-        key = (id(conv), d.n, d.hi, d.wi, d.ci, d.co, bool(dgrad), up_ca, FRAG_POLICY, self.bf16)
+        key = (id(conv), d.n, d.hi, d.wi, d.ci, d.co, bool(dgrad), up_ca, FRAG_POLICY, self.bf16, self.epoch)
         hit = cache.get(key)
         if hit is not None and hit[0] is self.net._frag_arena:
             return hit[1]
@@ -619,7 +622,7 @@ class Plan:
         if ent is None or up_ca != conv.up_ca:
             return None
         cache = self.net.__dict__.setdefault("_upfrag_cache", {})
-        key = (id(conv), d.n, d.hi, d.wi, d.ci, d.co)
+        key = (id(conv), d.n, d.hi, d.wi, d.ci, d.co, self.epoch)
         hit = cache.get(key)
         if hit is not None and hit[0] is self.net._frag_arena:
             return hit[1]
@@ -638,7 +641,7 @@ class Plan:
         if ent is None or key2 not in ent:
             return None
         cache = self.net.__dict__.setdefault("_n16_cache", {})
-        key = (id(conv), d.n, d.hi, d.wi, d.ci, d.co, bool(dgrad))
+        key = (id(conv), d.n, d.hi, d.wi, d.ci, d.co, bool(dgrad), self.epoch)
         hit = cache.get(key)
         if hit is not None and hit[0] is self.net._frag_arena:
             return hit[1]
@@ -700,7 +703,7 @@ class Plan:
         cache = self.net.__dict__.setdefault("_lazy_cache", {})
         key = (id(consumer), c, n, ho, wo, act, residual is None, up, self.bf16, FUSE_BN_APPLY, FUSE_BN_APPLY_1X1_ONLY, FUSE_BN_REDUCE,
                FUSE_BN_APPLY_F32, FUSE_BN_APPLY_F32_SMALL_ONLY, FUSE_BN_APPLY_F32_UP, FUSE_BN_APPLY_F32_WRITE, USE_F32_SPLIT, FRAG_POLICY,
-               self.frag)
+               self.frag, self.epoch)
         v = cache.get(key)
         if v is None:
             v = cache[key] = self._lazy_ok_uncached(c, n, ho, wo, consumer, act, residual, up)
@@ -864,7 +867,7 @@ class Plan:
         if self.bf16 or not (USE_UP_PHASE and USE_UP_PHASE_WGRAD and self._wgrad_halo and USE_F32_SPLIT) or isinstance(x.a, LazyAct):
             return False
         cache = self.net.__dict__.setdefault("_wgup_cache", {})
-        key = (id(conv), d.n, d.hi, d.wi, d.ci, d.co, x.a.shape[-1])
+        key = (id(conv), d.n, d.hi, d.wi, d.ci, d.co, x.a.shape[-1], self.epoch)
         v = cache.get(key)
         if v is None:
             v = K.conv2d_wgrad_up_ok(d, x.a.shape[-1])

@@ -722,14 +722,31 @@ def axpy(y, x, alpha=1.0, st=None):
           "axpy_f32")
 
 
+def set_option(name, value):
+    """Override one switch of the library's switchboard (``_lib.OPTIONS``: name -> UDASEG_OPT_* key; the environment variable of the
+    same name is only its default); value -1 restores the default.  Every override bumps ``option_epoch()``."""
+    key = _lib.OPTIONS[name] if isinstance(name, str) else int(name)
+    check(ops.udaseg_set_option(key, int(value)), f"set_option({name})")
+
+
+def get_option(name):
+    key = _lib.OPTIONS[name] if isinstance(name, str) else int(name)
+    return int(ops.udaseg_get_option(key))
+
+
+def option_epoch():
+    """Number of overrides made so far: the plans key their cached routing answers with it (engine.Plan)."""
+    return int(ops.udaseg_option_epoch())
+
+
 def set_generic_gather(value):
     """1: convolution kernels keep their generic gather loops; 0: uniform-tap / row-uniform loops allowed; -1: environment."""
-    check(ops.udaseg_set_option(0, int(value)), "set_option")
+    set_option("GENERIC_GATHER", value)
 
 
 def set_f32_split(value):
     """0: the shared-source fp32 kernels stay on the fp32 matrix pipe; 1: three-term bf16 split allowed; -1: environment."""
-    check(ops.udaseg_set_option(1, int(value)), "set_option")
+    set_option("F32_SPLIT", value)
 
 
 def prof_enable(on):
