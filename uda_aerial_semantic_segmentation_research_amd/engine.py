@@ -54,6 +54,11 @@ USE_UP_PHASE_WGRAD = os.environ.get("UDASEG_UP_PHASE_WGRAD", "0") == "1"
 # fp32 storage (round 5): 3x3 layers that produce exactly 16 channels (decoder block 4 conv2 forward / data gradient, the head's data
 # gradient) on the sixteen-wide matrix tile (csrc/conv_n16_f32x3.hip).  UDASEG_N16=0: the 32-row tile (A/B, cross-check)
 USE_N16 = os.environ.get("UDASEG_N16", "1") != "0"
+# fp32 storage, phase form: the skip half of a decoder conv1 is a convolution of an ENCODER feature alone -- it is launched on the side
+# stream as soon as that feature exists and runs beside the rest of the encoder / the earlier decoder blocks (the forward has no other
+# side-stream work; its many small BatchNorm launches leave most of the chip idle).  UDASEG_PRELAUNCH_SKIP=0: on the main stream, in
+# program order (A/B)
+PRELAUNCH_SKIP = os.environ.get("UDASEG_PRELAUNCH_SKIP", "1") != "0"
 
 
 # bf16 storage: BatchNorm + activation of a layer whose ONLY consumer is a convolution on the bf16-first kernels is not written at
@@ -541,6 +546,7 @@ class Plan:
         self._packed = None
         self._bnb = {}                    # id(conv output y) -> BN-backward sums already made by the consumer's data gradient
         self._producer = {}               # id(activation) -> the conv+BN+activation record that produced it (decoder block outputs)
+        self._pre = {}                    # id(decoder conv1) -> (y holding its skip half, side stream handle): prelaunch_skip
         # the library's switchboard may change between two plans of one network (udaseg_set_option, the force_config entry points:
         # tests, tuning): every cached routing answer below is keyed with the number of overrides made so far
         self.epoch = K.option_epoch()
@@ -612,6 +618,24 @@ class Plan:
             view = self.net._frag_arena[o:o + n]
         cache[key] = (self.net._frag_arena, view)
         return view
+
+    def prelaunch_skip(self, conv, skip, up_ca):
+        """Start the skip half of decoder conv1 ``conv`` (phase form) on the side stream now: y = conv3x3(skip, W[:, up_ca:]).  Called
+        by the network as soon as the encoder feature ``skip`` exists; conv_bn_act picks the result up (self._pre)."""
+        if not (PRELAUNCH_SKIP and SIDE_STREAM_WGRAD and self.training and self.save and skip is not None):
+            return
+        n, h, w, cs = skip.shape
+        d = K.conv_desc(n, h, w, up_ca + cs, conv.cout_p, 3, 1, 1)
+        upw = self.up_frag(conv, d, up_ca)
+        if upw is None or "skip_fwd" not in upw:
+            return
+        side = self.net._side_stream()
+        y = torch.empty((n, h, w, conv.cout_p), device=skip.device, dtype=self.adt)
+        K.stream_wait(side.cuda_stream, self.st)             # the feature (and y's allocation) are ordered before the launch
+        y.record_stream(side)
+        skip.record_stream(side)
+        K.conv2d_fwd_frag(K.conv_desc(n, h, w, cs, conv.cout_p, 3, 1, 1), skip, None, upw["skip_fwd"], None, y, st=side.cuda_stream)
+        self._pre[id(conv)] = (y, side.cuda_stream)
 
     def up_frag(self, conv, d, up_ca):
         """The phase packings of a decoder conv1 ({"up_fwd", "up_bwd"[, "skip_fwd", "skip_bwd"]} -> views of the fragment arena) when
@@ -766,15 +790,19 @@ class Plan:
         bias = self.b(conv) if conv.bias is not None else None
         if self.training:
             d = K.conv_desc(n, h, w, ci, conv.cout_p, conv.k, conv.stride, conv.pad)
-            y = torch.empty((n, d.ho, d.wo, conv.cout_p), device=dev, dtype=self.adt)
+            pre = self._pre.pop(id(conv), None) if up else None
+            y = pre[0] if pre is not None else torch.empty((n, d.ho, d.wo, conv.cout_p), device=dev, dtype=self.adt)
             sums = self._next_stats(ceil4(bn.c))
             wf = self.wfrag(conv, d, up_ca=x.a.shape[3] if up else 0)
             upw = self.up_frag(conv, d, x.a.shape[3]) if (up and not isinstance(x.a, LazyAct)) else None
+            if pre is not None:
+                assert upw is not None and x.skip is not None and tuple(y.shape) == (n, d.ho, d.wo, conv.cout_p)
+                K.stream_wait(self.st, pre[1])                 # the skip half, started on the side stream when its feature appeared
             if upw is not None:
                 # phase form: the skip half as a plain 3x3 convolution of its own, the up-sampled half (4 taps per phase) on top,
                 # BatchNorm statistics of the sum in the second launch's epilogue
                 assert bias is None
-                if x.skip is not None:
+                if x.skip is not None and pre is None:
                     ds = K.conv_desc(n, h, w, x.skip.shape[3], conv.cout_p, 3, 1, 1)
                     K.conv2d_fwd_frag(ds, x.skip, None, upw["skip_fwd"], None, y, st=self.st)
                 K.conv2d_fwd_up(d, x.a, upw["up_fwd"], y, accumulate=x.skip is not None, stats=sums[0], st=self.st)

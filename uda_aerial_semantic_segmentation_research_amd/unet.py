@@ -328,11 +328,22 @@ class Unet(ArenaModule):
         pooled, pidx = K.maxpool_fwd(f1, P.st)
         feats = [f1]
         h = pooled
-        for stage in enc.stages():
+        dblocks = self.decoder.blocks
+        nskip = len(enc.out_channels) - 2             # features f1 .. f4 are skip inputs of decoder blocks 3 .. 0
+
+        def prelaunch(fi):
+            # feature fi (0 = f1) feeds decoder block nskip - 1 - fi as its skip input: its half of that block's conv1 starts now
+            bi = nskip - 1 - fi
+            if FUSE_UPCAT and 0 <= bi < len(dblocks) and dblocks[bi].upsample == "nearest" and not isinstance(feats[fi], LazyAct):
+                P.prelaunch_skip(dblocks[bi].conv1[0], feats[fi], dblocks[bi].conv1[0].up_ca)
+        prelaunch(0)
+        for si, stage in enumerate(enc.stages()):
             for blk in stage:
                 h, rec = blk.fwd(P, h)
                 tape.append((blk, rec, h))
             feats.append(h)
+            if si + 1 < nskip:
+                prelaunch(si + 1)
         skips = feats[:-1][::-1]                  # f4, f3, f2, f1
         head = self.segmentation_head[0]
         nblk = len(self.decoder.blocks)
