@@ -38,6 +38,7 @@ echo "pmc sq done"
 # in-kernel timelines of the two dominant split kernels, the 1x1 kernels stand-alone, and the one-GPU rehearsal of the RCCL path
 python3 $ROOT/tools/wgrad_timeline.py > $OUT/${TAG}_wgrad_timeline.txt 2>&1
 python3 $ROOT/tools/f3_timeline.py > $OUT/${TAG}_f3_timeline.txt 2>&1
+python3 $ROOT/tools/up_probe.py > $OUT/${TAG}_up_probe.txt 2>&1
 python3 $ROOT/tools/gemm1x1_probe.py 2>&1 | grep "M=" > $OUT/${TAG}_gemm1x1_probe.txt
 UDASEG_GEMM_1X1=0 python3 $ROOT/tools/gemm1x1_probe.py 2>&1 | grep "M=" > $OUT/${TAG}_gemm1x1_probe_stream_only.txt
 python3 $ROOT/tools/x3_bias_check.py 2>&1 | grep "l2" > $OUT/${TAG}_mfma_bias.txt
