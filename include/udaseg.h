@@ -549,17 +549,6 @@ int udaseg_conv2d_wgrad_halo_slice_f32x3(const udaseg_conv_desc* d, const float*
 /* tests / tuning: blocks per launch of the phase-form weight gradient (0 = the default, 128) */
 int udaseg_wgrad_up_set_blocks(int blocks);
 
-/* The same two kernels as the encoder's 3x3 / STRIDE 2 / pad 1 layers (torchvision BasicBlock.conv1 / Bottleneck.conv2 of the first
- * block of layer2-4): the forward reads the four parity phases of x through the data-gradient kernel's space-to-depth gather with 9
- * of its 16 tap slots, the data gradient writes the four parity phases of dx from 9 of the forward kernel's 16 slots (the other
- * slots are skipped).  Packings: udaseg_pack_up_batched_f32x3 mode 6 (forward, from w32 OHWI [co][9][ci]: 3 * frag_elems(co, ci, 4))
- * and mode 7 (data gradient, from wt32 [ci][9][co]: 3 * frag_elems(ci, co, 4)).  ci and co multiples of 8, even extents.
- * Replaces udaseg_conv2d_fwd_bnstats / udaseg_conv2d_dgrad (conv_igemm_kernel X3) on those layers. */
-int udaseg_conv_s2_f32x3_ok(const udaseg_conv_desc* d);
-int udaseg_conv2d_fwd_s2_f32x3(const udaseg_conv_desc* d, const float* x, const void* wfrag, float* y, double* stats, void* stream);
-int udaseg_conv2d_dgrad_s2_f32x3(const udaseg_conv_desc* d, const float* dy, const void* wfrag_t, float* dx, int accumulate,
-                                 void* stream);
-
 /* ---- sixteen produced channels on a sixteen-wide matrix tile (round 5, csrc/conv_n16_f32x3.hip): the full-resolution tail of
  *      smp.Unet's decoder (decoder_channels[-1] = 16: block 4 conv2 forward and data gradient, the head's data gradient; reference
  *      src/test_system.py:90-95, src/models/train.py:341,343).  v_mfma_f32_16x16x32_bf16 with K = two taps of a 16-channel chunk:

@@ -286,58 +286,3 @@ def test_up_phase_dgrad_with_bn_backward_reductions(K, n, h, w, ca, co, act, slo
     tot = bs.view(R, 2, ca).sum(0).cpu()
     assert ((tot[0] - s1).abs().max() / s1.abs().max()).item() <= 1e-5
     assert ((tot[1] - s2).abs().max() / s2.abs().max()).item() <= 1e-5
-
-
-S2_CASES = [(2, 32, 64, 64, 128), (1, 20, 72, 16, 32), (8, 128, 128, 64, 128), (8, 64, 64, 128, 256), (8, 32, 32, 256, 512), (1, 12, 24, 24, 40),
-            (2, 2, 2, 8, 8), (3, 34, 38, 32, 64)]
-
-
-@pytest.mark.parametrize("case", S2_CASES, ids=[("n%d_%dx%d_ci%d_co%d" % c) for c in S2_CASES])
-@pytest.mark.parametrize("cfg", [0, 1, 3, 5, 7, 8], ids=["heuristic", "2x32x64ch", "4x32x32ch", "4x16x64ch", "8x16x32ch", "8x32x64ch_dgrad"])
-def test_stride2_conv_on_the_phase_kernels_fp32_grade(K, case, cfg, force_up):
-    """3x3 / stride 2 / pad 1 (the encoder's first block of layer2-4): forward through the space-to-depth kernel with 9 of its 16 tap
-    slots, data gradient through the forward-phase kernel -- against float64, next to the shared implicit-GEMM source in its three-term
-    mode (the kernel these layers ran on before); BatchNorm statistics of the output; accumulation onto an existing gradient."""
-    n, h, w, ci, co = case
-    force_up(cfg)
-    g = torch.Generator().manual_seed(sum(case))
-    x = torch.randn(n, ci, h, w, generator=g)
-    wt = torch.randn(co, ci, 3, 3, generator=g) / math.sqrt(ci * 9)
-    x64 = x.double().requires_grad_(True)
-    y_ref = F.conv2d(x64, wt.double(), stride=2, padding=1)
-    dy = torch.randn(y_ref.shape, generator=g)
-    y_ref.backward(dy.double())
-    d = K.conv_desc(n, h, w, ci, co, 3, 2, 1)
-    assert K.conv_s2_ok(d)
-    w32 = wt.permute(0, 2, 3, 1).contiguous().cuda()
-    wt32 = wt.permute(1, 2, 3, 0).contiguous().cuda()
-    nf, nb = 3 * K.frag_elems(co, ci, 4), 3 * K.frag_elems(ci, co, 4)
-    packed = torch.full((nf + nb,), float("nan"), device="cuda", dtype=bf)
-    K.pack_up_batched(w32, wt32, packed, torch.tensor([[6, 0, 0, co, ci, ci, 0, 0], [7, 0, nf, ci, co, co, 0, 0]], dtype=torch.int32,
-                                                       device="cuda"))
-    assert torch.isfinite(packed.float()).all()
-    R = K.bn_replicas()
-    xd, dyd = nhwc(x), nhwc(dy)
-    y = torch.full((n, h // 2, w // 2, co), float("nan"), device="cuda", dtype=f32)
-    st = torch.zeros(R * 2 * co, dtype=f64, device="cuda")
-    K.conv2d_fwd_s2(d, xd, packed[:nf], y, stats=st)
-    y_ig = torch.empty_like(y)
-    K.conv2d_fwd(d, xd, w32, None, y_ig, 0, 0.0, False)
-    e2, n2, em = err2(nchw(y), y_ref.detach()), err2(nchw(y_ig), y_ref.detach()), err(nchw(y), y_ref.detach())
-    print(f"forward: l2 phase kernels {e2:.3e} implicit GEMM {n2:.3e} | worst element {em:.3e}")
-    assert e2 <= 1.5 * n2 + 2.0 ** -24 and em <= 3e-6
-    tot = st.view(R, 2, co).sum(0).cpu()
-    yd = y_ref.detach().permute(0, 2, 3, 1).reshape(-1, co)
-    assert (tot[0] - yd.sum(0)).abs().max().item() <= 1e-5 * yd.abs().sum(0).max().item(), "fused sum"
-    assert ((tot[1] - (yd * yd).sum(0)).abs().max() / (yd * yd).sum(0).max()).item() <= 1e-5, "fused sum of squares"
-    dx = torch.full((n, h, w, ci), float("nan"), device="cuda", dtype=f32)
-    K.conv2d_dgrad_s2(d, dyd, packed[nf:], dx)
-    dx_ig = torch.empty_like(dx)
-    K.conv2d_dgrad(d, dyd, wt32, dx_ig, False)
-    e2, n2, em = err2(nchw(dx), x64.grad), err2(nchw(dx_ig), x64.grad), err(nchw(dx), x64.grad)
-    print(f"data gradient: l2 phase kernels {e2:.3e} implicit GEMM {n2:.3e} | worst element {em:.3e}")
-    assert e2 <= 1.5 * n2 + 2.0 ** -24 and em <= 3e-6
-    base = torch.randn(n, ci, h, w, generator=g)
-    dxa = nhwc(base)
-    K.conv2d_dgrad_s2(d, dyd, packed[nf:], dxa, accumulate=True)
-    assert err(nchw(dxa), x64.grad + base.double()) <= 3e-6

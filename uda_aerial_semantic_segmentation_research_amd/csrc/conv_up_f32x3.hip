@@ -48,7 +48,6 @@ struct UpArgs {
   double* sscr;
   int ntx, nty, ncb, nk16;
   int q1, q3;           // groups [q1, q3) run on negated weights and a negated accumulator
-  int s2;               // the same two kernels as a 3x3 / STRIDE 2 / pad 1 convolution (see "stride 2" below): taps a phase lacks are skipped
   unsigned x_bytes, w_plane_bytes, y_bytes;
   // data gradient: the conv output of the conv + BatchNorm + activation layer that PRODUCED a (a's only consumer is this convolution,
   // so da is that activation's complete gradient) -> its two BatchNorm-backward sums into stats, as conv_halo_f32x3_epilogue.inc
@@ -256,10 +255,6 @@ __global__ __launch_bounds__(512, 1) void conv_up_fwd_f32x3_kernel(const UpArgs 
 #pragma unroll
           for (int r = 0; r < RPW; ++r) acc[p][r] = -acc[p][r];
       }
-      if (g == 0 && a.s2) {          // stride 2: output column phase 0 has no tap at column offset px - 1
-        __syncthreads();
-        continue;
-      }
       u32x4 bf[4][3];                              // j = (ey, py) in {(0,0), (1,0), (1,1), (2,1)}
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -283,7 +278,6 @@ __global__ __launch_bounds__(512, 1) void conv_up_fwd_f32x3_kernel(const UpArgs 
             for (int j = 0; j < 4; ++j) {
               constexpr int EYJ[4] = {0, 1, 1, 2}, PYJ[4] = {0, 0, 1, 1};
               const int d = s - EYJ[j];            // the fragment that starts at halo row s is row offset ey of MFMA block d / RL
-              if (j == 0 && a.s2) continue;        // stride 2: output row phase 0 has no tap at row offset py - 1 (uniform)
               if (d >= 0 && d % C::RL == 0 && d / C::RL < RPW)
                 acc[PYJ[j] * 2 + px][d / C::RL] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                     __builtin_bit_cast(bf16x8, bf[j][i]), __builtin_bit_cast(bf16x8, pf[s & 1][ij - i]), acc[PYJ[j] * 2 + px][d / C::RL], 0, 0, 0);
@@ -431,7 +425,6 @@ __global__ __launch_bounds__(512, 1) void conv_up_dgrad_f32x3_kernel(const UpArg
     }
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-      if (a.s2 && px == 0 && e == 1) continue;     // stride 2: input column phase 0 is read by the centre column only (uniform)
       const int ex = px ? e : 1 + e;               // px = 0: halo column offsets {1, 2}; px = 1: {0, 1}
       u32x4 bf[2][3];                              // halo row offsets ey = ey0 + {0, 1}, ey0 = 1 (py = 0) / 0 (py = 1)
 #pragma unroll
@@ -459,7 +452,6 @@ __global__ __launch_bounds__(512, 1) void conv_up_dgrad_f32x3_kernel(const UpArg
 #pragma unroll
             for (int jy = 0; jy < 2; ++jy) {
               const int d = s - jy;
-              if (jy == 1 && a.s2 && py == 0) continue;      // stride 2: input row phase 0 is read by the centre row only (uniform)
               if (d >= 0 && d % C::RL == 0 && d / C::RL < RPW)
                 acc[d / C::RL] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bf[jy][i]),
                                                                         __builtin_bit_cast(bf16x8, pf[s & 1][ij - i]), acc[d / C::RL], 0, 0, 0);
@@ -471,8 +463,7 @@ __global__ __launch_bounds__(512, 1) void conv_up_dgrad_f32x3_kernel(const UpArg
 
   const int cbase = nb * 32;
   __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)a.y_bytes, 0x00020000);
-  const bool want_bnb = a.stats != nullptr && a.bnb_y != nullptr;
-  const bool want_stats = a.stats != nullptr && a.bnb_y == nullptr;      // stride-2 forward: BatchNorm statistics of the output
+  const bool want_bnb = a.stats != nullptr;
   __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(want_bnb ? a.bnb_y : a.x), 0,
                                                                   (int)(want_bnb ? a.y_bytes : 0u), 0x00020000);
   float sA[16], sB[16];
@@ -510,14 +501,6 @@ __global__ __launch_bounds__(512, 1) void conv_up_dgrad_f32x3_kernel(const UpArg
 #pragma unroll
       for (int e = 0; e < 4; ++e) d[e] = __builtin_bit_cast(unsigned, val[e]);
       __builtin_amdgcn_raw_buffer_store_b128(d, rs_y, (int)off, 0, 0);
-      if (want_stats) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float q = cv ? val[e] : 0.f;
-          sA[4 * g + e] += q;
-          sB[4 * g + e] = __builtin_fmaf(q, q, sB[4 * g + e]);
-        }
-      }
       if (want_bnb) {
         const f32x4 yv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_p, (int)off, 0, 0));
 #pragma unroll
@@ -530,7 +513,7 @@ __global__ __launch_bounds__(512, 1) void conv_up_dgrad_f32x3_kernel(const UpArg
       }
     }
   }
-  if (want_bnb || want_stats) {
+  if (want_bnb) {
     asm volatile("s_nop 1");
     halfwave_sum_n(sA);
     halfwave_sum_n(sB);
@@ -572,8 +555,6 @@ __global__ __launch_bounds__(512, 1) void conv_up_dgrad_f32x3_kernel(const UpArg
 //   mode 2: phase packing for conv_up_fwd_f32x3_kernel from w32 OHWI [N][3][3][ldk], channels [0, K);
 //   mode 3: phase packing for conv_up_dgrad_f32x3_kernel from wt32 [ci][9][K = co] rows [0, N).
 //   mode 4 / 5: sixteen-wide-tile packings (conv_n16_f32x3.hip), N == 16, plane stride = ceil(K / 16) * 5 * 512 elements.
-//   mode 6 / 7: 3x3 / stride 2 packings in the layouts of modes 3 / 2 (forward on the data-gradient kernel / data gradient on the
-//               forward kernel), plane stride frag_elems(N, K, 4).
 // plane stride = frag_elems(N, K, 3) (modes 0, 1) / frag_elems(N, K, 4) (modes 2, 3).
 __device__ __forceinline__ void up_taps(int ph, int uv, int& k0, int& k1) {      // Ky(py, u) / Kx(px, v) as a range [k0, k1]
   if (ph == 0) { k0 = uv ? 1 : 0; k1 = uv ? 2 : 0; }
@@ -584,7 +565,7 @@ __global__ void pack_up_batched_f32x3_kernel(const float* __restrict__ w32, cons
                                              __bf16* __restrict__ packed, const int* __restrict__ table, int signs) {
   const int* e = table + 8 * blockIdx.y;
   const int mode = e[0], N = e[3], K = e[4], ldk = e[5];
-  const float* src = ((mode & 1) ? wt32 : w32) + e[1];      // odd modes read the dgrad packing
+  const float* src = ((mode & 1) ? wt32 : w32) + e[1];
   __bf16* dst = packed + e[2];
   const int nb = (N + 31) >> 5, nk16 = (K + 15) >> 4;
   if (mode < 2) {                                  // the plain packing, with a row stride
@@ -622,7 +603,7 @@ __global__ void pack_up_batched_f32x3_kernel(const float* __restrict__ w32, cons
     }
     return;
   }
-  if (mode == 4 || mode == 5) {
+  if (mode >= 4) {
     // sixteen-wide tile (conv_n16_f32x3.hip): plane[p][chunk][pair j][lane][8], lane l: channel n = l & 15 (N == 16), K slice
     // g = l >> 4: tap 2 j + (g >> 1) (the ninth tap's partner: zeros), channels 16 chunk + 8 (g & 1) .. + 7 of the chunk.
     // mode 4: forward, w32 OHWI [16][9][ldk]; mode 5: data gradient, wt32 [16 = ci][9][ldk = co], window flipped
@@ -670,7 +651,7 @@ __global__ void pack_up_batched_f32x3_kernel(const float* __restrict__ w32, cons
     const int G = (int)(f % NG);
     const int b = (int)(f / NG);
     int kk, py, px, u, v;
-    if (mode == 2 || mode == 7) {                  // G = 4 chunk + g, g = (px, ex) in {(0,0), (0,1), (1,1), (1,2)}; j = (ey, py)
+    if (mode == 2) {                               // G = 4 chunk + g, g = (px, ex) in {(0,0), (0,1), (1,1), (1,2)}; j = (ey, py)
       kk = G >> 2;
       const int g = G & 3;
       px = g >> 1;
@@ -688,20 +669,7 @@ __global__ void pack_up_batched_f32x3_kernel(const float* __restrict__ w32, cons
     }
     const int n = b * 32 + (lane & 31), k0 = kk * 16 + 8 * (lane >> 5);
     f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
-    if (mode >= 6) {
-      // stride 2 (see "stride 2" at the entry points): ONE tap per slot, or none.
-      //   mode 6 (forward on the data-gradient kernel): slot (py, u) reads input row phase py at halo offset ey = 2 - py - u:
-      //          py 0: u 1 -> kernel row 1 (u 0: none); py 1: u 1 -> kernel row 0, u 0 -> kernel row 2; source w32 OHWI [N = co][9][ldk]
-      //   mode 7 (data gradient on the forward kernel): slot (py, u) of OUTPUT row phase py: py 0: u 1 -> kernel row 1 (u 0: none);
-      //          py 1: u 0 -> kernel row 2, u 1 -> kernel row 0; source wt32 [N = ci][9][ldk = co]
-      const int ty = mode == 6 ? (py == 0 ? (u == 1 ? 1 : -1) : (u == 1 ? 0 : 2)) : (py == 0 ? (u == 1 ? 1 : -1) : (u == 0 ? 2 : 0));
-      const int tx = mode == 6 ? (px == 0 ? (v == 1 ? 1 : -1) : (v == 1 ? 0 : 2)) : (px == 0 ? (v == 1 ? 1 : -1) : (v == 0 ? 2 : 0));
-      if (n < N && k0 < K && ty >= 0 && tx >= 0) {
-        const float* sp = src + ((size_t)n * 9 + ty * 3 + tx) * ldk + k0;
-        lo = *reinterpret_cast<const f32x4*>(sp);
-        if (k0 + 4 < K) hi = *reinterpret_cast<const f32x4*>(sp + 4);
-      }
-    } else if (n < N && k0 < K) {
+    if (n < N && k0 < K) {
       int ya, yb, xa, xb;
       up_taps(py, u, ya, yb);
       up_taps(px, v, xa, xb);
@@ -897,67 +865,5 @@ extern "C" int udaseg_conv2d_dgrad_up_f32x3(const udaseg_conv_desc* d, const flo
   prof_begin(0, st);
   const int rc = launch_up<true>(u, st, flops);
   prof_end(0, st, flops, 1, &dd);
-  return rc;
-}
-
-// ---- stride 2: the SAME two kernels compute the 3x3 / stride 2 / pad 1 layers of the encoder (torchvision BasicBlock.conv1 / Bottleneck.conv2
-// of the first block of layer2-4; reference smp.Unet, src/models/train.py:341,343).  y[q, r] = sum_{dy,dx} W[dy][dx] x[2q + dy - 1, 2r + dx - 1]
-// reads the four parity phases of x -- the space-to-depth gather of conv_up_dgrad_f32x3_kernel -- with ONE, TWO or FOUR of that
-// kernel's 2 x 2 taps per phase (9 of its 16 slots; the others are skipped by uniform branches and packed as zeros), output at
-// the half resolution; the data gradient writes the four parity phases of dx at the full resolution from 9 of the forward-phase
-// kernel's 16 slots.  Before: conv_igemm_kernel X3 (the split re-done per block for the gathered rows AND the weights: 0.15 of
-// the pipe).
-static bool s2_applicable(const udaseg_conv_desc* d) {
-  if (!d || !f32_halo_enabled()) return false;
-  if (d->kh != 3 || d->kw != 3 || d->stride != 2 || d->pad != 1) return false;
-  if (d->n <= 0 || d->hi < 2 || d->wi < 2 || d->hi % 2 != 0 || d->wi % 2 != 0 || d->ho * 2 != d->hi || d->wo * 2 != d->wi) return false;
-  if (d->ci % 8 != 0 || d->co % 8 != 0) return false;
-  const long long pin = (long long)d->n * d->hi * d->wi, pout = (long long)d->n * d->ho * d->wo;
-  return pin * d->ci * 4 < (1LL << 31) && pout * d->co * 4 < (1LL << 31);
-}
-
-extern "C" int udaseg_conv_s2_f32x3_ok(const udaseg_conv_desc* d) { return s2_applicable(d) ? 1 : 0; }
-
-// y[n][ho][wo][co] = conv3x3 / stride 2 (x); stats: BatchNorm statistics of y.  wfrag: mode-6 packing, 3 * frag_elems(co, ci, 4)
-extern "C" int udaseg_conv2d_fwd_s2_f32x3(const udaseg_conv_desc* d, const float* x, const void* wfrag, float* y, double* stats,
-                                          void* stream) {
-  UDASEG_CHECK_ARG(d && x && wfrag && y, "conv2d_fwd_s2_f32x3: NULL pointer");
-  if (!s2_applicable(d)) {
-    set_error("conv2d_fwd_s2_f32x3: geometry not supported (ask udaseg_conv_s2_f32x3_ok first)");
-    return UDASEG_E_UNSUPPORTED;
-  }
-  UpArgs u = {};
-  u.x = x; u.wf = wfrag; u.y = y;
-  u.n = d->n; u.h = d->ho; u.w = d->wo; u.ci = d->ci; u.co = d->co;
-  u.s2 = 1; u.stats = stats;
-  u.x_bytes = (unsigned)((long long)d->n * d->hi * d->wi * d->ci * 4);
-  u.w_plane_bytes = (unsigned)(udaseg_frag_elems(d->co, d->ci, 4) * 2);
-  u.y_bytes = (unsigned)((long long)d->n * d->ho * d->wo * d->co * 4);
-  hipStream_t st = as_stream(stream);
-  prof_begin(0, st);
-  const int rc = launch_up<true>(u, st, udaseg_conv_flops(d));
-  prof_end(0, st, udaseg_conv_flops(d), 0, d);
-  return rc;
-}
-
-// dx[n][hi][wi][ci] (+)= conv_transpose(dy, w) of the same layer.  wfrag_t: mode-7 packing, 3 * frag_elems(ci, co, 4)
-extern "C" int udaseg_conv2d_dgrad_s2_f32x3(const udaseg_conv_desc* d, const float* dy, const void* wfrag_t, float* dx, int accumulate,
-                                            void* stream) {
-  UDASEG_CHECK_ARG(d && dy && wfrag_t && dx, "conv2d_dgrad_s2_f32x3: NULL pointer");
-  if (!s2_applicable(d)) {
-    set_error("conv2d_dgrad_s2_f32x3: geometry not supported (ask udaseg_conv_s2_f32x3_ok first)");
-    return UDASEG_E_UNSUPPORTED;
-  }
-  UpArgs u = {};
-  u.x = dy; u.wf = wfrag_t; u.y = dx;
-  u.n = d->n; u.h = d->ho; u.w = d->wo; u.ci = d->co; u.co = d->ci;
-  u.s2 = 1; u.accumulate = accumulate;
-  u.x_bytes = (unsigned)((long long)d->n * d->ho * d->wo * d->co * 4);
-  u.w_plane_bytes = (unsigned)(udaseg_frag_elems(d->ci, d->co, 4) * 2);
-  u.y_bytes = (unsigned)((long long)d->n * d->hi * d->wi * d->ci * 4);
-  hipStream_t st = as_stream(stream);
-  prof_begin(0, st);
-  const int rc = launch_up<false>(u, st, udaseg_conv_flops(d));
-  prof_end(0, st, udaseg_conv_flops(d), 1, d);
   return rc;
 }

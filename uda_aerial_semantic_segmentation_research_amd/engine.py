@@ -54,9 +54,6 @@ USE_UP_PHASE_WGRAD = os.environ.get("UDASEG_UP_PHASE_WGRAD", "0") == "1"
 # fp32 storage (round 5): 3x3 layers that produce exactly 16 channels (decoder block 4 conv2 forward / data gradient, the head's data
 # gradient) on the sixteen-wide matrix tile (csrc/conv_n16_f32x3.hip).  UDASEG_N16=0: the 32-row tile (A/B, cross-check)
 USE_N16 = os.environ.get("UDASEG_N16", "1") != "0"
-# fp32 storage (round 5): the encoder's 3x3 / stride 2 layers on the phase kernels (9 of their 16 tap slots).  UDASEG_S2_PHASE=0: the
-# shared implicit-GEMM source in its three-term mode (A/B, cross-check)
-USE_S2_PHASE = os.environ.get("UDASEG_S2_PHASE", "1") != "0"
 # fp32 storage, phase form: the skip half of a decoder conv1 is a convolution of an ENCODER feature alone -- it is launched on the side
 # stream as soon as that feature exists and runs beside the rest of the encoder / the earlier decoder blocks (the forward has no other
 # side-stream work; its many small BatchNorm launches leave most of the chip idle).  UDASEG_PRELAUNCH_SKIP=0: on the main stream, in
@@ -404,23 +401,6 @@ class ArenaModule(nn.Module):
                         foff += ne
                     if ent:
                         self._n16_off[id(m)] = ent
-            # fp32: 3x3 / stride 2 layers on the phase kernels (modes 6 / 7 of the same packer)
-            self._s2_off = {}
-            if f32 and USE_S2_PHASE:
-                for m in self.modules():
-                    if not (isinstance(m, ConvP) and m.k == 3 and m.stride == 2 and m.pad == 1 and m.bias is None
-                            and m.cin_p % 8 == 0 and m.cout_p % 8 == 0):
-                        continue
-                    ne = 3 * K.frag_elems(m.cout_p, m.cin_p, 4)
-                    urows_f.append([6, self._idx[(id(m), "weight")][0], foff, m.cout_p, m.cin_p, m.cin_p, 0, 0])
-                    ent = {"fwd": (foff, ne)}
-                    foff += ne
-                    if m.needs_dgrad:
-                        ne = 3 * K.frag_elems(m.cin_p, m.cout_p, 4)
-                        urows_b.append([7, self._wt_off[id(m)], foff, m.cin_p, m.cout_p, m.cout_p, 0, 0])
-                        ent["bwd"] = (foff, ne)
-                        foff += ne
-                    self._s2_off[id(m)] = ent
             self._up_fwd_table = torch.tensor(urows_f, dtype=torch.int32, device=device) if urows_f else None
             self._up_bwd_table = torch.tensor(urows_b, dtype=torch.int32, device=device) if urows_b else None
             if frows:
@@ -676,26 +656,6 @@ class Plan:
         cache[key] = (self.net._frag_arena, views)
         return views
 
-    def s2_frag(self, conv, d, dgrad):
-        """The conv's stride-2 phase packing (forward or data gradient) when this launch can take the phase kernels."""
-        if not (self.frag and USE_S2_PHASE and USE_F32_SPLIT and not self.bf16):
-            return None
-        ent = getattr(self.net, "_s2_off", {}).get(id(conv))
-        key2 = "bwd" if dgrad else "fwd"
-        if ent is None or key2 not in ent:
-            return None
-        cache = self.net.__dict__.setdefault("_s2_cache", {})
-        key = (id(conv), d.n, d.hi, d.wi, d.ci, d.co, bool(dgrad), self.epoch)
-        hit = cache.get(key)
-        if hit is not None and hit[0] is self.net._frag_arena:
-            return hit[1]
-        view = None
-        if K.conv_s2_ok(d):
-            o, n = ent[key2]
-            view = self.net._frag_arena[o:o + n]
-        cache[key] = (self.net._frag_arena, view)
-        return view
-
     def n16_frag(self, conv, d, dgrad):
         """The conv's sixteen-wide-tile packing (forward or data gradient) when this launch can take csrc/conv_n16_f32x3.hip."""
         if not (self.frag and USE_N16 and USE_F32_SPLIT and not self.bf16):
@@ -854,8 +814,6 @@ class Plan:
                                      st=self.st)
                 else:
                     K.conv2d_fwd_n16(d, x, n16, y, stats=sums[0], st=self.st)
-            elif (not up and not lazy_in and bias is None and conv.stride == 2 and self.s2_frag(conv, d, False) is not None):
-                K.conv2d_fwd_s2(d, x, self.s2_frag(conv, d, False), y, stats=sums[0], st=self.st)      # 3x3 / stride 2: phase kernels
             elif lazy_in:
                 assert wf is not None, "a LazyAct input needs the bf16-first kernels (decided by the producer)"
                 K.conv2d_fwd_frag(d, x.y, None, wf, bias, y, stats=sums[0], in_scale=x.scale, in_shift=x.shift, in_act=x.act,
@@ -1051,8 +1009,6 @@ class Plan:
                 self._bnb[id(p_y)] = bs
             elif n16 is not None:
                 K.conv2d_dgrad_n16(d, dy, n16, dx, st=self.st)
-            elif conv.stride == 2 and self.s2_frag(conv, d, True) is not None:
-                K.conv2d_dgrad_s2(d, dy, self.s2_frag(conv, d, True), dx, accumulate=dx_acc, st=self.st)
             elif wfd is not None:
                 K.conv2d_dgrad_frag(d, dy, wfd, dx, accumulate=dx_acc, st=self.st)
             else:

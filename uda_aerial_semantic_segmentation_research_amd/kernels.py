@@ -283,20 +283,6 @@ def conv2d_wgrad_halo_slice(d_slice, x, dy, dw, c_off, st=None):
     check(ops.udaseg_conv2d_wgrad_halo_slice_f32x3(d_slice, x, dy, dw, dw.shape[-1], c_off, st), "conv2d_wgrad_halo_slice_f32x3")
 
 
-def conv_s2_ok(d):
-    return bool(ops.udaseg_conv_s2_f32x3_ok(d))
-
-
-def conv2d_fwd_s2(d, x, wfrag, y, stats=None, st=None):
-    """3x3 / stride 2 forward on the phase machinery (csrc/conv_up_f32x3.hip, mode-6 packing)."""
-    check(ops.udaseg_conv2d_fwd_s2_f32x3(d, x, wfrag, y, stats, st), "conv2d_fwd_s2_f32x3")
-
-
-def conv2d_dgrad_s2(d, dy, wfrag_t, dx, accumulate=False, st=None):
-    """3x3 / stride 2 data gradient on the phase machinery (mode-7 packing)."""
-    check(ops.udaseg_conv2d_dgrad_s2_f32x3(d, dy, wfrag_t, dx, int(accumulate), st), "conv2d_dgrad_s2_f32x3")
-
-
 def conv_n16_ok(d, dgrad=False):
     return bool(ops.udaseg_conv_n16_f32x3_ok(d, int(dgrad)))
 
