@@ -392,7 +392,9 @@ int64_t udaseg_frag_elems(int n_out, int k_in, int ks);
  * DEVICE, not by stream.  Launches that use them -- K-sliced / split partial results, and the statistics of launches with more
  * than 1024 blocks -- must all be issued on ONE compute stream per device (or be ordered by the caller): two such launches on
  * different streams of one device would add into the same scratch and the first fold would take the second's partials.  The
- * weight-gradient side stream of the Python host (engine.py) only issues launches that use neither.
+ * weight-gradient side stream of the Python host (engine.py) only issues launches that use neither.  Round 5: for the STATISTICS
+ * scratch the contract is enforced -- the first stream that needs it after a bind owns it; a launch on any other stream of that
+ * device does not get it and adds into the 16 replicas of `stats` directly (correct, slower).
  * Optional caller-owned f64 scratch (bound to the current device; the caller ZEROES it once, the library leaves it zeroed after
  * every use): launches of more than 1024 blocks put their per-channel statistics there (256 replicas) and a fold kernel adds
  * them into `stats` -- otherwise hundreds of same-address f64 atomics per accumulator bound the low-channel full-resolution

@@ -1137,12 +1137,18 @@ __global__ void __launch_bounds__(FOLD_W * FOLD_G) halo_stats_fold_kernel(double
 static double* g_sscr[16] = {};
 static size_t g_sscr_bytes[16] = {};
 
-double* halo_stats_scratch(int co) {
+static hipStream_t g_sscr_owner[16] = {};
+static bool g_sscr_owned[16] = {};
+double* halo_stats_scratch(int co, hipStream_t s) {
   int dev = 0;
-  if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16 && g_sscr[dev] != nullptr &&
-      (size_t)HALO_SCR_REPLICAS * 2 * co * sizeof(double) <= g_sscr_bytes[dev])
-    return g_sscr[dev];
-  return nullptr;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || g_sscr[dev] == nullptr ||
+      (size_t)HALO_SCR_REPLICAS * 2 * co * sizeof(double) > g_sscr_bytes[dev])
+    return nullptr;
+  if (!g_sscr_owned[dev]) {
+    g_sscr_owned[dev] = true;
+    g_sscr_owner[dev] = s;
+  }
+  return g_sscr_owner[dev] == s ? g_sscr[dev] : nullptr;
 }
 
 void launch_halo_stats_fold(double* sscr, int co, double* stats, hipStream_t s) {
@@ -1168,7 +1174,7 @@ static int launch_halo_t(HaloArgs a, hipStream_t s, double flops) {
   if (blocks <= 0) return UDASEG_OK;
   a.timeline = (g_timeline && blocks <= g_timeline_blocks) ? g_timeline : nullptr;
   a.sscr = nullptr;
-  if (a.stats != nullptr && blocks > 1024) a.sscr = halo_stats_scratch(a.co);
+  if (a.stats != nullptr && blocks > 1024) a.sscr = halo_stats_scratch(a.co, s);
   static std::atomic<int> kid{-1};
   if (kid < 0) {
     char nm[96];
@@ -1435,6 +1441,7 @@ extern "C" int udaseg_set_stats_scratch(void* ptr, size_t bytes) {
   UDASEG_CHECK_ARG(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16, "set_stats_scratch: no current HIP device");
   UDASEG_CHECK_ARG(ptr == nullptr || (reinterpret_cast<uintptr_t>(ptr) & 15) == 0, "set_stats_scratch: 16-byte alignment");
   g_sscr[dev] = static_cast<double*>(ptr);
+  g_sscr_owned[dev] = false;            // the next stream that needs it owns it
   g_sscr_bytes[dev] = ptr ? bytes : 0;
   return UDASEG_OK;
 }

@@ -727,7 +727,7 @@ static int launch_f3_ws_t(F3Args a, hipStream_t s, double flops) {
   const long long blocks = (long long)a.n * a.nty * a.ntx * a.ncb;
   if (blocks <= 0) return UDASEG_OK;
   a.sscr = nullptr;
-  if (a.stats != nullptr && blocks > 1024) a.sscr = halo_stats_scratch(a.co);
+  if (a.stats != nullptr && blocks > 1024) a.sscr = halo_stats_scratch(a.co, s);
   static std::atomic<int> kid{-1};
   if (kid < 0) {
     char nm[96];
@@ -798,7 +798,7 @@ static int launch_f3_t(F3Args a, hipStream_t s, double flops) {
   const long long blocks = (long long)a.n * a.nty * a.ntx * a.ncb;
   if (blocks <= 0) return UDASEG_OK;
   a.sscr = nullptr;
-  if (a.stats != nullptr && blocks > 1024) a.sscr = halo_stats_scratch(a.co);
+  if (a.stats != nullptr && blocks > 1024) a.sscr = halo_stats_scratch(a.co, s);
   static std::atomic<int> kid{-1};
   if (kid < 0) {
     char nm[96];

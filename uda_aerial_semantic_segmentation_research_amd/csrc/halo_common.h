@@ -131,7 +131,10 @@ inline bool f32_halo_enabled() { return opt_get(UDASEG_OPT_F32_HALO) != 0; }
 
 // f64 partial-sum scratch of launches with more than 1024 blocks (udaseg_set_stats_scratch): the current device's, when it holds
 // HALO_SCR_REPLICAS x 2 x co doubles, else nullptr; and the launch that folds it into the [R][2][co] accumulators
-double* halo_stats_scratch(int co);
+// One scratch per device, used by ONE stream: the first stream that asks owns it until the scratch is re-bound
+// (udaseg_set_stats_scratch); a launch on any other stream gets nullptr and adds into the 16 replicas directly (correct, slower)
+// instead of mixing its partial sums with the owner's in-flight launch (the contract was only written down before round 5).
+double* halo_stats_scratch(int co, hipStream_t s);
 void launch_halo_stats_fold(double* sscr, int co, double* stats, hipStream_t s);
 
 }  // namespace udaseg

@@ -132,6 +132,12 @@ class FusedAdam(torch.optim.Optimizer):
                 K.adam_flat(fp, fg, fl["m"], fl["v"], fp.numel(), lr, b1, b2, eps, 1 - b1 ** t, 1 - b2 ** t)
                 self.flat_launches += 1
             # parameters that are not a whole arena: same arithmetic, per tensor (dense tensors -> the kernel)
+            if rest and not getattr(self, "_warned_per_tensor", False):
+                import warnings
+                warnings.warn(f"FusedAdam: {len(rest)} parameter(s) of this group are not a whole parameter arena (frozen layers, a "
+                              "sub-module's parameters, several groups over one network): they take the per-tensor path -- same "
+                              "arithmetic, one launch per tensor instead of one per network", stacklevel=2)
+                self._warned_per_tensor = True
             for p in rest:
                 st = self.state[p]
                 if "exp_avg" not in st:
