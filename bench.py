@@ -274,7 +274,7 @@ def build_leg(workload, encoder, dtype, batch, size, classes, dev, rank, world, 
 # every convolution kernel symbol of the library, classed EXPLICITLY by the matrix pipe it runs on (a heuristic on the
 # template-argument count mispriced launches silently whenever a kernel's template list changed; an unknown symbol now raises)
 SPLIT_PREFIXES = ("conv3x3_f32x3_kernel<", "conv3x3_f32x3_ws_kernel<", "conv_wgrad_h2_kernel<3,", "conv_wgrad_x3_kernel<",
-                  "conv_up_fwd_f32x3_kernel<", "conv_up_dgrad_f32x3_kernel<", "conv_wgrad_up_kernel<", "conv3x3_n16_f32x3_kernel<")
+                  "conv_up_fwd_f32x3_kernel<", "conv_up_dgrad_f32x3_kernel<", "conv_wgrad_up_kernel<", "conv3x3_n16_f32x3_kernel<", "conv_stem_f32x3_kernel")
 NATIVE_PREFIXES = ("conv_wgrad_kernel<", "conv3x3_small_", "conv_wgrad_bf16_kernel<", "conv_wgrad_h2_kernel<1,", "conv_halo_bf16_kernel<",
                    "conv1x1_stream_bf16_kernel<", "conv1x1_gemm_bf16_kernel", "conv_halo_s2", "conv_small", "conv2d_folded")
 # conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, BF16, UNI, UP[, X3]>: the three-term instantiations carry an EIGHTH argument "true"

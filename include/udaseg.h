@@ -564,6 +564,14 @@ int udaseg_conv2d_dgrad_n16_f32x3(const udaseg_conv_desc* d, const float* dy, co
                                   const float* save_mean, const float* save_rstd, const float* gamma, const float* beta, int bn_act,
                                   float bn_slope, double* bsums, void* stream);
 
+/* ---- the encoder's stem (round 5, csrc/conv_stem_f32x3.hip): 7x7 / stride 2 / pad 3, 4 (3 + padding) -> 64 channels, forward --
+ *      torchvision ResNet.conv1 inside smp.Unet (reference src/test_system.py:90-95, src/models/train.py:341).  For one kernel row the
+ *      7 taps x 4 channels of an output pixel are 28 contiguous floats of an input row: the kernel stages a band of input rows once
+ *      and runs K as 7 rows x 32, no im2col gather.  fp32 tensors, three-term split.  Weights: udaseg_pack_up_batched_f32x3 mode 8
+ *      (3 planes of 28 * 512 bf16).  Replaces udaseg_conv2d_fwd_bnstats (conv_igemm_kernel, generic gather) on that layer. ---- */
+int udaseg_conv_stem_f32x3_ok(const udaseg_conv_desc* d);
+int udaseg_conv2d_fwd_stem_f32x3(const udaseg_conv_desc* d, const float* x, const void* wfrag, float* y, double* stats, void* stream);
+
 /* ---- diagnosis: while a device buffer of 6 * blocks u64 is registered, every implicit-GEMM launch of at most `blocks` blocks
  *      writes per block {entry, first tile load, end of K loop, exit} (100 MHz wall-clock ticks), HW_ID and XCC_ID into it
  *      (tools/igemm_timeline.py).  NULL switches it off.  Not for timed runs. ---- */

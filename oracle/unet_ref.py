@@ -84,6 +84,12 @@ def _relu(x):
     return y
 
 
+def _max_pool(x):
+    # torchvision ResNet.maxpool = MaxPool2d(3, 2, 1); a function of its own so tests/_parity.py can make both paths pick the same
+    # window winners (like _relu's mask)
+    return F.max_pool2d(x, 3, 2, 1)
+
+
 class BasicBlock(nn.Module):
     expansion = 1
 
@@ -171,7 +177,7 @@ class ResNetEncoderRef(nn.Module):
         feats = [x]
         x = _relu(_bn(_conv(x, self.conv1), self.bn1))
         feats.append(x)
-        x = F.max_pool2d(x, 3, 2, 1)
+        x = _max_pool(x)
         if _TR is not None:
             _TR.add("max_pool2d", x, kernel=[3, 3], stride=[2, 2], padding=[1, 1], dilation=[1, 1], ceil_mode=0)
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):

@@ -125,6 +125,11 @@ def test_n16_forward_fp32_grade(K, case, lazy):
     yd = y_ref.permute(0, 2, 3, 1).reshape(-1, co)
     assert (tot[0] - yd.sum(0)).abs().max().item() <= 1e-5 * yd.abs().sum(0).max().item(), "fused sum"
     assert ((tot[1] - (yd * yd).sum(0)).abs().max() / (yd * yd).sum(0).max()).item() <= 1e-5, "fused sum of squares"
+    # the statistics are those of the tensor the kernel stored (BatchNorm's backward relies on sum(y_hat) == 0 over the stored y)
+    own = y.double().reshape(-1, y.shape[-1])
+    e_own = ((tot[0] - own.sum(0).cpu()).abs().max() / own.abs().sum(0).max().cpu()).item()
+    print(f"statistics against the stored tensor's own sums: {e_own:.2e}")
+    assert e_own <= 2e-7
 
 
 BWD_CASES = [(2, 16, 32, 16), (1, 24, 40, 24), (1, 20, 72, 16), (2, 9, 33, 24), (8, 128, 128, 24), (1, 512, 512, 16)]
@@ -172,3 +177,47 @@ def test_n16_data_gradient_fp32_grade(K, case, bnb):
         tot = bs.view(R, 2, ci).sum(0).cpu()
         assert ((tot[0] - s1).abs().max() / s1.abs().max()).item() <= 1e-5
         assert ((tot[1] - s2).abs().max() / s2.abs().max()).item() <= 1e-5
+
+
+STEM_CASES = [(2, 64, 64), (1, 48, 80), (8, 256, 256), (1, 34, 38), (1, 2, 2), (2, 512, 512), (8, 512, 512), (5, 1024, 768)]
+
+
+@pytest.mark.parametrize("case", STEM_CASES, ids=[("n%d_%dx%d" % c) for c in STEM_CASES])
+def test_stem_forward_fp32_grade(K, case):
+    """The 7x7 / stride 2 / pad 3 stem (3 + 1 padding channels -> 64) on csrc/conv_stem_f32x3.hip against float64, next to the shared
+    implicit-GEMM source on the fp32 matrix pipe; BatchNorm statistics; ragged tiles; the zero-weight columns that pad a kernel row's
+    28 values to K = 32 read the neighbouring pixel and must contribute nothing (the image's 4th channel is NOT zero here)."""
+    n, h, w = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(n, 4, h, w, generator=g) if n != 8 else torch.rand(n, 4, h, w, generator=g)     # n == 8: images in [0, 1)
+    wt = torch.randn(64, 4, 7, 7, generator=g) / math.sqrt(4 * 49)
+    y_ref = F.conv2d(x.double(), wt.double(), stride=2, padding=3)
+    d = K.conv_desc(n, h, w, 4, 64, 7, 2, 3)
+    assert K.conv_stem_ok(d)
+    w32 = wt.permute(0, 2, 3, 1).contiguous().cuda()
+    packed = torch.full((K.STEM_FRAG_ELEMS,), float("nan"), device="cuda", dtype=bf)
+    K.pack_up_batched(w32, None, packed, torch.tensor([[8, 0, 0, 64, 4, 4, 0, 0]], dtype=torch.int32, device="cuda"))
+    assert torch.isfinite(packed.float()).all()
+    R = K.bn_replicas()
+    xd = nhwc(x)
+    y = torch.full((n, h // 2, w // 2, 64), float("nan"), device="cuda", dtype=f32)
+    st = torch.zeros(R * 2 * 64, dtype=f64, device="cuda")
+    K.conv2d_fwd_stem(d, xd, packed, y, stats=st)
+    y_nat = torch.empty_like(y)
+    K.set_f32_split(0)
+    try:
+        K.conv2d_fwd(d, xd, w32, None, y_nat, 0, 0.0, False)
+    finally:
+        K.set_f32_split(-1)
+    e2, n2, em = err2(nchw(y), y_ref), err2(nchw(y_nat), y_ref), err(nchw(y), y_ref)
+    print(f"stem forward: l2 {e2:.3e} fp32-MFMA implicit GEMM {n2:.3e} | worst element {em:.3e}")
+    assert e2 <= 1.25 * n2 + 2.0 ** -24 and em <= 3e-6
+    tot = st.view(R, 2, 64).sum(0).cpu()
+    yd = y_ref.permute(0, 2, 3, 1).reshape(-1, 64)
+    assert (tot[0] - yd.sum(0)).abs().max().item() <= 1e-5 * yd.abs().sum(0).max().item(), "fused sum"
+    assert ((tot[1] - (yd * yd).sum(0)).abs().max() / (yd * yd).sum(0).max()).item() <= 1e-5, "fused sum of squares"
+    # the statistics are those of the tensor the kernel stored (BatchNorm's backward relies on sum(y_hat) == 0 over the stored y)
+    own = y.double().reshape(-1, y.shape[-1])
+    e_own = ((tot[0] - own.sum(0).cpu()).abs().max() / own.abs().sum(0).max().cpu()).item()
+    print(f"statistics against the stored tensor's own sums: {e_own:.2e}")
+    assert e_own <= 2e-7

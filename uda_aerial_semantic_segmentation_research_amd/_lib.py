@@ -149,6 +149,8 @@ SIGNATURES = {
     "udaseg_conv2d_wgrad_up_f32x3": (_I, [_D, _P, _I, _P, _P, _P]),
     "udaseg_conv2d_wgrad_halo_slice_f32x3": (_I, [_D, _P, _P, _P, _I, _I, _P]),
     "udaseg_wgrad_up_set_blocks": (_I, [_I]),
+    "udaseg_conv_stem_f32x3_ok": (_I, [_D]),
+    "udaseg_conv2d_fwd_stem_f32x3": (_I, [_D, _P, _P, _P, _P, _P]),
     "udaseg_conv_n16_f32x3_ok": (_I, [_D, _I]),
     "udaseg_conv2d_fwd_n16_f32x3": (_I, [_D, _P, _P, _P, _I, _F, _P, _P, _P, _P]),
     "udaseg_conv2d_dgrad_n16_f32x3": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _P, _P]),

@@ -68,6 +68,7 @@ OPERANDS = {
     "udaseg_f32x3_force_config": [I("cfg")], "udaseg_up_f32x3_force_config": [I("cfg")],
     "udaseg_conv_up_f32x3_ok": [D, I("up_ca")], "udaseg_conv2d_wgrad_up_f32x3_ok": [D, I("up_ca")],
     "udaseg_wgrad_up_set_blocks": [I("blocks")], "udaseg_conv_n16_f32x3_ok": [D, I("dgrad")],
+    "udaseg_conv_stem_f32x3_ok": [D],
     "udaseg_prof_enable": [I("on")], "udaseg_prof_kernel_name": [I("kid")],
     "udaseg_prof_read": [I("family"), H("total_ms"), H("total_flops"), H("launches")],
     "udaseg_prof_kernel_read": [I("kid"), H("total_ms"), H("total_flops"), H("launches")],
@@ -128,6 +129,7 @@ OPERANDS = {
     "udaseg_conv2d_wgrad_up_f32x3": [D, T("a", f32, _HALF + "*up_c"), I("up_c"), T("dy", f32, "Y"), T("dw", f32, "W"), S],
     "udaseg_conv2d_wgrad_halo_slice_f32x3": [D, T("x", f32, "X"), T("dy", f32, "Y"), T("dw", f32, "co*kh*kw*ldw_"), I("ldw_"),
                                              I("c_off"), S],
+    "udaseg_conv2d_fwd_stem_f32x3": [D, T("x", f32, "X"), T("wfrag", bf16, "3*28*512"), T("y", f32, "Y"), T("stats", f64, "2*co*R", True), S],
     "udaseg_conv2d_fwd_n16_f32x3": [D, T("x", f32, "X"), T("in_scale", f32, "ci", True), T("in_shift", f32, "ci", True), I("in_act"),
                                     F("in_slope"), T("wfrag", bf16, "3*((ci+15)//16)*5*512"), T("y", f32, "Y"),
                                     T("stats", f64, "2*co*R", True), S],

@@ -555,6 +555,7 @@ __global__ __launch_bounds__(512, 1) void conv_up_dgrad_f32x3_kernel(const UpArg
 //   mode 2: phase packing for conv_up_fwd_f32x3_kernel from w32 OHWI [N][3][3][ldk], channels [0, K);
 //   mode 3: phase packing for conv_up_dgrad_f32x3_kernel from wt32 [ci][9][K = co] rows [0, N).
 //   mode 4 / 5: sixteen-wide-tile packings (conv_n16_f32x3.hip), N == 16, plane stride = ceil(K / 16) * 5 * 512 elements.
+//   mode 8: the stem's packing (conv_stem_f32x3.hip), N == 64, K == 4, plane stride 28 * 512 elements.
 // plane stride = frag_elems(N, K, 3) (modes 0, 1) / frag_elems(N, K, 4) (modes 2, 3).
 __device__ __forceinline__ void up_taps(int ph, int uv, int& k0, int& k1) {      // Ky(py, u) / Kx(px, v) as a range [k0, k1]
   if (ph == 0) { k0 = uv ? 1 : 0; k1 = uv ? 2 : 0; }
@@ -603,7 +604,38 @@ __global__ void pack_up_batched_f32x3_kernel(const float* __restrict__ w32, cons
     }
     return;
   }
-  if (mode >= 4) {
+  if (mode == 8) {
+    // the stem (conv_stem_f32x3.hip): plane[p][ky][h][cb][lane][8], lane l: channel n = 32 cb + (l & 31), elements j = 16 h + 8 (l >> 5) .. + 7
+    // of kernel row ky, j = 4 kx + c (j >= 28: the four zero columns that pad a row's 28 values to K = 32); source w32 OHWI [64][7][7][4]
+    const long long total = 28 * 64;
+    const long long plane = total * 8;
+    int q1 = 0, q3 = 0;
+    if (signs) up_negated_groups(14, q1, q3);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+      const int lane = (int)(i & 63), f = (int)(i >> 6);
+      const int cb = f & 1, h = (f >> 1) & 1, ky = f >> 2;
+      const int n = cb * 32 + (lane & 31), j0 = 16 * h + 8 * (lane >> 5);
+      u32x4 lo = {0u, 0u, 0u, 0u}, hi = lo;
+      if (n < N) {
+        const float* sp = src + ((size_t)n * 49 + ky * 7) * 4 + j0;
+        if (j0 < 28) lo = *reinterpret_cast<const u32x4*>(sp);
+        if (j0 + 4 < 28) hi = *reinterpret_cast<const u32x4*>(sp + 4);
+      }
+      u32x4 p0, p1, p2;
+      split3(lo, hi, p0, p1, p2);
+      const int G = 2 * ky + h;
+      if (G >= q1 && G < q3) {
+        p0 ^= 0x80008000u;
+        p1 ^= 0x80008000u;
+        p2 ^= 0x80008000u;
+      }
+      *reinterpret_cast<u32x4*>(dst + i * 8) = p0;
+      *reinterpret_cast<u32x4*>(dst + plane + i * 8) = p1;
+      *reinterpret_cast<u32x4*>(dst + 2 * plane + i * 8) = p2;
+    }
+    return;
+  }
+  if (mode == 4 || mode == 5) {
     // sixteen-wide tile (conv_n16_f32x3.hip): plane[p][chunk][pair j][lane][8], lane l: channel n = l & 15 (N == 16), K slice
     // g = l >> 4: tap 2 j + (g >> 1) (the ninth tap's partner: zeros), channels 16 chunk + 8 (g & 1) .. + 7 of the chunk.
     // mode 4: forward, w32 OHWI [16][9][ldk]; mode 5: data gradient, wt32 [16 = ci][9][ldk = co], window flipped

@@ -54,6 +54,9 @@ USE_UP_PHASE_WGRAD = os.environ.get("UDASEG_UP_PHASE_WGRAD", "0") == "1"
 # fp32 storage (round 5): 3x3 layers that produce exactly 16 channels (decoder block 4 conv2 forward / data gradient, the head's data
 # gradient) on the sixteen-wide matrix tile (csrc/conv_n16_f32x3.hip).  UDASEG_N16=0: the 32-row tile (A/B, cross-check)
 USE_N16 = os.environ.get("UDASEG_N16", "1") != "0"
+# fp32 storage (round 5): the 7x7 / stride 2 stem forward on its own kernel (csrc/conv_stem_f32x3.hip).  UDASEG_STEM=0: the shared
+# implicit-GEMM source (A/B, cross-check)
+USE_STEM = os.environ.get("UDASEG_STEM", "1") != "0"
 # fp32 storage, phase form: the skip half of a decoder conv1 is a convolution of an ENCODER feature alone -- it is launched on the side
 # stream as soon as that feature exists and runs beside the rest of the encoder / the earlier decoder blocks (the forward has no other
 # side-stream work; its many small BatchNorm launches leave most of the chip idle).  UDASEG_PRELAUNCH_SKIP=0: on the main stream, in
@@ -401,6 +404,14 @@ class ArenaModule(nn.Module):
                         foff += ne
                     if ent:
                         self._n16_off[id(m)] = ent
+            self._stem_off = {}
+            if f32 and USE_STEM:
+                for m in self.modules():
+                    if (isinstance(m, ConvP) and m.k == 7 and m.stride == 2 and m.pad == 3 and m.cin_p == 4 and m.cout_p == 64
+                            and m.bias is None):
+                        urows_f.append([8, self._idx[(id(m), "weight")][0], foff, 64, 4, 4, 0, 0])
+                        self._stem_off[id(m)] = (foff, K.STEM_FRAG_ELEMS)
+                        foff += K.STEM_FRAG_ELEMS
             self._up_fwd_table = torch.tensor(urows_f, dtype=torch.int32, device=device) if urows_f else None
             self._up_bwd_table = torch.tensor(urows_b, dtype=torch.int32, device=device) if urows_b else None
             if frows:
@@ -656,6 +667,22 @@ class Plan:
         cache[key] = (self.net._frag_arena, views)
         return views
 
+    def stem_frag(self, conv, d):
+        """The stem's fragment packing when this launch can take csrc/conv_stem_f32x3.hip."""
+        if not (self.frag and USE_STEM and USE_F32_SPLIT and not self.bf16):
+            return None
+        ent = getattr(self.net, "_stem_off", {}).get(id(conv))
+        if ent is None:
+            return None
+        cache = self.net.__dict__.setdefault("_stem_cache", {})
+        key = (id(conv), d.n, d.hi, d.wi, self.epoch)
+        hit = cache.get(key)
+        if hit is not None and hit[0] is self.net._frag_arena:
+            return hit[1]
+        view = self.net._frag_arena[ent[0]:ent[0] + ent[1]] if K.conv_stem_ok(d) else None
+        cache[key] = (self.net._frag_arena, view)
+        return view
+
     def n16_frag(self, conv, d, dgrad):
         """The conv's sixteen-wide-tile packing (forward or data gradient) when this launch can take csrc/conv_n16_f32x3.hip."""
         if not (self.frag and USE_N16 and USE_F32_SPLIT and not self.bf16):
@@ -814,6 +841,8 @@ class Plan:
                                      st=self.st)
                 else:
                     K.conv2d_fwd_n16(d, x, n16, y, stats=sums[0], st=self.st)
+            elif not up and not lazy_in and bias is None and conv.k == 7 and self.stem_frag(conv, d) is not None:
+                K.conv2d_fwd_stem(d, x, self.stem_frag(conv, d), y, stats=sums[0], st=self.st)      # the 7x7 / stride 2 stem
             elif lazy_in:
                 assert wf is not None, "a LazyAct input needs the bf16-first kernels (decided by the producer)"
                 K.conv2d_fwd_frag(d, x.y, None, wf, bias, y, stats=sums[0], in_scale=x.scale, in_shift=x.shift, in_act=x.act,

@@ -283,6 +283,18 @@ def conv2d_wgrad_halo_slice(d_slice, x, dy, dw, c_off, st=None):
     check(ops.udaseg_conv2d_wgrad_halo_slice_f32x3(d_slice, x, dy, dw, dw.shape[-1], c_off, st), "conv2d_wgrad_halo_slice_f32x3")
 
 
+STEM_FRAG_ELEMS = 3 * 28 * 512
+
+
+def conv_stem_ok(d):
+    return bool(ops.udaseg_conv_stem_f32x3_ok(d))
+
+
+def conv2d_fwd_stem(d, x, wfrag, y, stats=None, st=None):
+    """The encoder's 7x7 / stride 2 stem on its own kernel (csrc/conv_stem_f32x3.hip, mode-8 packing)."""
+    check(ops.udaseg_conv2d_fwd_stem_f32x3(d, x, wfrag, y, stats, st), "conv2d_fwd_stem_f32x3")
+
+
 def conv_n16_ok(d, dgrad=False):
     return bool(ops.udaseg_conv_n16_f32x3_ok(d, int(dgrad)))
 
