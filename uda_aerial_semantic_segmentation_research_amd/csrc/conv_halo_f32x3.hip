@@ -33,6 +33,7 @@
 // 856 images/s -- the larger LDS block costs the 32-channel configuration its third resident block.)
 // inf / values within 2^-8 of FLT_MAX: x0 rounds to inf and the remainders become NaN -- such activations are already lost.
 #include <stdlib.h>
+#include <type_traits>
 
 #include "common.h"
 #include "halo_common.h"
@@ -347,7 +348,8 @@ struct F3WsCfg {
   static constexpr int NT = 512, NLD = 256;               // threads; loader threads
   static constexpr int TW = TW_, RL = 32 / TW_;           // image rows per 32-pixel MFMA block
   static constexpr int TH = WM * RPW * RL;
-  static constexpr int NJ = RL * RPW + 2;                  // fragment start rows a wave reads per (dx) group
+  static constexpr int NJ = RL * (RPW - 1) + 3;            // fragment start rows a wave reads per (dx) group (the last one is tap row 2 of its last MFMA block)
+  static constexpr bool DEEP = TW_ == 16;                  // loader roles split, weights requested three groups ahead (see the kernel)
   static constexpr int HR = TH + 2, HWD = TW + 2;
   // LDS pitch of a halo row, in pixels (32 bytes each).  16-pixel rows: a fragment spans TWO halo rows, and ds_read_b128 serves
   // lanes {0-3, 12-15, 20-27} in one cycle -- columns 0-3 / 12-15 of row r with columns 4-11 of row r + 1: conflict-free only if the
@@ -411,19 +413,32 @@ __global__ __launch_bounds__(512, 1) void conv3x3_f32x3_ws_kernel(const F3Args a
     for (int v = 0; v < 16; ++v) acc[r][v] = 0.f;
 
   if (loader) {
-    const int lt = tid - 256;
+    // DEEP (F3WsCfg::DEEP: the 16-pixel-row tiles, one block per CU, 18 MFMAs per group): the two jobs are split between the loader
+    // waves -- waves 4-5 stage weights only and request a group's fragments THREE groups ahead into one of two register sets (a weight
+    // fragment comes from L2 / the Infinity Cache: ~1200 cycles, more than one group lasts; with one set the wave sat in s_waitcnt
+    // for most of every group: 1093 of 1262 cycles, profiles/r05_f3_deep.txt), waves 6-7 stage the halo.  Every load of the weight
+    // waves is issued unconditionally (past the last group: out of range, returns zeros) so that the wait count in front of each
+    // LDS store is a compile-time number of younger loads.
+    constexpr bool DEEP = C::DEEP;
+    constexpr int NLDX = DEEP ? 128 : C::NLD;
+    constexpr int NIX = (C::NPIECE + NLDX - 1) / NLDX;
+    constexpr int WSTEP = DEEP ? 2 : 4;
+    constexpr int NWIX = (C::NFG + WSTEP - 1) / WSTEP;
+    const bool h_role = !DEEP || wave >= 6;
+    const int lt = tid - (DEEP ? 384 : 256);
+    const int wq0 = DEEP ? (wave - 4) : mw;
     const int oct = lt & 1;
-    unsigned voff[C::NI], voff2[C::NI], soffl[C::NI];
+    unsigned voff[NIX], voff2[NIX], soffl[NIX];
     unsigned zmask = 0;
     const bool UPC = a.up_ca > 0;
     const int cx = UPC ? a.up_ca : a.ci, cx2 = a.ci - a.up_ca;
 #pragma unroll
-    for (int i = 0; i < C::NI; ++i) {
-      const int piece = lt + i * C::NLD;
+    for (int i = 0; i < NIX; ++i) {
+      const int piece = lt + i * NLDX;
       const int pix = piece >> 1;
       const int hy = pix / C::HWD, hx = pix - hy * C::HWD;
       const int iy = y0 + hy - 1, ix = x0 + hx - 1;
-      const bool ok = piece < C::NPIECE && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      const bool ok = h_role && piece < C::NPIECE && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
       if (UPC) {
         voff[i] = ok ? (unsigned)((((img * (H >> 1) + (iy >> 1)) * (W >> 1) + (ix >> 1)) * cx + oct * 8) * 4) : 0x80000000u;
         voff2[i] = ok ? (unsigned)((((img * H + iy) * W + ix) * cx2 + oct * 8) * 4) : 0x80000000u;
@@ -444,18 +459,18 @@ __global__ __launch_bounds__(512, 1) void conv3x3_f32x3_ws_kernel(const F3Args a
                                                                     (int)(XF && a.z_out ? a.z_bytes : 0u), 0x00020000);
     const bool zwrite = XF && a.z_out != nullptr && cb == 0 && !UPC;
     const int frag_per_nb = 3 * a.nk16 * 3;
-    int wbase[C::NWI];
+    int wbase[NWIX];
     const unsigned wlane16 = (unsigned)lane * 16u;
 #pragma unroll
-    for (int i = 0; i < C::NWI; ++i) {
-      const int q = mw + 4 * i;                    // slot of the group: ((wq * 3 + dy) * 3 + plane)
+    for (int i = 0; i < NWIX; ++i) {
+      const int q = wq0 + WSTEP * i;               // slot of the group: ((wq * 3 + dy) * 3 + plane)
       const int wq = q / 9, rem = q - wq * 9;
       const int dy = rem / 3, pl = rem - dy * 3;
       const int nbq = cb * WN + wq;
       const bool live = q < C::NFG && nbq < nblocks32;
       wbase[i] = live ? (int)(pl * a.w_plane_bytes) + (nbq * frag_per_nb + dy) * 1024 : -1;
     }
-    u32x4 stage[C::NI][2], wstage[C::NWI];
+    u32x4 stage[NIX][2], wstage[DEEP ? 2 : 1][NWIX];
     auto load_chunk = [&](int c) {
       const int cbeg = c * 16;
       const bool second = UPC && cbeg >= a.up_ca;
@@ -463,13 +478,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_f32x3_ws_kernel(const F3Args a
       const unsigned kill = (cbeg + oct * 8 < a.ci) ? 0u : 0x80000000u;
       if (second) {
 #pragma unroll
-        for (int i = 0; i < C::NI; ++i) {
+        for (int i = 0; i < NIX; ++i) {
           stage[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_x2, (int)(voff2[i] | kill), soff, 0);
           stage[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_x2, (int)(voff2[i] | kill), soff + 16, 0);
         }
       } else {
 #pragma unroll
-        for (int i = 0; i < C::NI; ++i) {
+        for (int i = 0; i < NIX; ++i) {
           stage[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(voff[i] | kill), soff, 0);
           stage[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(voff[i] | kill), soff + 16, 0);
         }
@@ -491,8 +506,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_f32x3_ws_kernel(const F3Args a
         }
       }
 #pragma unroll
-      for (int i = 0; i < C::NI; ++i) {
-        if (i < C::NI - 1 || lt + i * C::NLD < C::NPIECE) {
+      for (int i = 0; i < NIX; ++i) {
+        if (i < NIX - 1 || lt + i * NLDX < C::NPIECE) {
           if constexpr (XF) {
             const bool inside = voff[i] != 0x80000000u;
             f32x4 l = __builtin_bit_cast(f32x4, stage[i][0]), h = __builtin_bit_cast(f32x4, stage[i][1]);
@@ -524,49 +539,108 @@ __global__ __launch_bounds__(512, 1) void conv3x3_f32x3_ws_kernel(const F3Args a
         }
       }
     };
-    auto load_w = [&](int G) {
+    // SET: the register set (compile-time); G >= NG: out of range, nothing is fetched (the load still counts)
+    auto load_w = [&](int G, auto SET) {
       const int c = G / 3, dx = G - 3 * c;
       const int soff = (dx * a.nk16 + c) * 3 * 1024;
+      const bool dead = G >= NG;
 #pragma unroll
-      for (int i = 0; i < C::NWI; ++i)
-        wstage[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wbase[i] < 0 ? 0x80000000u : wlane16), wbase[i] < 0 ? 0 : wbase[i] + soff, 0);
+      for (int i = 0; i < NWIX; ++i)
+        wstage[SET.value][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)((wbase[i] < 0 || dead) ? 0x80000000u : wlane16),
+                                                                     (wbase[i] < 0 || dead) ? 0 : wbase[i] + soff, 0);
     };
-    auto store_w = [&](int buf) {
+    auto store_w = [&](int buf, auto SET) {
 #pragma unroll
-      for (int i = 0; i < C::NWI; ++i) {
-        const int q = mw + 4 * i;
-        if (i < C::NWI - 1 || q < C::NFG) *reinterpret_cast<u32x4*>(wlds + buf * C::LDS_WBUF + q * 1024 + lane * 16) = wstage[i];
+      for (int i = 0; i < NWIX; ++i) {
+        const int q = wq0 + WSTEP * i;
+        if (i < NWIX - 1 || q < C::NFG) *reinterpret_cast<u32x4*>(wlds + buf * C::LDS_WBUF + q * 1024 + lane * 16) = wstage[SET.value][i];
       }
     };
+    constexpr std::integral_constant<int, 0> S0{};
+    constexpr std::integral_constant<int, DEEP ? 1 : 0> S1{};
 
-    load_chunk(0);
-    load_w(0);
-    store_chunk(0, 0);
-    store_w(0);
-    if (nchunk > 1) load_chunk(1);
-    if (NG > 1) load_w(1);
-    __syncthreads();                               // group 0 is staged
-    if constexpr (TL) tl_first = tl_t = __builtin_amdgcn_s_memtime();
-    for (int G = 0; G < NG; ++G) {
-      const int c = G / 3, dx = G - 3 * c;
-      if (G + 1 < NG) {
-        store_w((G + 1) & 1);                      // last read by the MFMA waves in group G - 1
-        if (G + 2 < NG) load_w(G + 2);
+    if constexpr (DEEP) {
+     if (!h_role) {
+      // weight waves: group G's fragments live in register set G & 1 and in LDS weight buffer G & 1
+      // (scheduling barriers: the issue ORDER of the three requests is what the wait counts at the loop head are derived from)
+      load_w(0, S0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_w(1, S1);
+      __builtin_amdgcn_sched_barrier(0);
+      store_w(0, S0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_w(2, S0);
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();                             // group 0 is staged
+      if constexpr (TL) tl_first = tl_t = __builtin_amdgcn_s_memtime();
+      auto wgroup = [&](int G, auto NEXT) {        // NEXT: set / buffer of group G + 1 (last read by the MFMA waves in group G - 1)
+        if (G + 1 < NG) store_w(NEXT.value, NEXT);
+        load_w(G + 3, NEXT);
+        if constexpr (TL) {
+          const unsigned long long t = __builtin_amdgcn_s_memtime();
+          tl_work += t - tl_t;
+          tl_t = t;
+        }
+        __syncthreads();
+        if constexpr (TL) {
+          const unsigned long long t = __builtin_amdgcn_s_memtime();
+          tl_bar += t - tl_t;
+          tl_t = t;
+        }
+      };
+      // both halves unconditional inside the loop: a path that skips one would make the younger-load count at the loop head
+      // unknown, and the compiler then waits for everything (vmcnt(0)) in front of the stores -- the prefetch distance would be gone
+      int G = 0;
+      for (; G + 1 < NG; G += 2) {
+        wgroup(G, S1);
+        wgroup(G + 1, S0);
       }
-      if (dx == 1 && c + 1 < nchunk) {
-        store_chunk((c + 1) & 1, c + 1);           // last read in chunk c - 1
-        if (c + 2 < nchunk) load_chunk(c + 2);
+      if (G < NG) wgroup(G, S1);
+     } else {
+      // halo waves
+      load_chunk(0);
+      store_chunk(0, 0);
+      if (nchunk > 1) load_chunk(1);
+      __syncthreads();                             // group 0 is staged
+      for (int G = 0; G < NG; ++G) {
+        const int c = G / 3, dx = G - 3 * c;
+        if (dx == 1 && c + 1 < nchunk) {
+          store_chunk((c + 1) & 1, c + 1);         // last read in chunk c - 1
+          if (c + 2 < nchunk) load_chunk(c + 2);
+        }
+        __syncthreads();
       }
-      if constexpr (TL) {
-        const unsigned long long t = __builtin_amdgcn_s_memtime();
-        tl_work += t - tl_t;
-        tl_t = t;
-      }
-      __syncthreads();
-      if constexpr (TL) {
-        const unsigned long long t = __builtin_amdgcn_s_memtime();
-        tl_bar += t - tl_t;
-        tl_t = t;
+     }
+    } else {
+      load_chunk(0);
+      load_w(0, S0);
+      store_chunk(0, 0);
+      store_w(0, S0);
+      if (nchunk > 1) load_chunk(1);
+      if (NG > 1) load_w(1, S0);
+      __syncthreads();                               // group 0 is staged
+      if constexpr (TL) tl_first = tl_t = __builtin_amdgcn_s_memtime();
+      for (int G = 0; G < NG; ++G) {
+        const int c = G / 3, dx = G - 3 * c;
+        if (G + 1 < NG) {
+          store_w((G + 1) & 1, S0);                  // last read by the MFMA waves in group G - 1
+          if (G + 2 < NG) load_w(G + 2, S0);
+        }
+        if (dx == 1 && c + 1 < nchunk) {
+          store_chunk((c + 1) & 1, c + 1);           // last read in chunk c - 1
+          if (c + 2 < nchunk) load_chunk(c + 2);
+        }
+        if constexpr (TL) {
+          const unsigned long long t = __builtin_amdgcn_s_memtime();
+          tl_work += t - tl_t;
+          tl_t = t;
+        }
+        __syncthreads();
+        if constexpr (TL) {
+          const unsigned long long t = __builtin_amdgcn_s_memtime();
+          tl_bar += t - tl_t;
+          tl_t = t;
+        }
       }
     }
     if constexpr (TL) tl_kend = tl_t;
