@@ -967,7 +967,7 @@ using namespace udaseg;
 extern "C" int udaseg_pack_frag_batched_f32x3(const float* w32, const float* wt32, void* packed, const int* table, int entries,
                                               void* stream) {
   UDASEG_CHECK_ARG(packed && table && entries > 0 && (w32 || wt32), "pack_frag_batched_f32x3: NULL pointer / no entries");
-  hipLaunchKernelGGL(pack_frag_batched_f32x3_kernel, dim3(64, (unsigned)entries), dim3(256), 0, as_stream(stream), w32, wt32,
+  hipLaunchKernelGGL(pack_frag_batched_f32x3_kernel, dim3(256, (unsigned)entries), dim3(256), 0, as_stream(stream), w32, wt32,
                      static_cast<__bf16*>(packed), table, f3_signs_on() ? 1 : 0);
   UDASEG_LAUNCH_CHECK("pack_frag_batched_f32x3 launch");
   return UDASEG_OK;
