@@ -19,6 +19,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_ovl -- 
 cp $(find $OUT/${TAG}_prof_ovl -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats_overlapped.csv
 python3 $ROOT/tools/trace_neighbors.py $OUT/${TAG}_prof_ovl > $OUT/${TAG}_step_gaps.txt 2>&1
 python3 $ROOT/tools/ddp_tail.py $(find $OUT/${TAG}_prof_ovl -name "*kernel_trace.csv" | head -1) > $OUT/${TAG}_step_tail.txt 2>&1
+python3 $ROOT/tools/step_timeline.py $(find $OUT/${TAG}_prof_ovl -name "*kernel_trace.csv" | head -1) > $OUT/${TAG}_step_timeline.txt 2>&1
 echo "overlapped stats done"
 UDASEG_SERIAL=1 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_fetch -- $BENCH > $OUT/${TAG}_pmc_fetch.log 2>&1 || exit 1
 echo "pmc fetch done"

@@ -19,6 +19,9 @@ def main():
     lo = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     hi = int(sys.argv[3]) if len(sys.argv) > 3 else len(step)
     qs = sorted({r["Queue_Id"] for r in step})
+    print("# tools/step_timeline.py on a rocprofv3 --kernel-trace of bench.py (two streams): every kernel of the last traced step in start")
+    print("# order -- index, start, end (us from the step's first kernel), duration, queue (q0 main, q1 side), symbol.  Durations inside")
+    print("# the step are stretched by what runs beside them (the single-stream statistics are in the kernel_stats_serial file).")
     for i, r in enumerate(step[lo:hi], lo):
         s, e = (int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - t0) / 1e3
         print(f"{i:4d} {s:9.1f} {e:9.1f} {e - s:7.1f}  q{qs.index(r['Queue_Id'])}  {short(r['Kernel_Name'])}")
