@@ -257,6 +257,14 @@ int udaseg_ce_fwd(const float* logits, const int64_t* target, int64_t pixels, in
 int udaseg_ce_bwd(const float* logits, const int64_t* target, const float* lse, const float* grad_out, int64_t pixels,
                   int classes, int ldc, float* dlogits, float* colsum_partials, float* colsum, void* stream);
 
+/* round 5: both in ONE pass over the logits (ldc <= 32): loss as udaseg_ce_fwd leaves it (bit for bit), dlogits / colsum as
+ * udaseg_ce_bwd leaves them for an upstream gradient of exactly 1 (bit for bit) -- what loss.backward() (train.py:343) passes.
+ * udaseg_scale_unless_one(x, count, x2, count2, g): x[i] *= *g, x2[j] *= *g unless the DEVICE scalar *g is 1 (then the launch
+ * returns at once): the backward of a loss whose gradient was made ahead of time (count % 4 == 0, count2 <= 256). */
+int udaseg_ce_fwd_bwd(const float* logits, const int64_t* target, int64_t pixels, int classes, int ldc, double* partials, float* loss,
+                      float* dlogits, float* colsum_partials, float* colsum, void* stream);
+int udaseg_scale_unless_one(float* x, int64_t count, float* x2, int count2, const float* g, void* stream);
+
 /* ---- the reference's other segmentation losses (src/models/losses.py), same logits layout as udaseg_ce_* (ldc <= 32) ----
  * udaseg_seg_partials(): doubles of scratch the *_fwd calls below need in `partials`. */
 int udaseg_seg_partials(void);

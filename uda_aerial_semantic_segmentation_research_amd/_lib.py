@@ -79,6 +79,8 @@ SIGNATURES = {
     "udaseg_ce_partials": (_I, []),
     "udaseg_ce_fwd": (_I, [_P, _P, _L, _I, _I, _P, _P, _P, _P]),
     "udaseg_ce_bwd": (_I, [_P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _P]),
+    "udaseg_ce_fwd_bwd": (_I, [_P, _P, _L, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "udaseg_scale_unless_one": (_I, [_P, _L, _P, _I, _P, _P]),
     "udaseg_seg_partials": (_I, []),
     "udaseg_dice_fwd": (_I, [_P, _P, _I, _L, _I, _I, _F, _F, _I, _P, _P, _P, _P]),
     "udaseg_gap_linear_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),

@@ -255,6 +255,10 @@ OPERANDS = {
     "udaseg_ce_bwd": [T("logits", f32, "pixels*ldc"), T("target", i64, "pixels"), T("lse", f32, "pixels"), T("grad_out", f32, 1, True),
                       I("pixels"), I("classes"), I("ldc"), T("dlogits", f32, "pixels*ldc"),
                       T("colsum_partials", f32, "ce_partials()*ldc", True), T("colsum", f32, "ldc", True), S],
+    "udaseg_ce_fwd_bwd": [T("logits", f32, "pixels*ldc"), T("target", i64, "pixels"), I("pixels"), I("classes"), I("ldc"),
+                          T("partials", f64, "ce_partials()"), T("loss", f32, 1), T("dlogits", f32, "pixels*ldc"),
+                          T("colsum_partials", f32, "ce_partials()*ldc", True), T("colsum", f32, "ldc", True), S],
+    "udaseg_scale_unless_one": [T("x", f32, "count"), I("count"), T("x2", f32, "count2", True), I("count2"), T("g", f32, 1), S],
     "udaseg_argmax_confusion": [T("logits", f32, "pixels*ldc"), T("target", i64, "pixels"), I("pixels"), I("classes"), I("ldc"),
                                 T("confusion", i64, "classes*classes"), T("pred", i64, "pixels", True), S],
     "udaseg_dice_fwd": [T("logits", f32, "batch*pix_per_image*ldc"), T("target", i64, "batch*pix_per_image"), I("batch"),

@@ -146,6 +146,99 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const f32x4* __restrict__ l
   }
 }
 
+// Forward and backward in ONE pass over the logits (round 5): the loss partials of ce_fwd_kernel (same pixel-to-thread map, same
+// block reduction: the loss is bit-identical) and the gradient of ce_bwd_kernel for an upstream gradient of 1 (scale 1 / pixels; same
+// expressions: bit-identical), through the same LDS tile with the same column sums.  The training step read the 200 MB of logits
+// twice (ce_fwd for the loss, ce_bwd for the gradient); loss.backward() hands this loss a gradient of exactly 1, and
+// scale_unless_one_kernel below covers every other caller.
+template <int LDC4>
+__global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(const f32x4* __restrict__ logits, const int64_t* __restrict__ target,
+                                                         int64_t pixels, int classes, double* __restrict__ partials,
+                                                         f32x4* __restrict__ dlogits, float* __restrict__ colpart) {
+  constexpr int LDC = LDC4 * 4;
+  constexpr int NG = 256 / LDC;
+  __shared__ __attribute__((aligned(16))) float tile[256 * LDC];
+  __shared__ float colred[NG * LDC];
+  __shared__ double red[4];
+  const int tid = threadIdx.x;
+  const float scale = 1.f / (float)pixels;
+  const int64_t nchunks = (pixels + 255) / 256;
+  const int cc = tid % LDC, rg = tid / LDC;
+  float colacc = 0.f;
+  double local = 0.0;
+  for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    const int64_t p = chunk * 256 + tid;
+    if (p < pixels) {
+      f32x4 v[LDC4];
+#pragma unroll
+      for (int k = 0; k < LDC4; ++k) v[k] = logits[p * LDC4 + k];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int k = 0; k < LDC4; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (k * 4 + e < classes) mx = fmaxf(mx, v[k][e]);
+      float sum = 0.f;
+      const int t = (int)target[p];
+      float xt = 0.f;
+#pragma unroll
+      for (int k = 0; k < LDC4; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (k * 4 + e < classes) {
+            sum += expf(v[k][e] - mx);
+            if (k * 4 + e == t) xt = v[k][e];
+          }
+      const float l = mx + logf(sum);
+      local += (double)(l - xt);
+#pragma unroll
+      for (int k = 0; k < LDC4; ++k) {
+        f32x4 g;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c = k * 4 + e;
+          g[e] = c < classes ? (expf(v[k][e] - l) - (c == t ? 1.f : 0.f)) * scale : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(tile + tid * LDC + k * 4) = g;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < LDC4; ++k) *reinterpret_cast<f32x4*>(tile + tid * LDC + k * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+    const int64_t base4 = chunk * 256 * LDC4, lim4 = pixels * LDC4;
+#pragma unroll
+    for (int it = 0; it < LDC4; ++it) {
+      const int idx = it * 256 + tid;
+      if (base4 + idx < lim4) dlogits[base4 + idx] = reinterpret_cast<const f32x4*>(tile)[idx];
+    }
+    if (colpart && rg < NG) {
+      for (int r = rg; r < 256; r += NG) colacc += tile[r * LDC + cc];
+    }
+    __syncthreads();
+  }
+  local = wave_sum_d(local);
+  if ((tid & 63) == 0) red[tid >> 6] = local;
+  if (colpart && rg < NG) colred[rg * LDC + cc] = colacc;
+  __syncthreads();
+  if (tid == 0) partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+  if (colpart && tid < LDC) {
+    float s = 0.f;
+    for (int g2 = 0; g2 < NG; ++g2) s += colred[g2 * LDC + tid];
+    colpart[(size_t)blockIdx.x * LDC + tid] = s;
+  }
+}
+
+// x[i] *= *g unless *g == 1 (then the launch returns at once: the gradient made for an upstream gradient of 1 is already right)
+__global__ void scale_unless_one_kernel(f32x4* __restrict__ x, int64_t n4, float* __restrict__ x2, int n2, const float* __restrict__ g) {
+  const float s = *g;
+  if (s == 1.f) return;
+  const int64_t T = (int64_t)gridDim.x * blockDim.x;
+  const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int64_t i = i0; i < n4; i += T) x[i] = x[i] * s;
+  if (x2 != nullptr && i0 < n2) x2[i0] *= s;
+}
+
 // colsum[c] (+)= sum over blocks of colpart[b][c]: one 256-thread block per column, fixed-order tree => deterministic
 __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ colpart, int nblocks, int ldc,
                                                             float* __restrict__ colsum, int accumulate) {
@@ -349,6 +442,49 @@ extern "C" int udaseg_ce_fwd(const float* logits, const int64_t* target, int64_t
   UDASEG_LAUNCH_CHECK("ce_fwd launch");
   hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(64), 0, st, partials, grid, pixels, loss);
   UDASEG_LAUNCH_CHECK("ce_finish launch");
+  return UDASEG_OK;
+}
+
+extern "C" int udaseg_ce_fwd_bwd(const float* logits, const int64_t* target, int64_t pixels, int classes, int ldc, double* partials,
+                                 float* loss, float* dlogits, float* colsum_partials, float* colsum, void* stream) {
+  UDASEG_CHECK_ARG(logits && target && partials && loss && dlogits, "ce_fwd_bwd: NULL pointer");
+  UDASEG_CHECK_ARG(pixels > 0 && classes > 0 && classes <= ldc && ldc % 4 == 0 && ldc <= 32,
+                   "ce_fwd_bwd: need 0 < classes <= ldc <= 32, ldc %% 4 == 0 (classes=%d ldc=%d)", classes, ldc);
+  UDASEG_CHECK_ARG((colsum == nullptr) == (colsum_partials == nullptr), "ce_fwd_bwd: colsum and colsum_partials come together");
+  hipStream_t st = as_stream(stream);
+  const int64_t nchunks = (pixels + 255) / 256;
+  const int grid = (int)(nchunks > CE_BLOCKS ? CE_BLOCKS : nchunks);
+#define CE_FB_CASE(L)                                                                                                    \
+  case L:                                                                                                                \
+    hipLaunchKernelGGL(ce_fwd_bwd_kernel<L>, dim3(grid), dim3(256), 0, st, (const f32x4*)logits, target, pixels, classes,  \
+                       partials, (f32x4*)dlogits, colsum_partials);                                                      \
+    break;
+  switch (ldc / 4) {
+    CE_FB_CASE(1) CE_FB_CASE(2) CE_FB_CASE(3) CE_FB_CASE(4) CE_FB_CASE(5) CE_FB_CASE(6) CE_FB_CASE(7) CE_FB_CASE(8)
+    default:
+      set_error("ce_fwd_bwd: unsupported ldc %d", ldc);
+      return UDASEG_E_UNSUPPORTED;
+  }
+#undef CE_FB_CASE
+  UDASEG_LAUNCH_CHECK("ce_fwd_bwd launch");
+  hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(64), 0, st, partials, grid, pixels, loss);
+  UDASEG_LAUNCH_CHECK("ce_finish launch");
+  if (colsum) {
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3(ldc), dim3(256), 0, st, colsum_partials, grid, ldc, colsum, 0);
+    UDASEG_LAUNCH_CHECK("colsum_finish launch");
+  }
+  return UDASEG_OK;
+}
+
+extern "C" int udaseg_scale_unless_one(float* x, int64_t count, float* x2, int count2, const float* g, void* stream) {
+  UDASEG_CHECK_ARG(x && g && count > 0 && count % 4 == 0 && count2 >= 0 && count2 <= 256 && (x2 != nullptr || count2 == 0),
+                   "scale_unless_one: bad arguments");
+  const int64_t n4 = count / 4;
+  int64_t grid = (n4 + 1023) / 1024;
+  if (grid > 2048) grid = 2048;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(scale_unless_one_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), (f32x4*)x, n4, x2, count2, g);
+  UDASEG_LAUNCH_CHECK("scale_unless_one launch");
   return UDASEG_OK;
 }
 

@@ -580,6 +580,18 @@ def ce_bwd(logits_base, target, lse, grad_out, pixels, classes, ldc, dlogits, co
                                      st), "ce_bwd")
 
 
+def ce_fwd_bwd(logits_base, target, pixels, classes, ldc, partials, loss, dlogits, colsum_partials=None, colsum=None, st=None):
+    """Loss and its gradient for an upstream gradient of 1 in ONE pass over the logits (ldc <= 32); both bit-identical to
+    ``ce_fwd`` / ``ce_bwd``."""
+    check(ops.udaseg_ce_fwd_bwd(logits_base, target, pixels, classes, ldc, partials, loss, dlogits, colsum_partials, colsum, st),
+          "ce_fwd_bwd")
+
+
+def scale_unless_one(x, g, x2=None, st=None):
+    """x *= g (and x2 *= g) unless the device scalar ``g`` is exactly 1: then the launch returns at once."""
+    check(ops.udaseg_scale_unless_one(x, x.numel(), x2, 0 if x2 is None else x2.numel(), g, st), "scale_unless_one")
+
+
 def seg_partials():
     return ops.udaseg_seg_partials()
 

@@ -9,6 +9,8 @@
   csrc/losses_seg.hip: one pass over the logits per direction, softmax rows in registers.
 """
 from typing import Dict, Optional
+import os
+
 import torch
 import torch.nn as nn
 
@@ -17,6 +19,8 @@ from ._lib import load as _load
 from .engine import ceil4
 
 
+# the training step's loss makes its gradient in the forward pass (one read of the logits instead of two); UDASEG_FUSE_CE=0: two passes
+FUSE_CE_BACKWARD = os.environ.get("UDASEG_FUSE_CE", "1") != "0"
 # data_ptr of the last dlogits buffer -> its per-class column sums (consumed once by Unet._backward_plan)
 COLSUM_SIDE_TABLE = {}
 
@@ -41,20 +45,44 @@ class _CrossEntropyFunction(torch.autograd.Function):
         tgt = target.contiguous()
         pixels = n * h * w
         dev = logits.device
-        lse = torch.empty(pixels, device=dev, dtype=torch.float32)
         partials = torch.empty(_load().udaseg_ce_partials(), device=dev, dtype=torch.float64)
         loss = torch.empty((), device=dev, dtype=torch.float32)
+        ctx.meta = (n, c, h, w, ldc)
+        ctx.fused = None
+        if FUSE_CE_BACKWARD and ldc <= 32 and ctx.needs_input_grad[0]:
+            # a training step: the gradient for an upstream gradient of 1 (what loss.backward() passes) is made in the SAME pass over
+            # the logits as the loss, with the head's bias gradient (column sums); backward() only scales it if it has to
+            dl = torch.empty((n, h, w, ldc), device=dev, dtype=torch.float32)
+            parts = torch.empty(_load().udaseg_ce_partials() * ldc, device=dev, dtype=torch.float32)
+            colsum = torch.empty(ldc, device=dev, dtype=torch.float32)
+            K.ce_fwd_bwd(buf, tgt, pixels, c, ldc, partials, loss, dl, parts, colsum)
+            ctx.fused = [dl, colsum]
+            ctx.save_for_backward(buf, tgt)
+            return loss
+        lse = torch.empty(pixels, device=dev, dtype=torch.float32)
         K.ce_fwd(buf, tgt, pixels, c, ldc, lse, partials, loss)
         ctx.save_for_backward(buf, tgt, lse)
-        ctx.meta = (n, c, h, w, ldc)
         return loss
 
     @staticmethod
     def backward(ctx, grad_out):
-        buf, tgt, lse = ctx.saved_tensors
         n, c, h, w, ldc = ctx.meta
-        dl = torch.empty((n, h, w, ldc), device=buf.device, dtype=torch.float32)
         g = grad_out.detach().to(torch.float32).contiguous()
+        if ctx.fused is not None:
+            dl, colsum = ctx.fused
+            ctx.fused = None                           # consumed (a second backward through a retained graph takes the two-pass route)
+            K.scale_unless_one(dl, g, colsum)
+            COLSUM_SIDE_TABLE.clear()
+            COLSUM_SIDE_TABLE[dl.data_ptr()] = colsum
+            return dl.permute(0, 3, 1, 2)[:, :c], None
+        if len(ctx.saved_tensors) == 2:                # fused forward, second backward: recompute the log-sum-exp
+            buf, tgt = ctx.saved_tensors
+            lse = torch.empty(n * h * w, device=buf.device, dtype=torch.float32)
+            K.ce_fwd(buf, tgt, n * h * w, c, ldc, lse, torch.empty(_load().udaseg_ce_partials(), device=buf.device, dtype=torch.float64),
+                     torch.empty((), device=buf.device, dtype=torch.float32))
+        else:
+            buf, tgt, lse = ctx.saved_tensors
+        dl = torch.empty((n, h, w, ldc), device=buf.device, dtype=torch.float32)
         out = dl.permute(0, 3, 1, 2)[:, :c]
         if ldc <= 32:
             # per-class sums of the gradient come out of the same pass: the head conv's bias gradient (Unet's backward
