@@ -25,11 +25,15 @@ SIDE_STREAM_WGRAD = os.environ.get("UDASEG_SERIAL", "0") != "1"
 # BatchNorm-backward reductions of single-consumer activations in the consumer's data-gradient epilogue (UDASEG_FUSE_BN_REDUCE=0:
 # always the stand-alone reduce kernel; tests flip the module attribute to cross-check)
 FUSE_BN_REDUCE = os.environ.get("UDASEG_FUSE_BN_REDUCE", "1") != "0"
-# UDASEG_PREPACK=1: the per-step repack of the weights for the data-gradient kernels runs on the side stream during the
-# forward instead of on the main stream in front of the backward.  Measured in one A/B run (profiles/r02_ab_prepack_bnreduce.txt):
-# 645.3 / 646.1 images/s with it against 648.4 / 650.8 without -- the 0.1 ms pass competes with the forward convolutions for
-# HBM and costs more than it hides; off by default.
-PREPACK_DGRAD = os.environ.get("UDASEG_PREPACK", "0") == "1"
+# The backward pass needs the weights in three more packings (the data-gradient transpose, its fragment packing, the phase packing:
+# 20 + 27 + 14 us in front of the first data gradient).  They depend on the weights alone, which are final once the optimizer has
+# stepped: UDASEG_PREPACK=2 (default) issues all three on the side stream at the START of the forward, where they run beside the stem
+# and the first encoder blocks (matrix-pipe-bound) -- cfg 2 1026.9 -> 1033.5 images/s over four alternations, the bf16 legs unchanged
+# (profiles/r05_prepack.txt).  History: round 2 measured the transpose alone there at -0.4 % (a 0.1 ms element-wise pass then); this
+# round's first attempt put the three beside the LOSS kernels, which are HBM-bound like they are: neutral.  =1: the transpose only
+# (+0.1 %); =0: everything on the main stream in front of the backward (A/B).
+PREPACK_DGRAD = os.environ.get("UDASEG_PREPACK", "2") in ("1", "2")
+PREPACK_ALL = os.environ.get("UDASEG_PREPACK", "2") == "2"       # also the backward's fragment / phase packings
 # bf16 storage: the stride-1 3x3 / 1x1 convolutions run on the bf16-first kernels (halo staged once, fragment-packed weights);
 # UDASEG_FRAG=0 keeps them on the shared implicit-GEMM source (A/B, cross-check; tests flip the module attribute)
 USE_FRAG_KERNELS = os.environ.get("UDASEG_FRAG", "1") != "0"
@@ -555,6 +559,7 @@ class Plan:
         self._bstat_off = 0
         self.conv_flops = 0.0
         self._packed = None
+        self._packed_all = False
         self._bnb = {}                    # id(conv output y) -> BN-backward sums already made by the consumer's data gradient
         self._producer = {}               # id(activation) -> the conv+BN+activation record that produced it (decoder block outputs)
         self._pre = {}                    # id(decoder conv1) -> (y holding its skip half, side stream handle): prelaunch_skip
@@ -573,6 +578,13 @@ class Plan:
         main, side = torch.cuda.current_stream(), net._side_stream()
         side.wait_stream(main)                      # the optimizer step / load_state_dict that produced the weights
         K.pack_dgrad_batched(net._arena, net._wt_arena, net._wt_table, side.cuda_stream)
+        if PREPACK_ALL:
+            # ... and the two fragment packings made from it (fp32 split / bf16 kernels): everything the backward pass needs of the weights
+            if self.frag and net._frag_bwd_table is not None:
+                K.pack_frag_batched(None, net._wt_arena, net._frag_arena, net._frag_bwd_table, side.cuda_stream)
+            if self.frag and getattr(net, "_up_bwd_table", None) is not None:
+                K.pack_up_batched(None, net._wt_arena, net._frag_arena, net._up_bwd_table, side.cuda_stream)
+            self._packed_all = True
         self._packed = torch.cuda.Event()
         self._packed.record(side)
 
@@ -912,9 +924,9 @@ class Plan:
             self.main_stream.wait_event(self._packed)
         else:
             K.pack_dgrad_batched(net._arena, net._wt_arena, net._wt_table, self.st)
-        if self.frag and net._frag_bwd_table is not None:
+        if self.frag and net._frag_bwd_table is not None and not self._packed_all:
             K.pack_frag_batched(None, net._wt_arena, net._frag_arena, net._frag_bwd_table, self.st)
-        if self.frag and getattr(net, "_up_bwd_table", None) is not None:
+        if self.frag and getattr(net, "_up_bwd_table", None) is not None and not self._packed_all:
             K.pack_up_batched(None, net._wt_arena, net._frag_arena, net._up_bwd_table, self.st)
         if self.side_stream is not None:
             self.side_stream.wait_stream(self.main_stream)      # zeroed gradient arena is visible to the side stream
