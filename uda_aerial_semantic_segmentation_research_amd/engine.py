@@ -556,6 +556,7 @@ class Plan:
         self._stat_off = 0
         self.garena = None
         self.bstats = None
+        self._zeroed_early = False
         self._bstat_off = 0
         self.conv_flops = 0.0
         self._packed = None
@@ -585,6 +586,12 @@ class Plan:
             if self.frag and getattr(net, "_up_bwd_table", None) is not None:
                 K.pack_up_batched(None, net._wt_arena, net._frag_arena, net._up_bwd_table, side.cuda_stream)
             self._packed_all = True
+            # ... and the zeroed gradient arena / BatchNorm-backward sums of this step (two fills that sat in front of the backward)
+            self.garena = K.zeros_like(net._arena, side.cuda_stream)
+            self.garena.record_stream(side)
+            self.bstats = K.zeros((max(net._nbn, 2) * self.R,), torch.float64, self.dev, side.cuda_stream)
+            self.bstats.record_stream(side)
+            self._zeroed_early = True
         self._packed = torch.cuda.Event()
         self._packed.record(side)
 
@@ -912,9 +919,12 @@ class Plan:
         # weight gradients are off the backward critical path (only Adam / the all-reduce consume them): they run on a
         # side HIP stream and fill the matrix cores while the main chain sits in HBM-bound BatchNorm-backward kernels
         self.side_stream = net._side_stream() if SIDE_STREAM_WGRAD else None
-        self.garena = K.zeros_like(net._arena, self.st)
         nbn = net._nbn
-        self.bstats = K.zeros((max(nbn, 2) * self.R,), torch.float64, self.dev, self.st)
+        if self._zeroed_early:                      # zeroed on the side stream with the early packings (_prepack_dgrad_weights): once
+            self._zeroed_early = False
+        else:
+            self.garena = K.zeros_like(net._arena, self.st)
+            self.bstats = K.zeros((max(nbn, 2) * self.R,), torch.float64, self.dev, self.st)
         self._side_h = self.side_stream.cuda_stream if self.side_stream is not None else None
         self._main_h = self.main_stream.cuda_stream
         self._bstat_off = 0
